@@ -1,0 +1,499 @@
+"""CPU oracle for the g3py GP-inference hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module; the product (`g3py_amd`) never does.
+
+What it is: a NumPy/SciPy restatement of the reference's formulas for the path in
+SURVEY.md section 8(a), rows 1-14, using the same LAPACK entry points the reference
+calls (`scipy.linalg.lapack.dpotrf`, `scipy.linalg.solve`, `solve_triangular`).
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).
+
+Pinning status (see DESIGN.md "Oracle"):
+  * PINNED against the reference's own executable NumPy prototype `sandbox/gpmm.py`
+    (imported in the build container by `oracle/gen_golden.py`; outputs committed under
+    `tests/golden/gpmm_*.npz`): SE(+noise) and OU(+noise) Gram, Cholesky factor,
+    log marginal likelihood, posterior mean / variance / covariance.
+  * The main Theano/PyMC3 path cannot be imported here (ModuleNotFoundError: theano,
+    pymc3 -- an ordinary error, not a permission denial) and the reference ships no
+    tests or golden vectors, so for everything else (MAT32/MAT52/RQ/periodic kernels,
+    warped GP, Gauss-Hermite, jitter schedule) the restatement is "parity unpinned" by
+    the reference and is pinned by analytic known-answer tests in tests/test_oracle.py.
+
+dtype: the reference graph is hard-wired float32 (g3py/config.py:4,9) with the Cholesky
+done in float64 and cast back (g3py/libs/tensors.py:198,219).  `dtype=np.float64`
+(default) is the fp64 restatement the build is compared with; `dtype=np.float32`
+reproduces the float32-graph / fp64-dpotrf behaviour.
+
+Kernel "spec" format (plain nested tuples, natural-space hyper-parameters):
+    ('SE', var, rate[d], dims)      ('OU', var, rate[d], dims)
+    ('MAT32', var, rate[d], dims)   ('MAT52', var, rate[d], dims)
+    ('RQ', var, rate[d], alpha, dims)
+    ('COS', var, freq[d], dims)     ('SIN', var, freq[d], rate[d], dims)
+    ('SINC', var, freq[d], dims)    ('SM', var, freq[d], rate[d], dims)
+    ('NOISE', var)                  ('WN', var, dims)
+    ('sum', a, b) ('prod', a, b) ('scale', c, a) ('shift', c, a)
+`dims` is None (all columns) or an index array (hypers/__init__.py:55-83).
+"""
+import numpy as np
+import scipy as sp
+import scipy.linalg
+import scipy.linalg.lapack
+from scipy import stats
+
+pi = np.pi
+pi2 = np.pi ** 2
+
+
+# --------------------------------------------------------------------------- metrics
+def _cols(x, dims):
+    """x[:, self.dims] -- g3py/processes/hypers/metrics.py:11-13."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    return x if dims is None else x[:, dims]
+
+
+def _diff(x1, x2, dims):
+    """Broadcast difference x1[:,None,:]-x2[None,:,:] -- metrics.py:11-13, 59-61."""
+    return _cols(x1, dims)[:, None, :] - _cols(x2, dims)[None, :, :]
+
+
+def ard_l2(x1, x2, rate, dims=None):
+    """dot((x1-x2)**2, 0.5*rate**2) -- metrics.py:100-102."""
+    d = _diff(x1, x2, dims)
+    rate = np.asarray(rate, dtype=d.dtype)
+    return np.dot(d ** 2, d.dtype.type(0.5) * rate ** 2)
+
+
+def ard_l1(x1, x2, rate, dims=None):
+    """dot(|x1-x2|, rate) -- metrics.py:89-91."""
+    d = _diff(x1, x2, dims)
+    return np.dot(np.abs(d), np.asarray(rate, dtype=d.dtype))
+
+
+def delta(x1, x2, dims=None):
+    """tt_to_num(eq(x1-x2, 0).sum(axis=2)) -- metrics.py:30-35."""
+    d = _diff(x1, x2, dims)
+    return tt_to_num((d == 0).sum(axis=2).astype(d.dtype))
+
+
+# --------------------------------------------------------------------------- scrubs
+def tt_to_num(r, nan=0.0, inf=1e10):
+    """NaN -> 0, +-Inf -> 1e10 -- g3py/libs/tensors.py:90-92 (both infinities map to +1e10)."""
+    r = np.asarray(r)
+    t = r.dtype.type
+    return np.where(np.isnan(r), t(nan), np.where(np.isinf(r), t(np.float32(inf)), r))
+
+
+def tt_to_cov(c):
+    """tt_to_num then lift the diagonal if min(diag) <= 0 -- tensors.py:95-98."""
+    r = tt_to_num(c)
+    t = r.dtype.type
+    m = np.min(np.diag(r))
+    if m > 0:
+        return r
+    return r + (t(np.float32(1e-6)) - m) * np.eye(r.shape[0], dtype=r.dtype)
+
+
+def tt_to_bounded(r, lower=None, upper=None):
+    """clamp -- tensors.py:101-108."""
+    r = np.asarray(r)
+    if lower is None and upper is None:
+        return r
+    if lower is None:
+        return np.where(r > upper, upper, r)
+    if upper is None:
+        return np.where(r < lower, lower, r)
+    return np.where(r < lower, lower, np.where(r > upper, upper, r))
+
+
+# --------------------------------------------------------------------------- kernels
+def kernel_cov(spec, x1, x2=None, dtype=np.float64):
+    """Kernel.cov(x1, x2=None) for a spec tree -- kernels.py:96-110,192-244,360-487."""
+    x1 = np.asarray(x1, dtype=dtype)
+    if x1.ndim == 1:
+        x1 = x1[:, None]
+    sym = x2 is None
+    xb = x1 if sym else np.asarray(x2, dtype=dtype)
+    if xb.ndim == 1:
+        xb = xb[:, None]
+    t = np.dtype(dtype).type
+    op = spec[0]
+    if op == 'sum':      # kernels.py:240-241
+        return kernel_cov(spec[1], x1, x2, dtype) + kernel_cov(spec[2], x1, x2, dtype)
+    if op == 'prod':     # kernels.py:225-226
+        return kernel_cov(spec[1], x1, x2, dtype) * kernel_cov(spec[2], x1, x2, dtype)
+    if op == 'scale':    # kernels.py:196-197
+        return t(spec[1]) * kernel_cov(spec[2], x1, x2, dtype)
+    if op == 'shift':    # kernels.py:207-208
+        return t(spec[1]) + kernel_cov(spec[2], x1, x2, dtype)
+    var = t(spec[1])
+    if op == 'NOISE':    # kernels.py:367-371: var*I when square, zeros for cross
+        if sym:
+            return var * np.eye(x1.shape[0], dtype=dtype)
+        return np.zeros((x1.shape[0], xb.shape[0]), dtype=dtype)
+    if op == 'WN':       # kernels.py:381-385: var*I when square, var*Delta.gram for cross
+        if sym:
+            return var * np.eye(x1.shape[0], dtype=dtype)
+        return var * delta(x1, xb, spec[2])
+    if op in ('SE', 'MAT32', 'MAT52'):
+        d = ard_l2(x1, xb, np.asarray(spec[2], dtype=dtype), spec[3])
+        if op == 'SE':       # kernels.py:424-426
+            return var * np.exp(-d)
+        if op == 'MAT32':    # kernels.py:410-412
+            d3 = np.sqrt(t(3) * d)
+            return var * ((t(1) + d3) * np.exp(-d3))
+        d5 = np.sqrt(t(5) * d)   # kernels.py:419-421
+        return var * ((t(1) + d5 + t(5) * d / t(3)) * np.exp(-d5))
+    if op == 'OU':       # kernels.py:429-431 (ARD_L1 metric)
+        return var * np.exp(-ard_l1(x1, xb, np.asarray(spec[2], dtype=dtype), spec[3]))
+    if op == 'RQ':       # kernels.py:402-403
+        d = ard_l2(x1, xb, np.asarray(spec[2], dtype=dtype), spec[4])
+        alpha = t(spec[3])
+        return var * np.power(t(1) + d / alpha, -alpha)
+    if op == 'COS':      # kernels.py:466-467
+        d = _diff(x1, xb, spec[3])
+        f = np.asarray(spec[2], dtype=dtype)
+        return var * np.prod(np.cos(t(2 * pi) * d * f), axis=2)
+    if op == 'SIN':      # kernels.py:471-472 (positive exponent, as written)
+        d = _diff(x1, xb, spec[4])
+        f = np.asarray(spec[2], dtype=dtype)
+        r = np.asarray(spec[3], dtype=dtype)
+        return var * np.exp(t(2) * np.dot(np.sin(t(pi) * d * f) ** 2, r))
+    if op == 'SINC':     # kernels.py:479-482
+        d = _diff(x1, xb, spec[3])
+        f = np.asarray(spec[2], dtype=dtype)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            sinc = np.sin(t(2 * pi2) * d * f) / (t(2 * pi2) * f * d)
+        return var * np.prod(np.where(d != 0, sinc, t(1)), axis=2)
+    if op == 'SM':       # kernels.py:486-487
+        d = _diff(x1, xb, spec[4])
+        f = np.asarray(spec[2], dtype=dtype)
+        r = np.asarray(spec[3], dtype=dtype)
+        return var * (np.exp(t(-2 * pi2) * np.dot(d ** 2, r ** 2)) *
+                      np.prod(np.cos(t(2 * pi) * d * f), axis=2))
+    raise ValueError('unknown kernel spec ' + str(op))
+
+
+def with_noise(spec_f, noise_var):
+    """KernelSum(kernel, KernelNoise('Noise')) -- g3py/processes/elliptical.py:26-31."""
+    return ('sum', spec_f, ('NOISE', noise_var))
+
+
+# --------------------------------------------------------------------------- means
+def mean_eval(spec, x, dtype=np.float64):
+    """Zero / Bias / Linear -- g3py/processes/hypers/means.py:117-159."""
+    x = np.asarray(x, dtype=dtype)
+    if x.ndim == 1:
+        x = x[:, None]
+    op = spec[0]
+    if op == 'Zero':
+        return np.zeros(x.shape[0], dtype=dtype)
+    if op == 'Bias':
+        return np.dtype(dtype).type(spec[1]) * np.ones(x.shape[0], dtype=dtype)
+    if op == 'Linear':
+        xs = x if len(spec) < 4 or spec[3] is None else x[:, spec[3]]
+        return np.dtype(dtype).type(spec[1]) + np.dot(xs, np.asarray(spec[2], dtype=dtype))
+    raise ValueError('unknown mean spec ' + str(op))
+
+
+# --------------------------------------------------------------------------- mappings
+class Mapping:
+    """spec: ('Identity',) ('LinearMapping', shift, scale) ('LogShifted', shift)
+    ('BoxCoxLinear', shift, scale, power) ('ArcsinhLinear', shift, scale)
+    -- g3py/processes/hypers/mappings.py:88-215, 309-333."""
+
+    def __init__(self, spec, dtype=np.float64):
+        self.spec = spec
+        self.t = np.dtype(dtype).type
+
+    def __call__(self, x):
+        s, t = self.spec, self.t
+        x = np.asarray(x)
+        if s[0] == 'Identity':           # mappings.py:92-93
+            return x
+        if s[0] == 'LinearMapping':      # mappings.py:119-120
+            return t(s[2]) * (x - t(s[1]))
+        if s[0] == 'LogShifted':         # mappings.py:142-143
+            return np.exp(x) + t(s[1])
+        if s[0] == 'BoxCoxLinear':       # mappings.py:204-207
+            shift, scale, power = t(s[1]), t(s[2]), t(s[3])
+            scaled = power * x + t(1)
+            transformed = np.sign(scaled) * np.abs(scaled) ** (t(1) / power)
+            return transformed / scale - shift
+        if s[0] == 'ArcsinhLinear':      # mappings.py:326-327
+            return np.sinh((x - t(s[1])) / t(s[2]))
+        raise ValueError(s[0])
+
+    def inv(self, y):
+        s, t = self.spec, self.t
+        y = np.asarray(y)
+        if s[0] == 'Identity':           # mappings.py:95-96
+            return y
+        if s[0] == 'LinearMapping':      # mappings.py:122-123
+            return y / t(s[2]) + t(s[1])
+        if s[0] == 'LogShifted':         # mappings.py:145-146
+            return np.log(np.maximum(y - t(s[1]), t(np.float32(1e-32))))
+        if s[0] == 'BoxCoxLinear':       # mappings.py:209-211
+            shift, scale, power = t(s[1]), t(s[2]), t(s[3])
+            shifted = scale * (y + shift)
+            if power < np.float32(1e-5):
+                return np.log(shifted)
+            return ((np.sign(shifted) * np.abs(shifted) ** power) - t(1)) / power
+        if s[0] == 'ArcsinhLinear':      # mappings.py:329-330
+            return np.arcsinh(y) * t(s[2]) + t(s[1])
+        raise ValueError(s[0])
+
+    def logdet_dinv(self, y):
+        s, t = self.spec, self.t
+        y = np.asarray(y)
+        n = t(y.shape[0])
+        if s[0] == 'Identity':           # mappings.py:98-99
+            return t(0)
+        if s[0] == 'LinearMapping':      # mappings.py:125-126
+            return -n * np.log(t(s[2]))
+        if s[0] == 'LogShifted':         # mappings.py:148-149
+            return -np.sum(np.log(y - t(s[1])))
+        if s[0] == 'BoxCoxLinear':       # mappings.py:213-215
+            shift, scale, power = t(s[1]), t(s[2]), t(s[3])
+            return (power - t(1)) * np.sum(np.log(np.abs(scale * (y + shift)))) + n * np.log(scale)
+        if s[0] == 'ArcsinhLinear':      # mappings.py:332-333
+            return n * np.log(t(s[2])) - t(0.5) * np.sum(np.log1p(y ** 2))
+        raise ValueError(s[0])
+
+
+# --------------------------------------------------------------------------- Cholesky
+def cholesky_robust(K, maxtries=20, return_info=False):
+    """CholeskyRobust._cholesky + .perform -- g3py/libs/tensors.py:197-222.
+
+    dpotrf in float64 whatever K's dtype, result cast back to K.dtype (tensors.py:198,219).
+    Jitter schedule: dK = mean(diag)*1e-6*I; lift non-positive diagonals; retry up to 20
+    times with dK *= 10; final fallback 1e-10*I (tensors.py:203-221).
+    `return_info` additionally returns (tries, fallback) for tests."""
+    x = np.asarray(K)
+    tries, fallback = 0, False
+
+    def _cholesky(Kd):
+        nonlocal tries
+        L, info = sp.linalg.lapack.dpotrf(Kd, lower=True)
+        if info == 0:
+            return L
+        diagK = np.diag(Kd)
+        dK = np.eye(Kd.shape[0]) * diagK.mean() * np.float32(1e-6)
+        if np.any(diagK <= 0.0):
+            Kd = Kd + np.eye(Kd.shape[0]) * (diagK.mean() * np.float32(1e-6) - diagK.min())
+        for _ in range(maxtries):
+            tries += 1
+            try:
+                return np.nan_to_num(sp.linalg.cholesky(Kd + dK, lower=True))
+            except Exception:
+                dK = dK * np.float32(10)
+        raise sp.linalg.LinAlgError("not approximate positive-definite")
+
+    try:
+        z = _cholesky(x).astype(x.dtype)
+    except Exception:
+        fallback = True
+        z = (0 * x + np.float32(1e-10) * np.eye(len(x))).astype(x.dtype)
+    if return_info:
+        return z, tries, fallback
+    return z
+
+
+# --------------------------------------------------------------------------- logp
+def logp_cho(value, mu, cho, mapping):
+    """WarpedGaussianDistribution.logp_cho -- g3py/processes/gaussian.py:192-241."""
+    t = cho.dtype.type
+    delta_ = mapping.inv(value) - mu                                    # :208
+    if np.any(~np.isfinite(delta_)):                                    # cond1 :234
+        return t(np.float32(-1e30))
+    det_m = mapping.logdet_dinv(value)                                  # :225
+    if np.any(~np.isfinite(det_m)):                                     # cond2 :235
+        return t(np.float32(-1e30))
+    if np.any(~np.isfinite(cho)):                                       # cond3 :236
+        return t(np.float32(-1e30))
+    with np.errstate(all='ignore'):
+        lcho = sp.linalg.solve_triangular(cho, delta_, lower=True, check_finite=False)  # :212
+        lcho2 = lcho.T.dot(lcho)                                        # :215
+        npi = t(-0.5) * t(cho.shape[0]) * np.log(t(2.0 * np.pi))        # :218
+        dot2 = t(-0.5) * lcho2                                          # :219
+        det_k = -np.sum(np.log(np.diag(cho)))                           # :224
+        r = npi + dot2 + det_k + det_m                                  # :232
+    if np.any(~np.isfinite(lcho)):                                      # cond4 :237
+        return t(np.float32(-1e30))
+    return r
+
+
+def log_jacobian_positive(log_values):
+    """NonTransformLog.jacobian_det: 0 if exp(x) > 1e-6 else -inf -- hypers/__init__.py:199-200."""
+    v = np.atleast_1d(np.asarray(log_values))
+    return float(np.sum(np.where(np.exp(v) > 1e-6, 0.0, -np.inf)))
+
+
+# --------------------------------------------------------------------------- process
+class GP:
+    """EllipticalProcess.th_define_process + GaussianProcess / WarpedGaussianProcess methods.
+
+    kernel_f: spec of f_kernel; noise_var: None for noisy=False (elliptical.py:26-31);
+    mean: mean spec; mapping: mapping spec.  Follows elliptical.py:60-204,
+    gaussian.py:42-97,127-174, stochastic.py:294-313."""
+
+    def __init__(self, kernel_f, noise_var=None, mean=('Zero',), mapping=('Identity',),
+                 dtype=np.float64, log_positive_hypers=()):
+        self.kf = kernel_f
+        self.kn = kernel_f if noise_var is None else with_noise(kernel_f, noise_var)
+        self.mean_spec = mean
+        self.map = Mapping(mapping, dtype)
+        self.warped = mapping[0] != 'Identity'
+        self.dtype = dtype
+        self.t = np.dtype(dtype).type
+        self.log_positive_hypers = log_positive_hypers
+
+    # ---- basic tensors (elliptical.py:63-79)
+    def _x(self, a):
+        a = np.asarray(a, dtype=self.dtype)
+        return a[:, None] if a.ndim == 1 else a
+
+    def mapping_outputs(self, outputs):
+        return tt_to_num(self.map.inv(np.asarray(outputs, dtype=self.dtype)))   # :63
+
+    def prior_location(self, x):
+        return mean_eval(self.mean_spec, self._x(x), self.dtype)                # :67-68
+
+    def prior_kernel(self, x, noise):
+        if noise:
+            return tt_to_cov(kernel_cov(self.kn, self._x(x), None, self.dtype))  # :70-71
+        return kernel_cov(self.kf, self._x(x), None, self.dtype)                # :74-75
+
+    def cross_kernel(self, space, inputs, noise):
+        k = self.kn if noise else self.kf
+        return tt_to_num(kernel_cov(k, self._x(space), self._x(inputs), self.dtype))  # :78-79
+
+    # ---- selectors (elliptical.py:121-188)
+    def location(self, space, inputs=None, outputs=None, prior=False, noise=False):
+        if prior:
+            return self.prior_location(space)
+        c = self.cross_kernel(space, inputs, noise)
+        kin = self.prior_kernel(inputs, True)
+        rhs = self.mapping_outputs(outputs) - self.prior_location(inputs)
+        return self.prior_location(space) + c.dot(sp.linalg.solve(kin, rhs))    # :81-84
+
+    def kernel(self, space, inputs=None, prior=False, noise=False):
+        if prior:
+            return self.prior_kernel(space, noise)
+        c = self.cross_kernel(space, inputs, noise)
+        kin = self.prior_kernel(inputs, True)
+        return self.prior_kernel(space, noise) - c.dot(sp.linalg.solve(kin, c.T))  # :86-91
+
+    def cholesky(self, space, inputs=None, prior=False, noise=False):
+        return cholesky_robust(self.kernel(space, inputs, prior, noise))        # :72,76,88,92
+
+    def kernel_diag(self, space, inputs=None, prior=False, noise=False):
+        return tt_to_bounded(np.diag(self.kernel(space, inputs, prior, noise)), self.t(0))  # :94-97
+
+    def kernel_sd(self, space, inputs=None, prior=False, noise=False):
+        return np.sqrt(self.kernel_diag(space, inputs, prior, noise))           # :99-102
+
+    def cholesky_diag(self, space, inputs=None, prior=False, noise=False):
+        return np.diag(self.kernel_sd(space, inputs, prior, noise))             # :104-107
+
+    # ---- statistics
+    def gauss_hermite(self, f, mu, sigma, n=10):
+        """gaussian.py:162-174."""
+        _a, _w = np.polynomial.hermite.hermgauss(n)
+        a = _a.astype(self.dtype)[:, None]
+        w = _w.astype(self.dtype)
+        grille = mu + sigma * self.t(np.sqrt(2)) * a
+        return np.dot(w, f(grille.flatten()).reshape(grille.shape)) / self.t(np.sqrt(np.pi))
+
+    def mean(self, space, inputs=None, outputs=None, prior=False, noise=False):
+        loc = self.location(space, inputs, outputs, prior, noise)
+        if not self.warped:
+            return self.map(loc)                                                # elliptical.py:194-196
+        sd = self.kernel_sd(space, inputs, prior, noise)
+        return self.gauss_hermite(lambda v: self.map(v), loc, sd)               # gaussian.py:127-141
+
+    def median(self, space, inputs=None, outputs=None, prior=False, noise=False):
+        return self.map(self.location(space, inputs, outputs, prior, noise))    # elliptical.py:190-192
+
+    def variance(self, space, inputs=None, outputs=None, prior=False, noise=False):
+        if not self.warped:
+            return self.kernel_diag(space, inputs, prior, noise)                # elliptical.py:198-200
+        loc = self.location(space, inputs, outputs, prior, noise)
+        sd = self.kernel_sd(space, inputs, prior, noise)
+        return (self.gauss_hermite(lambda v: self.map(v) ** 2, loc, sd)
+                - self.mean(space, inputs, outputs, prior, noise) ** 2)         # gaussian.py:143-157
+
+    def std(self, *a, **k):
+        return np.sqrt(self.variance(*a, **k))                                  # stochastic.py:294-298
+
+    def covariance(self, space, inputs=None, prior=False, noise=False):
+        return self.kernel(space, inputs, prior, noise)                         # elliptical.py:202-204
+
+    def quantiler(self, space, inputs=None, outputs=None, q=0.975, prior=False, noise=False):
+        p = stats.norm.ppf(q)                                                   # gaussian.py:71-73
+        return self.map(self.location(space, inputs, outputs, prior, noise)
+                        + p * self.kernel_sd(space, inputs, prior, noise))
+
+    def sampler(self, space, inputs=None, outputs=None, rand=None, prior=False, noise=False):
+        """gaussian.py:89-97 with the normal draws `rand` (len(space) x samples) supplied."""
+        g = (self.location(space, inputs, outputs, prior, noise)[:, None]
+             + self.cholesky(space, inputs, prior, noise).dot(rand))
+        return np.array([self.map(k.T) for k in g.T]).T
+
+    def logpredictive(self, vector, space, inputs=None, outputs=None, prior=False, noise=False):
+        """gaussian.py:42-54: independent marginals, diagonal 'cholesky' with noise=True."""
+        return logp_cho(np.asarray(vector, dtype=self.dtype),
+                        self.location(space, inputs, outputs, prior, noise),
+                        self.cholesky_diag(space, inputs, prior, True), self.map)
+
+    def loglike(self, inputs, outputs):
+        """observed RV term -- gaussian.py:37-40,243-260; stochastic.py:311-313."""
+        cho = cholesky_robust(self.prior_kernel(inputs, True))
+        return logp_cho(np.asarray(outputs, dtype=self.dtype), self.prior_location(inputs), cho, self.map)
+
+    def logp(self, inputs=None, outputs=None, prior=False):
+        """stochastic.py:300-306: Flat priors contribute 0 plus the log-transform Jacobian
+        (hypers/__init__.py:199-200); observed term unless prior=True."""
+        lp = sum(log_jacobian_positive(v) for v in self.log_positive_hypers)
+        if prior:
+            return self.t(lp)
+        return self.t(lp) + self.loglike(inputs, outputs)
+
+
+# --------------------------------------------------------------------------- CPU baseline
+def cpu_hot_path(X, y, Xs, var=1.0, rate=1.0, noise=0.1):
+    """One pass of the benchmark hot path on the CPU (bench.py `cpu_baseline`, kind "port"):
+    SE Gram + dpotrf + triangular solves for logp, posterior mean and variance, using the
+    LAPACK entry points the reference calls.  Cholesky-based posterior (same algebra as the
+    HIP path) so the two are timed doing the same work.  Returns (logp, mean, var, timings)."""
+    import time
+    t0 = time.perf_counter()
+    N, d = X.shape
+    r = np.full(d, rate)
+    # tiled Gram (the reference's N x N x d broadcast would not fit at bench sizes)
+    w = 0.5 * r ** 2
+    Xw = X * np.sqrt(w)
+    sq = (Xw ** 2).sum(1)
+    K = sq[:, None] + sq[None, :] - 2.0 * Xw.dot(Xw.T)
+    np.maximum(K, 0.0, out=K)
+    np.exp(-K, out=K)
+    K *= var
+    K[np.diag_indices(N)] += noise
+    t1 = time.perf_counter()
+    L, info = sp.linalg.lapack.dpotrf(K, lower=True, overwrite_a=True)
+    assert info == 0
+    t2 = time.perf_counter()
+    a = sp.linalg.solve_triangular(L, y, lower=True, check_finite=False)
+    logp = -0.5 * N * np.log(2 * np.pi) - 0.5 * a.dot(a) - np.sum(np.log(np.diag(L)))
+    t3 = time.perf_counter()
+    Xsw = Xs * np.sqrt(w)
+    sqs = (Xsw ** 2).sum(1)
+    Ks = var * np.exp(-np.maximum(sqs[:, None] + sq[None, :] - 2.0 * Xsw.dot(Xw.T), 0.0))
+    V = sp.linalg.solve_triangular(L, Ks.T, lower=True, check_finite=False)
+    mean = V.T.dot(a)
+    varp = np.maximum(var - (V ** 2).sum(0), 0.0)
+    t4 = time.perf_counter()
+    return logp, mean, varp, dict(gram=t1 - t0, potrf=t2 - t1, logp=t3 - t2, predict=t4 - t3,
+                                  total=t4 - t0)

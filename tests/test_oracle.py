@@ -1,0 +1,175 @@
+"""CPU tests: pin oracle/g3_oracle.py against the reference's own gpmm.py outputs (committed
+fixtures) and against analytic known answers."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+from oracle import g3_oracle as orc
+
+
+def _gpmm_cases(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, 'gpmm_*.npz')))
+
+
+def test_gpmm_fixtures_exist(golden_dir):
+    assert len(_gpmm_cases(golden_dir)) == 4
+
+
+@pytest.mark.parametrize('name', ['se_d1', 'se_d3', 'se_d4', 'ou_d2'])
+def test_oracle_matches_gpmm(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, 'gpmm_%s.npz' % name))
+    kind = str(g['kind'])
+    spec = (kind, float(g['var']), g['rate'], None)
+    gp = orc.GP(kernel_f=spec, noise_var=float(g['noise']))
+    X, y, Xs = g['X'], g['y'], g['Xs']
+    K = gp.prior_kernel(X, noise=True)
+    np.testing.assert_allclose(K, g['K'], rtol=1e-13, atol=1e-15)
+    L = orc.cholesky_robust(K)
+    np.testing.assert_allclose(L, g['L'], rtol=1e-10, atol=1e-13)
+    lp = gp.logp(X, y)
+    assert abs(lp - float(g['logp'])) <= 1e-11 * abs(float(g['logp']))
+    # the reference main path uses an LU solve (elliptical.py:81-91); gpmm uses Cholesky solves
+    np.testing.assert_allclose(gp.mean(Xs, X, y), g['mean'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(gp.kernel(Xs, X), g['covariance'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(gp.variance(Xs, X, y), np.maximum(g['variance'], 0), rtol=1e-8, atol=1e-11)
+
+
+def test_kat_n1_n2_closed_form():
+    # N=1: logp = -0.5 log(2 pi (v+s)) - y^2 / (2 (v+s))
+    v, s, y = 1.7, 0.3, 0.8
+    gp = orc.GP(('SE', v, np.array([1.0]), None), noise_var=s)
+    lp = gp.logp(np.array([[0.2]]), np.array([y]))
+    assert abs(lp - (-0.5 * np.log(2 * np.pi * (v + s)) - y * y / (2 * (v + s)))) < 1e-14
+    # N=2 closed form through the 2x2 determinant / inverse
+    x = np.array([[0.0], [0.9]])
+    yy = np.array([0.3, -0.4])
+    rate = 1.3
+    k = v * np.exp(-0.5 * rate ** 2 * 0.81)
+    S = np.array([[v + s, k], [k, v + s]])
+    ref = -np.log(2 * np.pi) - 0.5 * np.log(np.linalg.det(S)) - 0.5 * yy.dot(np.linalg.solve(S, yy))
+    gp = orc.GP(('SE', v, np.array([rate]), None), noise_var=s)
+    assert abs(gp.logp(x, yy) - ref) < 1e-13
+
+
+def test_kat_noise_only():
+    rng = np.random.default_rng(0)
+    n, s = 37, 0.45
+    y = rng.standard_normal(n)
+    gp = orc.GP(('scale', 0.0, ('SE', 1.0, np.array([1.0]), None)), noise_var=s)
+    ref = -0.5 * n * np.log(2 * np.pi * s) - y.dot(y) / (2 * s)
+    assert abs(gp.logp(rng.standard_normal((n, 1)), y) - ref) < 1e-12
+
+
+def test_kat_interpolation_and_limits():
+    rng = np.random.default_rng(1)
+    X = rng.uniform(0, 5, (20, 2))
+    y = np.sin(X.sum(1))
+    gp = orc.GP(('SE', 1.0, np.array([1.0, 1.0]), None), noise_var=1e-10)
+    np.testing.assert_allclose(gp.mean(X[:5], X, y), y[:5], atol=1e-5)
+    # RQ -> SE as alpha -> inf ; MAT kernels at d=0 equal var
+    a = orc.kernel_cov(('RQ', 1.2, np.array([0.7, 0.9]), 1e7, None), X)
+    b = orc.kernel_cov(('SE', 1.2, np.array([0.7, 0.9]), None), X)
+    np.testing.assert_allclose(a, b, rtol=1e-4)
+    for k in ('MAT32', 'MAT52'):
+        np.testing.assert_allclose(np.diag(orc.kernel_cov((k, 0.9, np.array([1.0, 1.0]), None), X)), 0.9)
+    # COS in d=1 has rank 2 (cos(a-b) = cos a cos b + sin a sin b)
+    x1 = rng.uniform(0, 5, (30, 1))
+    C = orc.kernel_cov(('COS', 1.0, np.array([0.3]), None), x1)
+    assert np.linalg.matrix_rank(C, tol=1e-10) == 2
+
+
+def test_half_factor_in_ard_l2():
+    # metrics.py:102: the 1/2 lives inside the metric, so MAT32 sees sqrt(3 * 0.5 * r^2 * dx^2)
+    x = np.array([[0.0], [2.0]])
+    r = 0.8
+    d = 0.5 * r * r * 4.0
+    k = orc.kernel_cov(('MAT32', 1.0, np.array([r]), None), x)[0, 1]
+    assert abs(k - (1 + np.sqrt(3 * d)) * np.exp(-np.sqrt(3 * d))) < 1e-15
+
+
+def test_noise_excluded_from_cross(golden_dir):
+    X = np.arange(6.0)[:, None]
+    spec = orc.with_noise(('SE', 1.0, np.array([1.0]), None), 0.5)
+    sq = orc.kernel_cov(spec, X)
+    cr = orc.kernel_cov(spec, X, X)       # coincident points, but cross => no noise (kernels.py:367-371)
+    np.testing.assert_allclose(np.diag(sq) - np.diag(cr), 0.5)
+
+
+def test_scrubs():
+    a = np.array([[np.nan, np.inf], [-np.inf, 2.0]])
+    r = orc.tt_to_num(a)
+    assert r[0, 0] == 0 and r[0, 1] == np.float32(1e10) and r[1, 0] == np.float32(1e10) and r[1, 1] == 2
+    c = np.array([[-0.5, 0.1], [0.1, 1.0]])
+    rc = orc.tt_to_cov(c)
+    np.testing.assert_allclose(np.diag(rc), [np.float32(1e-6), 1.0 + 0.5 + np.float32(1e-6)])
+    np.testing.assert_allclose(orc.tt_to_bounded(np.array([-1.0, 2.0]), 0.0), [0.0, 2.0])
+
+
+def test_jitter_schedule(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'oracle_jitter.npz'))
+    for i in (1, 2, 3, 4):
+        L, tries, fb = orc.cholesky_robust(g['K%d' % i], return_info=True)
+        np.testing.assert_allclose(L, g['L%d' % i], rtol=1e-12, atol=1e-14)
+        assert tries == int(g['tries%d' % i]) and fb == bool(g['fallback%d' % i])
+    # case 1: one jitter step mean(diag)*1e-6 rescues a rank-deficient PSD matrix
+    K = g['K1']
+    L = g['L1']
+    jit = np.diag(K).mean() * np.float32(1e-6)
+    np.testing.assert_allclose(L.dot(L.T), K + jit * np.eye(len(K)), atol=1e-10)
+    # case 4: final fallback is 1e-10 * I (tensors.py:221)
+    np.testing.assert_allclose(g['L4'], np.float32(1e-10) * np.eye(len(K)))
+
+
+def test_logp_sentinel():
+    gp = orc.GP(('SE', 1.0, np.array([1.0]), None), noise_var=0.1)
+    X = np.arange(5.0)[:, None]
+    y = np.array([0.1, np.inf, 0.2, 0.3, 0.4])
+    assert gp.logp(X, y) == np.float32(-1e30)
+    # log-transform Jacobian: exp(v) <= 1e-6 => -inf (hypers/__init__.py:199-200)
+    gp2 = orc.GP(('SE', 1.0, np.array([1.0]), None), noise_var=0.1, log_positive_hypers=[np.log(1e-7)])
+    assert gp2.logp(X, np.zeros(5)) == -np.inf
+
+
+def test_mappings_inverse_and_logdet():
+    y = np.linspace(0.5, 3.0, 11)
+    for spec in [('Identity',), ('LinearMapping', 0.2, 1.5), ('LogShifted', -0.5),
+                 ('BoxCoxLinear', 1.0, 0.7, 1.2), ('ArcsinhLinear', 0.1, 0.8)]:
+        m = orc.Mapping(spec)
+        np.testing.assert_allclose(m(m.inv(y)), y, rtol=1e-12)
+        # logdet_dinv == sum log |d inv / dy| by central differences
+        h = 1e-6
+        num = np.sum(np.log(np.abs((m.inv(y + h) - m.inv(y - h)) / (2 * h))))
+        assert abs(num - m.logdet_dinv(y)) < 1e-6
+
+
+def test_gauss_hermite_lognormal():
+    # E[exp(f)] for f ~ N(mu, s^2) is exp(mu + s^2/2); 10 nodes are ample for s = 0.3
+    gp = orc.GP(('SE', 1.0, np.array([1.0]), None), noise_var=0.1, mapping=('LogShifted', 0.0))
+    mu, s = np.array([0.2, -0.1]), np.array([0.3, 0.2])
+    got = gp.gauss_hermite(lambda v: gp.map(v), mu, s)
+    np.testing.assert_allclose(got, np.exp(mu + s ** 2 / 2), rtol=1e-9)
+
+
+def test_fp32_graph_mode_close_to_fp64():
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 4, (64, 2))
+    y = np.sin(X.sum(1))
+    a = orc.GP(('SE', 1.0, np.array([1.0, 1.0]), None), 0.1).logp(X, y)
+    b = orc.GP(('SE', 1.0, np.array([1.0, 1.0]), None), 0.1, dtype=np.float32).logp(
+        X.astype(np.float32), y.astype(np.float32))
+    assert b.dtype == np.float32 and abs(a - b) < 1e-3 * abs(a)
+
+
+def test_cpu_hot_path_matches_oracle():
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 4, (200, 4))
+    Xs = rng.uniform(0, 4, (16, 4))
+    y = np.sin(X.sum(1) / 2) + 0.1 * rng.standard_normal(200)
+    lp, mean, var, _ = orc.cpu_hot_path(X, y, Xs)
+    gp = orc.GP(('SE', 1.0, np.ones(4), None), 0.1)
+    assert abs(lp - gp.logp(X, y)) < 1e-9 * abs(lp)
+    np.testing.assert_allclose(mean, gp.mean(Xs, X, y), atol=1e-9)
+    np.testing.assert_allclose(var, gp.variance(Xs, X, y), atol=1e-9)
