@@ -1,0 +1,110 @@
+"""ctypes binding of libg3hip.so (the C ABI declared in include/g3hip.h).
+
+There is no CPU fallback: importing this module without the built library, or creating a
+context without a GPU, raises.  Build with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C g3py_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libg3hip.so')
+
+G3_MAXD, G3_MAXCOLS, G3_MAXLEAF, G3_MAXPROD, G3_MAXFAC = 32, 60, 8, 16, 4
+G3_F64, G3_F32 = 0, 1
+G3_GRAM_LOWER, G3_GRAM_SCRUB, G3_GRAM_PAD_EYE = 1, 2, 4
+G3_LEAF = 64
+KINDS = dict(SE=0, OU=1, MAT32=2, MAT52=3, RQ=4, COS=5, SIN=6, SINC=7, SM=8, NOISE=9, WN=10)
+
+
+class Leaf(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('ndims', C.c_int32), ('dims', C.c_int32 * G3_MAXD),
+                ('var', C.c_double), ('alpha', C.c_double),
+                ('rate', C.c_double * G3_MAXD), ('freq', C.c_double * G3_MAXD)]
+
+
+class Prod(C.Structure):
+    _fields_ = [('coef', C.c_double), ('nfac', C.c_int32), ('fac', C.c_int32 * G3_MAXFAC),
+                ('_pad', C.c_int32 * 3)]
+
+
+class KernelProg(C.Structure):
+    _fields_ = [('nleaf', C.c_int32), ('nprod', C.c_int32), ('shift', C.c_double),
+                ('leaf', Leaf * G3_MAXLEAF), ('prod', Prod * G3_MAXPROD)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_SIGS = {
+    'g3_version': ([], C.c_int),
+    'g3_ctx_create': ([C.c_int, C.POINTER(_P)], C.c_int),
+    'g3_ctx_destroy': ([_P], C.c_int),
+    'g3_ctx_set_stream': ([_P, _P], C.c_int),
+    'g3_ctx_sync': ([_P], C.c_int),
+    'g3_last_error': ([_P], C.c_char_p),
+    'g3_malloc': ([_P, C.c_size_t, C.POINTER(_P)], C.c_int),
+    'g3_free': ([_P, _P], C.c_int),
+    'g3_memcpy_h2d': ([_P, _P, _P, C.c_size_t], C.c_int),
+    'g3_memcpy_d2h': ([_P, _P, _P, C.c_size_t], C.c_int),
+    'g3_memcpy_d2d': ([_P, _P, _P, C.c_size_t], C.c_int),
+    'g3_memset': ([_P, _P, C.c_int, C.c_size_t], C.c_int),
+    'g3_copy2d': ([_P, _P, _I64, _P, _I64, _I64, _I64, C.c_int], C.c_int),
+    'g3_gram': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
+                 _I64, _I64, C.c_uint], C.c_int),
+    'g3_gram_diag': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, C.c_int, _P], C.c_int),
+    'g3_cov_lift': ([_P, _P, _I64, _I64, C.c_int], C.c_int),
+    'g3_scrub': ([_P, _P, _I64, _I64, _I64, C.c_int], C.c_int),
+    'g3_gemm_nt': ([_P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, C.c_double, C.c_double, C.c_int,
+                    C.c_int], C.c_int),
+    'g3_potrf': ([_P, _P, _I64, _I64, C.c_int, _P, C.POINTER(C.c_int)], C.c_int),
+    'g3_potrf_robust': ([_P, _P, _I64, _P, _I64, _I64, C.c_int, C.c_int, C.POINTER(C.c_int),
+                         C.POINTER(C.c_int), C.POINTER(C.c_double)], C.c_int),
+    'g3_trsm_rlt': ([_P, _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P], C.c_int),
+    'g3_logp_terms': ([_P, _P, _I64, _I64, _P, C.c_int, C.POINTER(C.c_double)], C.c_int),
+    'g3_diag_stats': ([_P, _P, _I64, _I64, C.c_int, C.POINTER(C.c_double)], C.c_int),
+    'g3_diag_add': ([_P, _P, _I64, _I64, C.c_int, C.c_double], C.c_int),
+    'g3_rows_dot_ss': ([_P, _P, _I64, _I64, _I64, _P, C.c_int, _P, _P], C.c_int),
+    'g3_gp_factor': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, _P, C.c_int, _P, _I64, _P,
+                      C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P,
+                     C.c_int, _P, _I64, _P, _P], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class G3Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load libg3hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise G3Error('libg3hip.so not found at %s: build it first (make -C g3py_amd/csrc); '
+                      'g3py_amd has no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGS.items():
+        f = getattr(lib, name)      # AttributeError if the symbol is missing
+        f.argtypes = args
+        f.restype = res
+    _lib = lib
+    return lib
+
+
+def dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return G3_F64
+    if dtype == np.float32:
+        return G3_F32
+    raise G3Error('unsupported dtype %s' % dtype)
+
+
+def roundup(n, m=G3_LEAF):
+    return (int(n) + m - 1) // m * m

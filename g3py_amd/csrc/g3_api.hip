@@ -1,0 +1,515 @@
+// Context, device memory, element-wise / reduction kernels and the fused hot-path entry
+// points of libg3hip (see include/g3hip.h for the contract of each function).
+#include "g3_internal.h"
+
+// ----------------------------------------------------------------------------- context
+extern "C" int g3_version(void) { return 100; }
+
+extern "C" int g3_ctx_create(int device, g3_ctx** out) {
+  if (!out) return -2;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return G3_ERR_HIP;
+  if (device < 0 || device >= ndev) return -1;
+  g3_ctx* ctx = new (std::nothrow) g3_ctx();
+  if (!ctx) return G3_ERR_NOMEM;
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, 2 * sizeof(g3_kernel_prog));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_info, sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_stats, 64 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_prog, 2 * sizeof(g3_kernel_prog), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int));
+  if (e != hipSuccess) {
+    g3_ctx_destroy(ctx);
+    return G3_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return G3_OK;
+}
+
+extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
+  if (!ctx) return -1;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_info) (void)hipFree(ctx->d_info);
+  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->d_prog) (void)hipFree(ctx->d_prog);
+  if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+  if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+  if (ctx->h_prog) (void)hipHostFree(ctx->h_prog);
+  if (ctx->invd) (void)hipFree(ctx->invd);
+  if (ctx->work) (void)hipFree(ctx->work);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return G3_OK;
+}
+
+extern "C" int g3_ctx_set_stream(g3_ctx* ctx, void* s) {
+  if (!ctx) return -1;
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  ctx->adopted = (s != nullptr);
+  return G3_OK;
+}
+
+extern "C" int g3_ctx_sync(g3_ctx* ctx) {
+  if (!ctx) return -1;
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  return G3_OK;
+}
+
+extern "C" const char* g3_last_error(g3_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int g3_malloc(g3_ctx* ctx, size_t bytes, void** dev) {
+  if (!ctx) return -1;
+  if (!dev) return -3;
+  *dev = nullptr;
+  if (bytes == 0) return G3_OK;
+  G3_HIP(hipSetDevice(ctx->device));
+  G3_HIP(hipMalloc(dev, bytes));
+  return G3_OK;
+}
+extern "C" int g3_free(g3_ctx* ctx, void* dev) {
+  if (!ctx) return -1;
+  if (!dev) return G3_OK;
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  G3_HIP(hipFree(dev));
+  return G3_OK;
+}
+extern "C" int g3_memcpy_h2d(g3_ctx* ctx, void* dev, const void* host, size_t bytes) {
+  if (!ctx) return -1;
+  if (bytes == 0) return G3_OK;
+  if (!dev) return -2;
+  if (!host) return -3;
+  G3_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));  // host buffer is borrowed only for the call
+  return G3_OK;
+}
+extern "C" int g3_memcpy_d2h(g3_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  if (!ctx) return -1;
+  if (bytes == 0) return G3_OK;
+  if (!host) return -2;
+  if (!dev) return -3;
+  G3_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  return G3_OK;
+}
+extern "C" int g3_memcpy_d2d(g3_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return -1;
+  if (bytes == 0) return G3_OK;
+  if (!dst) return -2;
+  if (!src) return -3;
+  G3_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return G3_OK;
+}
+extern "C" int g3_memset(g3_ctx* ctx, void* dev, int byte, size_t bytes) {
+  if (!ctx) return -1;
+  if (bytes == 0) return G3_OK;
+  if (!dev) return -2;
+  G3_HIP(hipMemsetAsync(dev, byte, bytes, ctx->stream));
+  return G3_OK;
+}
+extern "C" int g3_copy2d(g3_ctx* ctx, void* dst, int64_t ldd, const void* src, int64_t lds,
+                         int64_t rows, int64_t cols, g3_dtype dt) {
+  if (!ctx) return -1;
+  if (rows == 0 || cols == 0) return G3_OK;
+  if (!dst) return -2;
+  if (!src) return -4;
+  if (rows < 0) return -6;
+  if (cols < 0 || cols > ldd || cols > lds) return -7;
+  const size_t es = g3_esize(dt);
+  G3_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * es, src, (size_t)lds * es, (size_t)cols * es,
+                          (size_t)rows, hipMemcpyDeviceToDevice, ctx->stream));
+  return G3_OK;
+}
+
+// ----------------------------------------------------------------------------- small kernels
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = __shfl_down(v, o, 64);
+    v = (u < v || u != u) ? u : v;  // NaN propagates like numpy.min
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = __shfl_down(v, o, 64);
+    v = (u > v || u != u) ? u : v;
+  }
+  return v;
+}
+
+// one workgroup (1024 threads): out = [min, mean, max] of diag(A); optionally applies
+// tt_to_cov's lift  A_ii += (1e-6f - min) when min <= 0  (tensors.py:95-98)
+template <typename T>
+__global__ void __launch_bounds__(1024)
+diag_stats_kernel(T* A, int64_t n, int64_t ld, double* out, int lift) {
+  __shared__ double s_min[16], s_max[16], s_sum[16];
+  __shared__ double s_m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double mn = 1.0 / 0.0, mx = -1.0 / 0.0, sm = 0.0;
+  bool first = true;
+  for (int64_t i = tid; i < n; i += 1024) {
+    const double v = (double)A[i * ld + i];
+    if (first) { mn = v; mx = v; first = false; }
+    else { mn = (v < mn || v != v) ? v : mn; mx = (v > mx || v != v) ? v : mx; }
+    sm += v;
+  }
+  mn = wave_min(mn); mx = wave_max(mx); sm = wave_sum(sm);
+  if (lane == 0) { s_min[wave] = mn; s_max[wave] = mx; s_sum[wave] = sm; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = s_min[0], b = s_max[0], c = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      a = (s_min[w] < a || s_min[w] != s_min[w]) ? s_min[w] : a;
+      b = (s_max[w] > b || s_max[w] != s_max[w]) ? s_max[w] : b;
+      c += s_sum[w];
+    }
+    if (out) { out[0] = a; out[1] = c / (double)n; out[2] = b; }
+    s_m = a;
+  }
+  __syncthreads();
+  if (lift) {
+    const T m = (T)s_m;
+    if (!(m > T(0))) {
+      const T add = (T)1e-6f - m;
+      for (int64_t i = tid; i < n; i += 1024) A[i * ld + i] += add;
+    }
+  }
+}
+
+template <typename T>
+__global__ void diag_add_kernel(T* A, int64_t n, int64_t ld, T v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i * ld + i] += v;
+}
+
+template <typename T>
+__global__ void scrub_kernel(T* A, int64_t n2, int64_t ld) {
+  const int64_t i = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n2; j += (int64_t)gridDim.x * blockDim.x) {
+    T v = A[i * ld + j];
+    if (v != v) A[i * ld + j] = T(0);
+    else if (__builtin_isinf(v)) A[i * ld + j] = (T)1e10f;
+  }
+}
+
+// out[0] = sum log L_ii ; out[1] = sum a_i^2 ; out[2] = #non-finite a ; out[3] = #bad diag
+template <typename T>
+__global__ void __launch_bounds__(1024)
+logp_terms_kernel(const T* L, int64_t n, int64_t ld, const T* a, double* out) {
+  __shared__ double s0[16], s1[16], s2[16], s3[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double ld_sum = 0, ss = 0, nf = 0, bd = 0;
+  for (int64_t i = tid; i < n; i += 1024) {
+    const double d = (double)L[i * ld + i];
+    ld_sum += log(d);
+    if (!(d > 0.0) || __builtin_isinf(d)) bd += 1;
+    if (a) {
+      const double v = (double)a[i];
+      ss += v * v;
+      if (v != v || __builtin_isinf(v)) nf += 1;
+    }
+  }
+  ld_sum = wave_sum(ld_sum); ss = wave_sum(ss); nf = wave_sum(nf); bd = wave_sum(bd);
+  if (lane == 0) { s0[wave] = ld_sum; s1[wave] = ss; s2[wave] = nf; s3[wave] = bd; }
+  __syncthreads();
+  if (tid == 0) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int w = 0; w < 16; ++w) { a0 += s0[w]; a1 += s1[w]; a2 += s2[w]; a3 += s3[w]; }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+  }
+}
+
+// one workgroup (256 threads) per row of V: dot with a, and sum of squares
+template <typename T>
+__global__ void __launch_bounds__(256)
+rows_dot_ss_kernel(const T* __restrict__ V, int64_t n, int64_t ld, const T* __restrict__ a,
+                   T* __restrict__ dot, T* __restrict__ ss) {
+  __shared__ double sd[4], sq[4];
+  const T* v = V + (int64_t)blockIdx.x * ld;
+  double d = 0, q = 0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) {
+    const double x = (double)v[j];
+    if (a) d += x * (double)a[j];
+    q += x * x;
+  }
+  d = wave_sum(d); q = wave_sum(q);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sd[wave] = d; sq[wave] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (dot) dot[blockIdx.x] = (T)(sd[0] + sd[1] + sd[2] + sd[3]);
+    if (ss) ss[blockIdx.x] = (T)(sq[0] + sq[1] + sq[2] + sq[3]);
+  }
+}
+
+static int fetch_stats(g3_ctx* ctx, double* out, int cnt) {
+  G3_HIP(hipMemcpyAsync(ctx->h_stats, ctx->d_stats, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < cnt; ++i) out[i] = ctx->h_stats[i];
+  return G3_OK;
+}
+
+static int diag_stats_launch(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double* dout, int lift) {
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(1), dim3(1024), 0, ctx->stream, (double*)A, n, ld, dout, lift);
+  else
+    hipLaunchKernelGGL((diag_stats_kernel<float>), dim3(1), dim3(1024), 0, ctx->stream, (float*)A, n, ld, dout, lift);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+extern "C" int g3_cov_lift(g3_ctx* ctx, void* K, int64_t n, int64_t ld, g3_dtype dt) {
+  if (!ctx) return -1;
+  if (!K) return -2;
+  if (n < 0) return -3;
+  if (ld < n) return -4;
+  if (n == 0) return G3_OK;
+  return diag_stats_launch(ctx, K, n, ld, dt, nullptr, 1);
+}
+
+extern "C" int g3_diag_stats(g3_ctx* ctx, const void* A, int64_t n, int64_t ld, g3_dtype dt, double out[3]) {
+  if (!ctx) return -1;
+  if (!A) return -2;
+  if (n <= 0) return -3;
+  if (ld < n) return -4;
+  if (!out) return -6;
+  int rc = diag_stats_launch(ctx, const_cast<void*>(A), n, ld, dt, ctx->d_stats + 8, 0);
+  if (rc) return rc;
+  G3_HIP(hipMemcpyAsync(ctx->h_stats + 8, ctx->d_stats + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3; ++i) out[i] = ctx->h_stats[8 + i];
+  return G3_OK;
+}
+
+extern "C" int g3_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value) {
+  if (!ctx) return -1;
+  if (!A) return -2;
+  if (n < 0) return -3;
+  if (ld < n) return -4;
+  if (n == 0) return G3_OK;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((diag_add_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)A, n, ld, value);
+  else
+    hipLaunchKernelGGL((diag_add_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)A, n, ld, (float)value);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+extern "C" int g3_scrub(g3_ctx* ctx, void* A, int64_t n1, int64_t n2, int64_t ld, g3_dtype dt) {
+  if (!ctx) return -1;
+  if (!A) return -2;
+  if (n1 < 0) return -3;
+  if (n2 < 0) return -4;
+  if (ld < n2) return -5;
+  if (n1 == 0 || n2 == 0) return G3_OK;
+  const dim3 grid((unsigned)((n2 + 255) / 256 > 64 ? 64 : (n2 + 255) / 256), (unsigned)n1);
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((scrub_kernel<double>), grid, dim3(256), 0, ctx->stream, (double*)A, n2, ld);
+  else
+    hipLaunchKernelGGL((scrub_kernel<float>), grid, dim3(256), 0, ctx->stream, (float*)A, n2, ld);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+static int logp_terms_launch(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const void* a, g3_dtype dt) {
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((logp_terms_kernel<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double*)L, n, ld,
+                       (const double*)a, ctx->d_stats);
+  else
+    hipLaunchKernelGGL((logp_terms_kernel<float>), dim3(1), dim3(1024), 0, ctx->stream, (const float*)L, n, ld,
+                       (const float*)a, ctx->d_stats);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+extern "C" int g3_logp_terms(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const void* a,
+                             g3_dtype dt, double out[4]) {
+  if (!ctx) return -1;
+  if (!L) return -2;
+  if (n <= 0) return -3;
+  if (ld < n) return -4;
+  if (!out) return -7;
+  int rc = logp_terms_launch(ctx, L, n, ld, a, dt);
+  if (rc) return rc;
+  return fetch_stats(ctx, out, 4);
+}
+
+static int rows_dot_ss_launch(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld, const void* a,
+                              g3_dtype dt, void* dot, void* ss) {
+  if (m == 0) return G3_OK;
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((rows_dot_ss_kernel<double>), dim3((unsigned)m), dim3(256), 0, ctx->stream,
+                       (const double*)V, n, ld, (const double*)a, (double*)dot, (double*)ss);
+  else
+    hipLaunchKernelGGL((rows_dot_ss_kernel<float>), dim3((unsigned)m), dim3(256), 0, ctx->stream,
+                       (const float*)V, n, ld, (const float*)a, (float*)dot, (float*)ss);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+extern "C" int g3_rows_dot_ss(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld,
+                              const void* a, g3_dtype dt, void* dot, void* ss) {
+  if (!ctx) return -1;
+  if (!V) return -2;
+  if (m < 0) return -3;
+  if (n < 0) return -4;
+  if (ld < n) return -5;
+  return rows_dot_ss_launch(ctx, V, m, n, ld, a, dt, dot, ss);
+}
+
+// ----------------------------------------------------------------------------- fused path
+template <typename T>
+__global__ void pad_row_kernel(T* dst, const T* src, int64_t n, int64_t npad, int64_t rows) {
+  // dst is rows x npad: row 0 = [src, 0...], other rows 0
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  for (int64_t r = 0; r < rows; ++r) dst[r * npad + j] = (r == 0 && j < n) ? src[j] : T(0);
+}
+
+extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N,
+                            int64_t ldx, int d, const void* delta, g3_dtype dt, void* K, int64_t ldk,
+                            void* a, double out[6]) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!X) return -3;
+  if (N <= 0) return -4;
+  if (!delta) return -7;
+  if (!K) return -9;
+  const int64_t Np = g3_roundup(N, G3_LEAF);
+  if (ldk < Np || ldk % (16 / (int64_t)g3_esize(dt))) return -10;
+  if (!a) return -11;
+  if (!out) return -12;
+  int rc = g3i_ensure_invd(ctx, Np, dt);
+  if (rc) return rc;
+  const unsigned gflags = G3_GRAM_LOWER | G3_GRAM_SCRUB | G3_GRAM_PAD_EYE;
+  // K = tt_to_cov(cov(X))  (elliptical.py:70-71), lower triangle only
+  auto build = [&]() -> int {
+    int r = g3_gram(ctx, prog, X, N, ldx, nullptr, 0, 0, d, dt, K, ldk, Np, Np, gflags);
+    if (r) return r;
+    return g3_cov_lift(ctx, K, N, ldk, dt);
+  };
+  rc = build();
+  if (rc) return rc;
+  int info = 0;
+  rc = g3_potrf(ctx, K, Np, ldk, dt, ctx->invd, &info);
+  if (rc) return rc;
+  double tries = 0, fallback = 0;
+  const int info0 = info;
+  if (info != 0) {
+    // jitter schedule of CholeskyRobust._cholesky (tensors.py:203-213); the Gram is rebuilt
+    // instead of kept: it costs one HBM pass, a copy would cost the same plus 8 N^2 bytes
+    rc = build();
+    if (rc) return rc;
+    double st[3];
+    rc = g3_diag_stats(ctx, K, N, ldk, dt, st);
+    if (rc) return rc;
+    const double c6 = (double)1e-6f, c10 = (double)10.0f;
+    double dK = st[1] * c6, lift = 0.0;
+    if (st[0] <= 0.0) lift = st[1] * c6 - st[0];
+    bool ok = false;
+    for (int t = 0; t < 20; ++t) {
+      tries += 1;
+      if (t > 0) {
+        rc = build();
+        if (rc) return rc;
+      }
+      rc = g3_diag_add(ctx, K, N, ldk, dt, lift + dK);
+      if (rc) return rc;
+      rc = g3_potrf(ctx, K, Np, ldk, dt, ctx->invd, &info);
+      if (rc) return rc;
+      if (info == 0) { ok = true; break; }
+      dK *= c10;
+    }
+    if (!ok) {
+      fallback = 1;
+      // 1e-10 * I (tensors.py:221); W = 1e10 * I
+      const size_t es = g3_esize(dt);
+      G3_HIP(hipMemset2DAsync(K, (size_t)ldk * es, 0, (size_t)Np * es, (size_t)Np, ctx->stream));
+      rc = g3_diag_add(ctx, K, N, ldk, dt, (double)1e-10f);
+      if (rc) return rc;
+      if (Np > N) {
+        rc = g3_diag_add(ctx, (char*)K + (size_t)N * (ldk + 1) * es, Np - N, ldk, dt, 1.0);
+        if (rc) return rc;
+      }
+      rc = g3i_reset_info(ctx);
+      if (rc) return rc;
+      rc = g3i_trtri_blocks(ctx, K, Np, ldk, dt, ctx->invd);
+      if (rc) return rc;
+    }
+  }
+  rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  // a = L^-1 delta as a 64-row right-hand-side block (row 0 carries delta)
+  rc = g3i_ensure_work(ctx, (size_t)G3_LEAF * Np * g3_esize(dt));
+  if (rc) return rc;
+  const unsigned nb = (unsigned)((Np + 255) / 256);
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)ctx->work,
+                       (const double*)delta, N, Np, (int64_t)G3_LEAF);
+  else
+    hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)ctx->work,
+                       (const float*)delta, N, Np, (int64_t)G3_LEAF);
+  G3_LAUNCH_CHECK();
+  rc = g3i_trsm_rlt(ctx, K, Np, ldk, ctx->work, G3_LEAF, Np, dt, ctx->invd);
+  if (rc) return rc;
+  G3_HIP(hipMemcpyAsync(a, ctx->work, (size_t)Np * g3_esize(dt), hipMemcpyDeviceToDevice, ctx->stream));
+  rc = logp_terms_launch(ctx, K, N, ldk, a, dt);
+  if (rc) return rc;
+  double st4[4];
+  rc = fetch_stats(ctx, st4, 4);
+  if (rc) return rc;
+  out[0] = st4[0];
+  out[1] = st4[1];
+  out[2] = st4[2];
+  out[3] = tries;
+  out[4] = fallback;
+  out[5] = (double)info0;
+  return G3_OK;
+}
+
+extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* Xs, int64_t M,
+                           int64_t ldxs, const void* X, int64_t N, int64_t ldx, int d, const void* L,
+                           int64_t ldl, const void* a, g3_dtype dt, void* V, int64_t ldv, void* mu,
+                           void* ss) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!Xs) return -3;
+  if (M <= 0) return -4;
+  if (!X) return -6;
+  if (N <= 0) return -7;
+  if (!L) return -10;
+  const int64_t Np = g3_roundup(N, G3_LEAF), Mp = g3_roundup(M, G3_LEAF);
+  const int64_t al = 16 / (int64_t)g3_esize(dt);
+  if (ldl < Np || ldl % al) return -11;
+  if (!V) return -14;
+  if (ldv < Np || ldv % al) return -15;
+  if (ctx->invd_bytes < (size_t)(Np / G3_LEAF) * G3_LEAF * G3_LEAF * g3_esize(dt)) return -10;
+  // V = tt_to_num(cov(Xs, X))  (elliptical.py:78-79), then V <- V L^-T
+  int rc = g3_gram(ctx, prog, Xs, M, ldxs, X, N, ldx, d, dt, V, ldv, Mp, Np, G3_GRAM_SCRUB);
+  if (rc) return rc;
+  rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  rc = g3i_trsm_rlt(ctx, L, Np, ldl, V, Mp, ldv, dt, ctx->invd);
+  if (rc) return rc;
+  if (mu || ss) rc = rows_dot_ss_launch(ctx, V, M, N, ldv, a, dt, mu, ss);
+  return rc;
+}

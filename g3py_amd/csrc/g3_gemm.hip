@@ -1,0 +1,231 @@
+// MFMA "NT" GEMM for gfx950:  C[m x n] = alpha * A[m x k] * B[n x k]^T + beta * C
+// (row-major, k contiguous in both operands).  This one kernel carries every O(N^3) part
+// of the path: the SYRK/GEMM trailing updates of the blocked Cholesky (replacing dpotrf,
+// g3py/libs/tensors.py:198), the panel solves against inverted diagonal blocks, the
+// multi-right-hand-side triangular solves of the posterior (g3py/processes/elliptical.py:
+// 81-91) and the posterior covariance / sampling products.
+//
+// CDNA4 mapping
+//   * v_mfma_f64_16x16x4_f64 (or v_mfma_f32_16x16x4_f32): one wave owns a WM x WN patch as
+//     (WM/16) x (WN/16) accumulator tiles; A and B fragments are ONE scalar per lane
+//     (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]).
+//   * The reduction index may be visited in any order as long as A and B agree, so a lane
+//     fetches one 16-byte LDS chunk (2 f64 / 4 f32 consecutive k) per fragment row with
+//     ds_read_b128 and feeds its elements to consecutive MFMAs.
+//   * LDS tiles are [row][128 bytes] with the 16-byte chunk index XOR-swizzled by
+//     (row >> 1) & 7, which makes every ds_read_b128 lane group hit 64 distinct banks.
+//   * Global -> register -> LDS staging, double-buffered, one barrier per K tile; the
+//     f64 MFMA is 64 cycles per instruction, so the loop is matrix-pipe bound.
+#include "g3_internal.h"
+
+template <typename T>
+struct MfmaT;
+template <>
+struct MfmaT<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  typedef double chunk_t __attribute__((ext_vector_type(2)));
+  static constexpr int EPC = 2;  // elements per 16-byte chunk
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct MfmaT<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  typedef float chunk_t __attribute__((ext_vector_type(4)));
+  static constexpr int EPC = 4;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
+constexpr int NCH = 8;     // 16-byte chunks per row
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
+gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+               int K, T alpha, T beta, int lower_only, const int* __restrict__ info) {
+  using M = MfmaT<T>;
+  using chunk_t = typename M::chunk_t;
+  using acc_t = typename M::acc_t;
+  constexpr int EPC = M::EPC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int NWN = BN / WN;
+  constexpr int NT = (BM / WM) * NWN * 64;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int CA = BM * NCH / NT, CB = BN * NCH / NT;
+  static_assert(BM * NCH % NT == 0 && BN * NCH % NT == 0, "tile/threads mismatch");
+
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (lower_only && n0 >= m0 + BM) return;
+  if (info != nullptr && *info != 0) return;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                      // [2][BM][ROWB]
+  char* sB = smem + 2 * BM * ROWB;      // [2][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
+
+  acc_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  // staging assignment: chunk c of row r  <-  idx = tid + i * NT
+  chunk_t ra[CA], rb[CB];
+  const T* gA = A + (int64_t)m0 * lda;
+  const T* gB = B + (int64_t)n0 * ldb;
+
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
+      ra[i] = *reinterpret_cast<const chunk_t*>(gA + (int64_t)r * lda + k0 + c * EPC);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
+      rb[i] = *reinterpret_cast<const chunk_t*>(gB + (int64_t)r * ldb + k0 + c * EPC);
+    }
+  };
+  auto store_stage = [&](int buf) {
+    char* a = sA + buf * BM * ROWB;
+    char* b = sB + buf * BN * ROWB;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
+      *reinterpret_cast<chunk_t*>(a + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
+      *reinterpret_cast<chunk_t*>(b + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4)) = rb[i];
+    }
+  };
+
+  const int frow = lane & 15, kq = lane >> 4, swz = (frow >> 1) & 7;
+  auto compute = [&](int buf) {
+    const char* a = sA + buf * BM * ROWB + (wm + frow) * ROWB;
+    const char* b = sB + buf * BN * ROWB + (wn + frow) * ROWB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int off = (((s * 4 + kq) ^ swz) << 4);
+      chunk_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const chunk_t*>(a + i * 16 * ROWB + off);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const chunk_t*>(b + j * 16 * ROWB + off);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = M::mfma(fa[i][e], fb[j][e], acc[i][j]);
+    }
+  };
+
+  const int KT = K / BK;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_stage((kt + 1) * BK);
+    compute(buf);
+    if (kt + 1 < KT) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: 16 consecutive columns per 16 lanes (128 B f64 / 64 B f32 segments per row)
+  const int col_l = lane & 15;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + j * 16 + col_l;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + i * 16 + M::row(lane, r);
+        if (lower_only && col > row) continue;
+        T* p = C + (int64_t)row * ldc + col;
+        T v = alpha * acc[i][j][r];
+        if (beta != T(0)) v += beta * (*p);
+        *p = v;
+      }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                      int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                      int lower_only) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int LDS = 2 * (BM + BN) * ROWB;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(n / BN), (unsigned)(m / BM));
+  hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, ctx->stream, (T*)C, ldc, (const T*)A, lda,
+                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+template <typename T>
+static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                    int lower_only) {
+  // tile choice: big tiles when they still fill the chip, small tiles for the narrow
+  // panel / leaf operations on the critical path of the factorisation
+  const int64_t blocks128 = (m / 128) * (n / 128) / (lower_only ? 2 : 1);
+  if (m % 256 == 0 && n % 128 == 0 && (m / 256) * (n / 128) / (lower_only ? 2 : 1) >= 512)
+    return launch_cfg<T, 256, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (m % 128 == 0 && n % 128 == 0 && blocks128 >= 96)
+    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+}
+
+int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                g3_dtype dt, int lower_only) {
+  if (m == 0 || n == 0) return G3_OK;
+  if (dt == G3_F64)
+    return launch_t<double>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  return launch_t<float>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+}
+
+extern "C" int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
+                          const void* B, int64_t ldb, int64_t m, int64_t n, int64_t k,
+                          double alpha, double beta, g3_dtype dt, int lower_only) {
+  if (!ctx) return -1;
+  if (!C) return -2;
+  if (!A) return -4;
+  if (!B) return -6;
+  const int64_t bk = ROWB / (int64_t)g3_esize(dt);
+  if (m < 0 || m % 64) return -8;
+  if (n < 0 || n % 64) return -9;
+  if (k < 0 || k % bk) return -10;
+  const int64_t al = 16 / (int64_t)g3_esize(dt);
+  if (ldc < n) return -3;
+  if (lda < k || lda % al) return -5;
+  if (ldb < k || ldb % al) return -7;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return -4;
+  if (k == 0) {
+    // degenerate: C = beta * C is not needed anywhere on the path
+    return -10;
+  }
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  return g3i_gemm_nt(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, dt, lower_only);
+}

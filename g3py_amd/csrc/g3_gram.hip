@@ -1,0 +1,353 @@
+// Gram-matrix assembly for g3py's stationary kernels on gfx950.
+//
+// Replaces Metric.gram + Kernel.cov (g3py/processes/hypers/metrics.py:11-13,
+// kernels.py:96-110,192-244,360-487): the reference materialises an n1 x n2 x d broadcast
+// tensor and then reduces it; here one 64 x 64 output tile is produced per workgroup from
+// two 64 x d input tiles staged in LDS (coalesced loads of the N x d input), every thread
+// evaluates the whole kernel expression for its pairs and writes K exactly once, row-wise
+// coalesced (HBM-write bound).  tt_to_num (tensors.py:90-92) is fused into the store.
+#include "g3_internal.h"
+
+#define GT 64           // output tile edge
+#define G3_PI 3.14159265358979323846
+
+template <typename T>
+__device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* xj, bool diag_sym,
+                                       bool sym) {
+  // xi, xj: LDS rows (all d columns of the two points)
+  const int nd = lf.ndims;
+  const T var = (T)lf.var;
+  switch (lf.kind) {
+    case G3_K_NOISE:
+      return diag_sym ? var : T(0);
+    case G3_K_WN: {
+      if (sym) return diag_sym ? var : T(0);
+      T cnt = T(0);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        cnt += (xi[c] - xj[c] == T(0)) ? T(1) : T(0);
+      }
+      return var * cnt;
+    }
+    case G3_K_SE:
+    case G3_K_MAT32:
+    case G3_K_MAT52:
+    case G3_K_RQ: {
+      T d = T(0);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        const T dx = xi[c] - xj[c];
+        const T r = (T)lf.rate[k];
+        d += (dx * dx) * (T(0.5) * r * r);  // ARD_L2, metrics.py:100-102
+      }
+      if (lf.kind == G3_K_SE) return var * exp(-d);
+      if (lf.kind == G3_K_MAT32) {
+        const T s = sqrt(T(3) * d);
+        return var * ((T(1) + s) * exp(-s));
+      }
+      if (lf.kind == G3_K_MAT52) {
+        const T s = sqrt(T(5) * d);
+        return var * ((T(1) + s + T(5) * d / T(3)) * exp(-s));
+      }
+      const T al = (T)lf.alpha;
+      return var * pow(T(1) + d / al, -al);
+    }
+    case G3_K_OU: {
+      T d = T(0);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        d += fabs(xi[c] - xj[c]) * (T)lf.rate[k];  // ARD_L1, metrics.py:89-91
+      }
+      return var * exp(-d);
+    }
+    case G3_K_COS: {
+      T p = T(1);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        p *= cos(T(2 * G3_PI) * (xi[c] - xj[c]) * (T)lf.freq[k]);
+      }
+      return var * p;
+    }
+    case G3_K_SIN: {
+      T s = T(0);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        const T v = sin(T(G3_PI) * (xi[c] - xj[c]) * (T)lf.freq[k]);
+        s += (v * v) * (T)lf.rate[k];
+      }
+      return var * exp(T(2) * s);  // positive exponent, as written at kernels.py:472
+    }
+    case G3_K_SINC: {
+      T p = T(1);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        const T dx = xi[c] - xj[c];
+        const T f = (T)lf.freq[k];
+        const T v = sin(T(2 * G3_PI * G3_PI) * dx * f) / (T(2 * G3_PI * G3_PI) * f * dx);
+        p *= (dx != T(0)) ? v : T(1);
+      }
+      return var * p;
+    }
+    case G3_K_SM: {
+      T s = T(0), p = T(1);
+      for (int k = 0; k < nd; ++k) {
+        const int c = lf.dims[k];
+        const T dx = xi[c] - xj[c];
+        const T r = (T)lf.rate[k];
+        s += (dx * dx) * (r * r);
+        p *= cos(T(2 * G3_PI) * dx * (T)lf.freq[k]);
+      }
+      return var * (exp(T(-2 * G3_PI * G3_PI) * s) * p);
+    }
+    default:
+      return T(0);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T prog_eval(const g3_kernel_prog* __restrict__ prog, const T* xi,
+                                       const T* xj, bool diag_sym, bool sym) {
+  T acc = (T)prog->shift;
+  const int np = prog->nprod;
+  for (int p = 0; p < np; ++p) {
+    T v = (T)prog->prod[p].coef;
+    const int nf = prog->prod[p].nfac;
+    for (int f = 0; f < nf; ++f) v *= leaf_eval<T>(prog->leaf[prog->prod[p].fac[f]], xi, xj, diag_sym, sym);
+    acc += v;
+  }
+  return acc;
+}
+
+template <typename T>
+__device__ __forceinline__ T scrub(T v) {
+  // tt_to_num: NaN -> 0, +-Inf -> 1e10 (tensors.py:90-92)
+  if (v != v) return T(0);
+  if (__builtin_isinf(v)) return (T)1e10f;
+  return v;
+}
+
+// Fast path: prog == var * SE(all d columns in order) [+ noise on the square diagonal].
+// D compile-time: x_j lives in registers, x_i is an LDS broadcast.
+template <typename T, int D>
+struct SeParams {
+  T w[D];   // 0.5 * rate^2
+  T var, noise;
+};
+
+template <typename T, int D, bool SE_FAST>
+__global__ void __launch_bounds__(256)
+gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
+            int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
+            T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym) {
+  const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+  if ((flags & G3_GRAM_LOWER) && j0 > i0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_g[];
+  const int dp = d | 1;  // odd row stride: conflict-free column-varying reads
+  T* xi_s = reinterpret_cast<T*>(smem_g);
+  T* xj_s = xi_s + GT * dp;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < GT * d; e += 256) {
+    const int r = e / d, c = e - r * d;
+    xi_s[r * dp + c] = (i0 + r < n1) ? X1[(i0 + r) * ldx1 + c] : T(0);
+    xj_s[r * dp + c] = (j0 + r < n2) ? X2[(j0 + r) * ldx2 + c] : T(0);
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;  // column within tile, row phase
+  const int64_t j = j0 + tx;
+  if (j >= n2pad) return;
+  const T* xj = xj_s + tx * dp;
+  T xjr[D];
+  if (SE_FAST) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) xjr[c] = xj[c];
+  }
+  const bool scr = (flags & G3_GRAM_SCRUB) != 0;
+  const bool eye = (flags & G3_GRAM_PAD_EYE) != 0;
+#pragma unroll 4
+  for (int rr = ty; rr < GT; rr += 4) {
+    const int64_t i = i0 + rr;
+    if (i >= n1pad) break;
+    T v;
+    if (i < n1 && j < n2) {
+      const bool dg = sym && (i == j);
+      if (SE_FAST) {
+        const T* xi = xi_s + rr * dp;
+        T dd = T(0);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          const T dx = xi[c] - xjr[c];
+          dd += (dx * dx) * se.w[c];
+        }
+        v = se.var * exp(-dd);
+        if (dg) v += se.noise;
+      } else {
+        v = prog_eval<T>(prog, xi_s + rr * dp, xj, dg, sym != 0);
+      }
+      if (scr) v = scrub(v);
+    } else {
+      v = (eye && i == j) ? T(1) : T(0);
+    }
+    K[i * ldk + j] = v;
+  }
+}
+
+template <typename T>
+__global__ void gram_diag_kernel(const g3_kernel_prog* __restrict__ prog, const T* __restrict__ X,
+                                 int64_t n, int64_t ldx, int d, T* __restrict__ out) {
+  // diag(Kernel.cov(X)): the square-case diagonal, so NOISE / WN contribute
+  extern __shared__ __attribute__((aligned(16))) char smem_g[];
+  T* xs = reinterpret_cast<T*>(smem_g);
+  const int dp = d | 1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  T* xi = xs + threadIdx.x * dp;
+  if (i < n)
+    for (int c = 0; c < d; ++c) xi[c] = X[i * ldx + c];
+  if (i < n) out[i] = prog_eval<T>(prog, xi, xi, true, true);
+}
+
+int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr) {
+  // pinned staging keeps the copy asynchronous; wait for earlier users of the slot first
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(&ctx->h_prog[slot], prog, sizeof(g3_kernel_prog));
+  G3_HIP(hipMemcpyAsync(&ctx->d_prog[slot], &ctx->h_prog[slot], sizeof(g3_kernel_prog),
+                        hipMemcpyHostToDevice, ctx->stream));
+  *dptr = &ctx->d_prog[slot];
+  return G3_OK;
+}
+
+static int validate_prog(const g3_kernel_prog* p, int d) {
+  if (p->nleaf < 0 || p->nleaf > G3_MAXLEAF || p->nprod < 0 || p->nprod > G3_MAXPROD) return 1;
+  for (int l = 0; l < p->nleaf; ++l) {
+    const g3_leaf& lf = p->leaf[l];
+    if (lf.kind < 0 || lf.kind > G3_K_WN) return 1;
+    if (lf.ndims < 0 || lf.ndims > G3_MAXD) return 1;
+    for (int k = 0; k < lf.ndims; ++k)
+      if (lf.dims[k] < 0 || lf.dims[k] >= d) return 1;
+  }
+  for (int q = 0; q < p->nprod; ++q) {
+    if (p->prod[q].nfac < 0 || p->prod[q].nfac > G3_MAXFAC) return 1;
+    for (int f = 0; f < p->prod[q].nfac; ++f)
+      if (p->prod[q].fac[f] < 0 || p->prod[q].fac[f] >= p->nleaf) return 1;
+  }
+  return 0;
+}
+
+// recognise  var*SE(x[:, 0:d]) (+ Noise)  so the common case takes the register fast path
+template <typename T, int D>
+static bool match_se(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
+  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 2) return false;
+  int se = -1, noise = -1;
+  for (int q = 0; q < p->nprod; ++q) {
+    if (p->prod[q].nfac != 1) return false;
+    const g3_leaf& lf = p->leaf[p->prod[q].fac[0]];
+    if (lf.kind == G3_K_SE && se < 0) se = q;
+    else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
+    else return false;
+  }
+  if (se < 0) return false;
+  const g3_leaf& lf = p->leaf[p->prod[se].fac[0]];
+  if (lf.ndims != D) return false;
+  for (int k = 0; k < D; ++k) {
+    if (lf.dims[k] != k) return false;
+    out->w[k] = (T)(0.5 * lf.rate[k] * lf.rate[k]);
+  }
+  // (coef * var) applied once; identical to var*k when coef == 1 (the un-scaled kernel)
+  if (p->prod[se].coef != 1.0) return false;
+  out->var = (T)lf.var;
+  out->noise = T(0);
+  if (noise >= 0) {
+    if (p->prod[noise].coef != 1.0) return false;
+    out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
+  }
+  return true;
+}
+
+template <typename T, int D>
+static int launch_gram_fast(g3_ctx* ctx, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
+                            const T* X2, int64_t n2, int64_t ldx2, T* K, int64_t ldk, int64_t n1pad,
+                            int64_t n2pad, unsigned flags, int sym) {
+  dim3 grid((unsigned)((n2pad + GT - 1) / GT), (unsigned)((n1pad + GT - 1) / GT));
+  const size_t lds = 2 * GT * (D | 1) * sizeof(T);
+  hipLaunchKernelGGL((gram_kernel<T, D, true>), grid, dim3(256), lds, ctx->stream,
+                     (const g3_kernel_prog*)nullptr, se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad,
+                     n2pad, flags, sym);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+template <typename T>
+static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t n1, int64_t ldx1,
+                  const T* X2, int64_t n2, int64_t ldx2, int d, T* K, int64_t ldk, int64_t n1pad,
+                  int64_t n2pad, unsigned flags, int sym) {
+  {
+    SeParams<T, 1> s1; SeParams<T, 2> s2; SeParams<T, 3> s3; SeParams<T, 4> s4; SeParams<T, 8> s8; SeParams<T, 16> s16;
+    if (match_se<T, 1>(prog, d, &s1)) return launch_gram_fast<T, 1>(ctx, s1, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if (match_se<T, 2>(prog, d, &s2)) return launch_gram_fast<T, 2>(ctx, s2, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if (match_se<T, 3>(prog, d, &s3)) return launch_gram_fast<T, 3>(ctx, s3, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if (match_se<T, 4>(prog, d, &s4)) return launch_gram_fast<T, 4>(ctx, s4, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if (match_se<T, 8>(prog, d, &s8)) return launch_gram_fast<T, 8>(ctx, s8, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if (match_se<T, 16>(prog, d, &s16)) return launch_gram_fast<T, 16>(ctx, s16, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+  }
+  const g3_kernel_prog* dprog;
+  int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
+  if (rc) return rc;
+  dim3 grid((unsigned)((n2pad + GT - 1) / GT), (unsigned)((n1pad + GT - 1) / GT));
+  const size_t lds = 2 * GT * (d | 1) * sizeof(T);
+  SeParams<T, 1> dummy{};
+  hipLaunchKernelGGL((gram_kernel<T, 1, false>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
+                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+extern "C" int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X1, int64_t n1, int64_t ldx1,
+                       const void* X2, int64_t n2, int64_t ldx2, int d, g3_dtype dt, void* K, int64_t ldk,
+                       int64_t n1pad, int64_t n2pad, unsigned flags) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!X1) return -3;
+  if (n1 < 0) return -4;
+  const int sym = (X2 == nullptr);
+  if (sym) { X2 = X1; n2 = n1; ldx2 = ldx1; }
+  if (n2 < 0) return -7;
+  if (d < 1 || d > G3_MAXCOLS) return -9;
+  if (ldx1 < d) return -5;
+  if (ldx2 < d) return -8;
+  if (validate_prog(prog, d)) return -2;
+  if (!K) return -11;
+  if (n1pad < n1) return -13;
+  if (n2pad < n2) return -14;
+  if (ldk < n2pad) return -12;
+  if (!sym && (flags & G3_GRAM_LOWER)) return -15;
+  if (n1pad == 0 || n2pad == 0) return G3_OK;
+  if (dt == G3_F64)
+    return gram_t<double>(ctx, prog, (const double*)X1, n1, ldx1, (const double*)X2, n2, ldx2, d, (double*)K,
+                          ldk, n1pad, n2pad, flags, sym);
+  return gram_t<float>(ctx, prog, (const float*)X1, n1, ldx1, (const float*)X2, n2, ldx2, d, (float*)K, ldk,
+                       n1pad, n2pad, flags, sym);
+}
+
+extern "C" int g3_gram_diag(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t n, int64_t ldx,
+                            int d, g3_dtype dt, void* diag) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!X) return -3;
+  if (n < 0) return -4;
+  if (d < 1 || d > G3_MAXCOLS) return -6;
+  if (ldx < d) return -5;
+  if (validate_prog(prog, d)) return -2;
+  if (!diag) return -8;
+  if (n == 0) return G3_OK;
+  const g3_kernel_prog* dprog;
+  int rc = g3i_upload_prog(ctx, prog, 1, &dprog);
+  if (rc) return rc;
+  const unsigned nb = (unsigned)((n + 63) / 64);
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((gram_diag_kernel<double>), dim3(nb), dim3(64), 64 * (d | 1) * sizeof(double),
+                       ctx->stream, dprog, (const double*)X, n, ldx, d, (double*)diag);
+  else
+    hipLaunchKernelGGL((gram_diag_kernel<float>), dim3(nb), dim3(64), 64 * (d | 1) * sizeof(float),
+                       ctx->stream, dprog, (const float*)X, n, ldx, d, (float*)diag);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}

@@ -1,0 +1,68 @@
+// Internal declarations shared by the libg3hip translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "g3hip.h"
+
+#define G3_LEAF 64  // diagonal block factored (and inverted) by one workgroup
+
+struct g3_ctx {
+  int device;
+  hipStream_t stream;      // stream work is enqueued on
+  hipStream_t own_stream;  // created by the context
+  bool adopted;            // stream belongs to the caller
+  // small device scratch
+  int* d_info;             // potrf info flag
+  double* d_stats;         // 64 doubles of reduction outputs
+  g3_kernel_prog* d_prog;  // kernel program (device copy, 2 slots)
+  // pinned host mirrors
+  int* h_info;
+  double* h_stats;
+  g3_kernel_prog* h_prog;
+  // block inverses of the last factorisation
+  void* invd;
+  size_t invd_bytes;
+  // padded workspace for g3_potrf_robust / g3_trsm on ragged sizes
+  void* work;
+  size_t work_bytes;
+  char err[512];
+};
+
+#define G3_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      snprintf(ctx->err, sizeof(ctx->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call,       \
+               hipGetErrorString(_e));                                                        \
+      return G3_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define G3_LAUNCH_CHECK()                                                                     \
+  do {                                                                                        \
+    hipError_t _e = hipGetLastError();                                                        \
+    if (_e != hipSuccess) {                                                                   \
+      snprintf(ctx->err, sizeof(ctx->err), "%s:%d launch -> %s", __FILE__, __LINE__,          \
+               hipGetErrorString(_e));                                                        \
+      return G3_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+static inline size_t g3_esize(g3_dtype dt) { return dt == G3_F64 ? 8 : 4; }
+static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+
+// internal launchers (stream-ordered, no host sync)
+int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                g3_dtype dt, int lower_only);
+int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd);
+int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,
+                 int64_t ldb, g3_dtype dt, const void* invd);
+int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd);
+int g3i_reset_info(g3_ctx* ctx);
+int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt);
+int g3i_ensure_work(g3_ctx* ctx, size_t bytes);
+int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr);

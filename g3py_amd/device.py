@@ -1,0 +1,267 @@
+"""Device plumbing over the C ABI: contexts, device arrays, kernel-program compilation.
+
+Nothing here computes on the CPU: every numerical routine is a call into libg3hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import G3Error, KernelProg, roundup
+
+
+def _check(dev, rc, what):
+    if rc != 0:
+        msg = ''
+        if rc == -1000 and dev is not None and dev.ctx:
+            msg = ': ' + (dev.lib.g3_last_error(dev.ctx) or b'').decode()
+        raise G3Error('%s failed with status %d%s' % (what, rc, msg))
+
+
+class DeviceArray:
+    """A row-major device matrix (rows x cols, leading dimension ld, in elements)."""
+
+    def __init__(self, dev, ptr, rows, cols, ld, dtype, owned=True, keep=None):
+        self.dev, self.ptr, self.rows, self.cols, self.ld = dev, ptr, int(rows), int(cols), int(ld)
+        self.dtype = np.dtype(dtype)
+        self.owned = owned
+        self._keep = keep
+
+    @property
+    def nbytes(self):
+        return self.rows * self.ld * self.dtype.itemsize
+
+    def offset(self, row, col=0):
+        return self.ptr + (row * self.ld + col) * self.dtype.itemsize
+
+    def free(self):
+        if self.owned and self.ptr:
+            self.dev.lib.g3_free(self.dev.ctx, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Device:
+    """One g3_ctx on one GPU.  Raises if the library or the GPU is missing."""
+    _default = {}
+
+    def __init__(self, index=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.g3_ctx_create(int(index), C.byref(h))
+        if rc != 0:
+            raise G3Error('g3_ctx_create(device=%d) failed with status %d: no usable MI355X; '
+                          'g3py_amd has no CPU fallback' % (index, rc))
+        self.ctx = h
+        self.index = index
+
+    @classmethod
+    def default(cls, index=0):
+        if index not in cls._default:
+            cls._default[index] = cls(index)
+        return cls._default[index]
+
+    def close(self):
+        if self.ctx:
+            self.lib.g3_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def set_stream(self, stream_handle):
+        _check(self, self.lib.g3_ctx_set_stream(self.ctx, stream_handle), 'g3_ctx_set_stream')
+
+    def sync(self):
+        _check(self, self.lib.g3_ctx_sync(self.ctx), 'g3_ctx_sync')
+
+    # ---- memory
+    def alloc(self, rows, cols, dtype, ld=None, zero=False):
+        ld = int(cols if ld is None else ld)
+        p = C.c_void_p()
+        nbytes = int(rows) * ld * np.dtype(dtype).itemsize
+        _check(self, self.lib.g3_malloc(self.ctx, nbytes, C.byref(p)), 'g3_malloc(%d)' % nbytes)
+        a = DeviceArray(self, p.value or 0, rows, cols, ld, dtype)
+        if zero and nbytes:
+            _check(self, self.lib.g3_memset(self.ctx, a.ptr, 0, nbytes), 'g3_memset')
+        return a
+
+    def wrap(self, ptr, rows, cols, ld, dtype, keep=None):
+        """Borrow foreign device memory (e.g. torch.Tensor.data_ptr())."""
+        return DeviceArray(self, int(ptr), rows, cols, ld, dtype, owned=False, keep=keep)
+
+    def upload(self, a, dtype=None, pad_rows=None, pad_cols=None):
+        a = np.asarray(a)
+        if dtype is not None:
+            a = a.astype(dtype, copy=False)
+        if a.ndim == 1:
+            a = a[None, :]
+        rows, cols = a.shape
+        pr = rows if pad_rows is None else int(pad_rows)
+        pc = cols if pad_cols is None else int(pad_cols)
+        if (pr, pc) != (rows, cols):
+            b = np.zeros((pr, pc), dtype=a.dtype)
+            b[:rows, :cols] = a
+            a = b
+        a = np.ascontiguousarray(a)
+        d = self.alloc(pr, pc, a.dtype)
+        if a.nbytes:
+            _check(self, self.lib.g3_memcpy_h2d(self.ctx, d.ptr, a.ctypes.data, a.nbytes), 'g3_memcpy_h2d')
+        d.rows, d.cols = pr, pc
+        return d
+
+    def download(self, d, rows=None, cols=None):
+        rows = d.rows if rows is None else rows
+        cols = d.cols if cols is None else cols
+        full = np.empty((d.rows, d.ld), dtype=d.dtype)
+        if full.nbytes:
+            _check(self, self.lib.g3_memcpy_d2h(self.ctx, full.ctypes.data, d.ptr, full.nbytes), 'g3_memcpy_d2h')
+        return np.ascontiguousarray(full[:rows, :cols])
+
+    # ---- kernels (thin, argument-checked wrappers)
+    def gram(self, prog, X1, X2, d, out, n1pad, n2pad, flags):
+        dt = _lib.dtype_code(out.dtype)
+        rc = self.lib.g3_gram(self.ctx, C.byref(prog), X1.ptr, X1.rows, X1.ld,
+                              X2.ptr if X2 is not None else None, X2.rows if X2 is not None else 0,
+                              X2.ld if X2 is not None else 0, d, dt, out.ptr, out.ld, n1pad, n2pad, flags)
+        _check(self, rc, 'g3_gram')
+
+    def gram_diag(self, prog, X, d, out):
+        rc = self.lib.g3_gram_diag(self.ctx, C.byref(prog), X.ptr, X.rows, X.ld, d,
+                                   _lib.dtype_code(out.dtype), out.ptr)
+        _check(self, rc, 'g3_gram_diag')
+
+    def cov_lift(self, K, n):
+        _check(self, self.lib.g3_cov_lift(self.ctx, K.ptr, n, K.ld, _lib.dtype_code(K.dtype)), 'g3_cov_lift')
+
+    def scrub(self, A, n1, n2):
+        _check(self, self.lib.g3_scrub(self.ctx, A.ptr, n1, n2, A.ld, _lib.dtype_code(A.dtype)), 'g3_scrub')
+
+    def gemm_nt(self, Cm, A, B, m, n, k, alpha=1.0, beta=0.0, lower_only=False, c_off=0, a_off=0, b_off=0):
+        rc = self.lib.g3_gemm_nt(self.ctx, Cm.ptr + c_off, Cm.ld, A.ptr + a_off, A.ld, B.ptr + b_off, B.ld,
+                                 m, n, k, alpha, beta, _lib.dtype_code(Cm.dtype), int(lower_only))
+        _check(self, rc, 'g3_gemm_nt')
+
+    def potrf(self, A, n):
+        info = C.c_int(0)
+        rc = self.lib.g3_potrf(self.ctx, A.ptr, n, A.ld, _lib.dtype_code(A.dtype), None, C.byref(info))
+        _check(self, rc, 'g3_potrf')
+        return info.value
+
+    def potrf_robust(self, K, L, n, maxtries=20):
+        tries, fb, jit = C.c_int(0), C.c_int(0), C.c_double(0)
+        rc = self.lib.g3_potrf_robust(self.ctx, K.ptr, K.ld, L.ptr, L.ld, n, _lib.dtype_code(K.dtype),
+                                      maxtries, C.byref(tries), C.byref(fb), C.byref(jit))
+        _check(self, rc, 'g3_potrf_robust')
+        return tries.value, bool(fb.value), jit.value
+
+    def trsm_rlt(self, L, n, B, m, have_inverses=False):
+        rc = self.lib.g3_trsm_rlt(self.ctx, L.ptr, n, L.ld, B.ptr, m, B.ld, _lib.dtype_code(L.dtype), None)
+        _check(self, rc, 'g3_trsm_rlt')
+
+    def logp_terms(self, L, n, a):
+        out = (C.c_double * 4)()
+        rc = self.lib.g3_logp_terms(self.ctx, L.ptr, n, L.ld, a.ptr if a is not None else None,
+                                    _lib.dtype_code(L.dtype), out)
+        _check(self, rc, 'g3_logp_terms')
+        return list(out)
+
+    def rows_dot_ss(self, V, m, n, a, dot, ss):
+        rc = self.lib.g3_rows_dot_ss(self.ctx, V.ptr, m, n, V.ld, a.ptr if a is not None else None,
+                                     _lib.dtype_code(V.dtype), dot.ptr if dot is not None else None,
+                                     ss.ptr if ss is not None else None)
+        _check(self, rc, 'g3_rows_dot_ss')
+
+    def gp_factor(self, prog, X, N, d, delta, K, a):
+        out = (C.c_double * 6)()
+        rc = self.lib.g3_gp_factor(self.ctx, C.byref(prog), X.ptr, N, X.ld, d, delta.ptr,
+                                   _lib.dtype_code(K.dtype), K.ptr, K.ld, a.ptr, out)
+        _check(self, rc, 'g3_gp_factor')
+        return dict(logdet=out[0], quad=out[1], nonfinite=out[2], tries=int(out[3]),
+                    fallback=bool(out[4]), info=int(out[5]))
+
+    def gp_cross(self, prog, Xs, M, X, N, d, L, a, V, mu, ss):
+        rc = self.lib.g3_gp_cross(self.ctx, C.byref(prog), Xs.ptr, M, Xs.ld, X.ptr, N, X.ld, d, L.ptr, L.ld,
+                                  a.ptr if a is not None else None, _lib.dtype_code(L.dtype), V.ptr, V.ld,
+                                  mu.ptr if mu is not None else None, ss.ptr if ss is not None else None)
+        _check(self, rc, 'g3_gp_cross')
+
+
+# --------------------------------------------------------------------------- kernel programs
+def _expand(spec, leaves):
+    """Expand a kernel spec tree (see g3py_amd.processes.hypers.kernels.Kernel.spec) into
+    shift + sum_p coef_p * prod leaf  (KernelSum/Prod/Scale/Shift, kernels.py:192-244)."""
+    op = spec[0]
+    if op == 'sum':
+        c1, t1 = _expand(spec[1], leaves)
+        c2, t2 = _expand(spec[2], leaves)
+        return c1 + c2, t1 + t2
+    if op == 'prod':
+        c1, t1 = _expand(spec[1], leaves)
+        c2, t2 = _expand(spec[2], leaves)
+        terms = [(a * b, fa + fb) for a, fa in t1 for b, fb in t2]
+        if c1 != 0.0:
+            terms += [(c1 * b, fb) for b, fb in t2]
+        if c2 != 0.0:
+            terms += [(c2 * a, fa) for a, fa in t1]
+        return c1 * c2, terms
+    if op == 'scale':
+        c, t = _expand(spec[2], leaves)
+        e = float(spec[1])
+        return e * c, [(e * a, f) for a, f in t]
+    if op == 'shift':
+        c, t = _expand(spec[2], leaves)
+        return float(spec[1]) + c, t
+    leaves.append(spec)
+    return 0.0, [(1.0, (len(leaves) - 1,))]
+
+
+def compile_spec(spec, d):
+    """spec tree -> g3_kernel_prog for an input with d columns."""
+    leaves = []
+    shift, terms = _expand(spec, leaves)
+    if len(leaves) > _lib.G3_MAXLEAF or len(terms) > _lib.G3_MAXPROD:
+        raise G3Error('kernel expression too large for one g3_kernel_prog (%d leaves, %d products)'
+                      % (len(leaves), len(terms)))
+    if d > _lib.G3_MAXCOLS:
+        raise G3Error('inputs with more than %d columns are not supported' % _lib.G3_MAXCOLS)
+    prog = KernelProg()
+    prog.nleaf, prog.nprod, prog.shift = len(leaves), len(terms), float(shift)
+    for i, lf in enumerate(leaves):
+        L = prog.leaf[i]
+        kind = lf[0]
+        L.kind = _lib.KINDS[kind]
+        L.var = float(lf[1])
+        dims = lf[-1] if kind != 'NOISE' else None
+        dims = np.arange(d) if dims is None else np.atleast_1d(np.asarray(dims)).astype(int)
+        dims = np.where(dims < 0, dims + d, dims)
+        if len(dims) > _lib.G3_MAXD or (len(dims) and (dims.min() < 0 or dims.max() >= d)):
+            raise G3Error('bad dims for kernel leaf %s' % kind)
+        L.ndims = len(dims)
+        for k, c in enumerate(dims):
+            L.dims[k] = int(c)
+
+        def put(dst, v):
+            v = np.broadcast_to(np.asarray(v, dtype=np.float64), (len(dims),))
+            for k in range(len(dims)):
+                dst[k] = float(v[k])
+        if kind in ('SE', 'OU', 'MAT32', 'MAT52'):
+            put(L.rate, lf[2])
+        elif kind == 'RQ':
+            put(L.rate, lf[2])
+            L.alpha = float(lf[3])
+        elif kind in ('COS', 'SINC'):
+            put(L.freq, lf[2])
+        elif kind in ('SIN', 'SM'):
+            put(L.freq, lf[2])
+            put(L.rate, lf[3])
+    for p, (coef, fac) in enumerate(terms):
+        if len(fac) > _lib.G3_MAXFAC:
+            raise G3Error('product of more than %d kernels is not supported' % _lib.G3_MAXFAC)
+        prog.prod[p].coef = float(coef)
+        prog.prod[p].nfac = len(fac)
+        for k, f in enumerate(fac):
+            prog.prod[p].fac[k] = int(f)
+    return prog

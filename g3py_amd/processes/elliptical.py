@@ -1,0 +1,271 @@
+"""EllipticalProcess: prior / posterior location, covariance, Cholesky, diagonal and sd of a
+GP (g3py/processes/elliptical.py:18-217) computed by libg3hip.
+
+The reference recompiles and recomputes Gram + an O(N^3) LU solve for EVERY requested
+statistic.  Here one Cholesky factor of K(X,X)+noise is built per
+(params, inputs, outputs) triple by `g3_gp_factor` and kept on the device; every posterior
+statistic is a cross-Gram + multi-right-hand-side triangular solve against it
+(`g3_gp_cross`).  Equal to the reference's `solve(K, .)` in exact arithmetic.
+"""
+import numpy as np
+
+from .. import _lib
+from ..device import Device, compile_spec
+from .hypers import HyperVar
+from .hypers.kernels import Kernel, KernelSum, KernelNoise
+from .hypers.means import Mean
+from .hypers.mappings import Mapping, Identity
+from .stochastic import StochasticProcess
+
+SENTINEL = np.float32(-1e30)     # gaussian.py:238-241
+
+
+class EllipticalProcess(StochasticProcess):
+    def __init__(self, space=None, location: Mean = None, kernel: Kernel = None, mapping: Mapping = None,
+                 degree=None, noisy=True, var_noise=None, *args, **kwargs):
+        self.f_location = location
+        self.f_degree = degree
+        self.f_mapping = Identity() if mapping is None else mapping
+        self.f_kernel = kernel
+        if noisy:   # elliptical.py:26-31
+            self.f_kernel_noise = KernelSum(self.f_kernel, KernelNoise(name='Noise', var=var_noise))
+        else:
+            self.f_kernel_noise = self.f_kernel
+        self._cache = None
+        kwargs['space'] = space
+        super().__init__(*args, **kwargs)
+
+    @property
+    def device(self):
+        if self._device is None:
+            self._device = Device.default()
+        return self._device
+
+    def _check_hypers(self):
+        """elliptical.py:35-52"""
+        x = self._inputs
+        self.f_location.check_dims(x)
+        self.f_kernel_noise.check_dims(x)
+        self.f_mapping.check_dims(x)
+        self.f_location.check_hypers(self.name + '_')
+        self.f_kernel_noise.check_hypers(self.name + '_')
+        self.f_mapping.check_hypers(self.name + '_')
+
+    def default_hypers(self):
+        x, y = self.inputs, self.outputs
+        return {**self.f_location.default_hypers_dims(x, y), **self.f_kernel_noise.default_hypers_dims(x, y),
+                **self.f_mapping.default_hypers_dims(x, y)}
+
+    # ---------------------------------------------------------------- helpers
+    def _values(self, params):
+        """transformed-space params dict -> natural-space values by hyper name; also the
+        log-Jacobian term of the FlatExp variables (hypers/__init__.py:199-200)."""
+        values, logjac = {}, 0.0
+        for v in self.model.vars:
+            p = np.asarray(params[v.key], dtype=np.float64)
+            if v.positive:
+                with np.errstate(over='ignore'):
+                    e = np.exp(p)
+                logjac += float(np.sum(np.where(e > 1e-6, 0.0, -np.inf)))
+                values[v.name] = e
+            else:
+                values[v.name] = p
+        return values, logjac
+
+    def _x(self, a):
+        a = np.asarray(a, dtype=self.dtype)
+        return a.reshape(len(a), 1) if a.ndim < 2 else np.ascontiguousarray(a)
+
+    def _prog(self, kernel, values, d):
+        return compile_spec(kernel.spec(values, d), d)
+
+    def _factor(self, values, inputs, outputs):
+        """L = cholesky_robust(tt_to_cov(K_noise(X, X))), a = L^-1 (T^-1(y) - m(X)) on the device
+        (elliptical.py:63,68,71; gaussian.py:208-212, 251-260), cached across statistics."""
+        X = self._x(inputs)
+        y = np.asarray(outputs, dtype=self.dtype).reshape(-1)
+        key = (tuple((k, np.asarray(v).tobytes()) for k, v in sorted(values.items())), X.shape)
+        c = self._cache
+        if c is not None and c['key'] == key and np.array_equal(c['X'], X) and np.array_equal(c['y'], y):
+            return c
+        dev = self.device
+        N, d = X.shape
+        with np.errstate(all='ignore'):
+            mapped = np.asarray(self.f_mapping.inv(y, values), dtype=self.dtype)      # elliptical.py:63
+            mu = self.f_location(X, values)
+            delta = mapped - mu                                                       # gaussian.py:208
+            det_m = self.f_mapping.logdet_dinv(y, values)                             # gaussian.py:225
+        # tt_to_num(mapping.inv(outputs)) is what the posterior uses (elliptical.py:63)
+        mapped_num = np.where(np.isnan(mapped), 0, np.where(np.isinf(mapped), self.dtype.type(np.float32(1e10)), mapped))
+        Np = _lib.roundup(N)
+        Xd = dev.upload(X)
+        Kd = dev.alloc(Np, Np, self.dtype)
+        ad = dev.alloc(1, Np, self.dtype)
+        c = dict(key=key, X=X.copy(), y=y.copy(), N=N, d=d, Np=Np, Xd=Xd, Kd=Kd, ad=ad, mu=mu, det_m=det_m,
+                 delta=delta, delta_post=mapped_num - mu, stats=None, which=None)
+        c['same_delta'] = bool(np.array_equal(c['delta'], c['delta_post']))
+        self._cache = c
+        return c
+
+    def _solve(self, c, values, which):
+        """run g3_gp_factor with delta (logp) or the scrubbed delta (posterior)"""
+        if c['which'] == which or (c['which'] is not None and c['same_delta']):
+            return c['stats']
+        dev = self.device
+        dl = c['delta'] if which == 'logp' else c['delta_post']
+        finite = np.all(np.isfinite(dl))
+        dvec = dev.upload(np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
+        prog = self._prog(self.f_kernel_noise, values, c['d'])
+        st = dev.gp_factor(prog, c['Xd'], c['N'], c['d'], dvec, c['Kd'], c['ad'])
+        st['delta_finite'] = bool(finite)
+        c['stats'], c['which'] = st, which
+        return st
+
+    def _cross(self, c, values, space, noise):
+        """V = K(space, X) L^-T, mu = V a, ss = |V_i|^2 (elliptical.py:78-91)"""
+        dev = self.device
+        S = self._x(space)
+        M = S.shape[0]
+        Mp = _lib.roundup(M)
+        Sd = dev.upload(S)
+        V = dev.alloc(Mp, c['Np'], self.dtype)
+        mu = dev.alloc(1, Mp, self.dtype)
+        ss = dev.alloc(1, Mp, self.dtype)
+        kern = self.f_kernel_noise if noise else self.f_kernel
+        dev.gp_cross(self._prog(kern, values, c['d']), Sd, M, c['Xd'], c['N'], c['d'], c['Kd'], c['ad'], V, mu, ss)
+        return V, dev.download(mu, 1, M)[0], dev.download(ss, 1, M)[0], M, Mp
+
+    def _prior_gram(self, values, space, noise, pad=False):
+        """prior_kernel_space = tt_to_cov(K_noise(space)) / prior_kernel_f_space = K_f(space)
+        (elliptical.py:70,74) as a device matrix"""
+        dev = self.device
+        S = self._x(space)
+        M, d = S.shape
+        Mp = _lib.roundup(M) if pad else M
+        Sd = dev.upload(S)
+        K = dev.alloc(Mp, Mp, self.dtype)
+        kern = self.f_kernel_noise if noise else self.f_kernel
+        dev.gram(self._prog(kern, values, d), Sd, None, d, K, Mp, Mp, _lib.G3_GRAM_SCRUB if noise else 0)
+        if noise:
+            dev.cov_lift(K, M)
+        return K, M, Mp
+
+    def _prior_diag(self, values, space, noise):
+        dev = self.device
+        S = self._x(space)
+        M, d = S.shape
+        Sd = dev.upload(S)
+        out = dev.alloc(1, M, self.dtype)
+        kern = self.f_kernel_noise if noise else self.f_kernel
+        dev.gram_diag(self._prog(kern, values, d), Sd, d, out)
+        dg = dev.download(out, 1, M)[0]
+        if noise:   # tt_to_cov acts on the whole matrix; its effect on the diagonal:
+            dg = np.where(np.isnan(dg), 0, np.where(np.isinf(dg), self.dtype.type(np.float32(1e10)), dg))
+            m = dg.min()
+            if not m > 0:
+                dg = dg + (self.dtype.type(np.float32(1e-6)) - m)
+        return dg
+
+    # ---------------------------------------------------------------- statistics (th_* of the reference)
+    def th_define_process(self):
+        pass   # the symbolic graph of elliptical.py:60-107 is replaced by the methods below
+
+    def th_mapping_inv(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        with np.errstate(all='ignore'):
+            r = np.asarray(self.f_mapping.inv(np.asarray(outputs, dtype=self.dtype), values))
+        return np.where(np.isnan(r), 0, np.where(np.isinf(r), self.dtype.type(np.float32(1e10)), r))
+
+    def th_mapping(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        with np.errstate(all='ignore'):
+            r = np.asarray(self.f_mapping(np.asarray(outputs, dtype=self.dtype), values))
+        return np.where(np.isnan(r), 0, np.where(np.isinf(r), self.dtype.type(np.float32(1e10)), r))
+
+    def th_location(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        S = self._x(space)
+        loc = self.f_location(S, values)
+        if prior:
+            return loc                                                    # elliptical.py:122-123
+        c = self._factor(values, inputs, outputs)
+        self._solve(c, values, 'post')
+        _, mu, _, _, _ = self._cross(c, values, space, noise)
+        return loc + mu                                                   # elliptical.py:81-84
+
+    def th_kernel(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        dev = self.device
+        if prior:
+            K, M, _ = self._prior_gram(values, space, noise)
+            return dev.download(K)
+        c = self._factor(values, inputs, outputs)
+        self._solve(c, values, c['which'] or 'post')
+        V, _, _, M, Mp = self._cross(c, values, space, noise)
+        K, _, _ = self._prior_gram(values, space, noise, pad=True)
+        dev.gemm_nt(K, V, V, Mp, Mp, c['Np'], alpha=-1.0, beta=1.0)        # elliptical.py:86-91
+        return dev.download(K, M, M)
+
+    def th_cholesky(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        dev = self.device
+        K = self.th_kernel(space, inputs, outputs, vector, params, prior=prior, noise=noise)
+        M = K.shape[0]
+        Kd, Ld = dev.upload(K), dev.alloc(M, M, self.dtype)
+        dev.potrf_robust(Kd, Ld, M)                                       # elliptical.py:72,76,88,92
+        return dev.download(Ld)
+
+    def th_kernel_diag(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        dg = self._prior_diag(values, space, noise)
+        if not prior:
+            c = self._factor(values, inputs, outputs)
+            self._solve(c, values, c['which'] or 'post')
+            _, _, ss, _, _ = self._cross(c, values, space, noise)
+            dg = dg - ss
+        return np.where(dg < 0, self.dtype.type(0), dg)                   # tt_to_bounded(., 0) elliptical.py:94-97
+
+    def th_kernel_sd(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        return np.sqrt(self.th_kernel_diag(space, inputs, outputs, vector, params, prior=prior, noise=noise))
+
+    def th_cholesky_diag(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        return np.diag(self.th_kernel_sd(space, inputs, outputs, vector, params, prior=prior, noise=noise))
+
+    def _loc_sd(self, space, inputs, outputs, params, prior, noise, sd_noise=None):
+        """location and sd from ONE cross solve (the reference runs two compiled functions)"""
+        values, _ = self._values(params)
+        S = self._x(space)
+        loc = self.f_location(S, values)
+        sd_noise = noise if sd_noise is None else sd_noise
+        dg = self._prior_diag(values, space, sd_noise)
+        if not prior:
+            c = self._factor(values, inputs, outputs)
+            self._solve(c, values, 'post')
+            _, mu, ss, _, _ = self._cross(c, values, space, noise)
+            loc = loc + mu
+            dg = dg - ss
+        dg = np.where(dg < 0, self.dtype.type(0), dg)
+        return loc, np.sqrt(dg), values
+
+    def th_median(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        return self.f_mapping(self.th_location(space, inputs, outputs, vector, params, prior, noise), values)
+
+    def th_mean(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        values, _ = self._values(params)
+        return self.f_mapping(self.th_location(space, inputs, outputs, vector, params, prior, noise), values)
+
+    def th_variance(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        return self.th_kernel_diag(space, inputs, outputs, vector, params, prior=prior, noise=noise)
+
+    def th_std(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        return np.sqrt(self.th_variance(space, inputs, outputs, vector, params, prior=prior, noise=noise))
+
+    def th_covariance(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        return self.th_kernel(space, inputs, outputs, vector, params, prior=prior, noise=noise)
+
+    _methods = (('mean', 'th_mean'), ('median', 'th_median'), ('variance', 'th_variance'), ('std', 'th_std'),
+                ('covariance', 'th_covariance'), ('logpredictive', 'th_logpredictive'), ('logp', 'th_logp'),
+                ('loglike', 'th_loglike'), ('mapping', 'th_mapping'), ('mapping_inv', 'th_mapping_inv'),
+                ('location', 'th_location'), ('kernel', 'th_kernel'), ('cholesky', 'th_cholesky'),
+                ('kernel_diag', 'th_kernel_diag'), ('kernel_sd', 'th_kernel_sd'),
+                ('cholesky_diag', 'th_cholesky_diag'))

@@ -1,0 +1,167 @@
+"""Warping maps on the path: Identity, LinearMapping, LogShifted, BoxCoxLinear, ArcsinhLinear
+(g3py/processes/hypers/mappings.py:88-215, 309-333): element-wise O(N) host arithmetic
+(`__call__`, `inv`, `logdet_dinv`) around the device path."""
+import numpy as np
+
+from . import Hypers, value_of
+
+
+class Mapping(Hypers):
+    def __call__(self, x, values=None):
+        raise NotImplementedError
+
+    def inv(self, y, values=None):
+        raise NotImplementedError
+
+    def logdet_dinv(self, y, values=None):
+        raise NotImplementedError
+
+
+class Identity(Mapping):
+    def __init__(self, y=None, name=None):
+        super().__init__(y, name)
+
+    def __call__(self, x, values=None):
+        return x
+
+    def inv(self, y, values=None):
+        return y
+
+    def logdet_dinv(self, y, values=None):
+        return 0.0
+
+
+class LinearMapping(Mapping):
+    def __init__(self, y=None, name=None, shift=None, scale=None):
+        super().__init__(y, name)
+        self.shift = shift
+        self.scale = scale
+
+    def check_hypers(self, parent=''):
+        if self.shift is None:
+            self.shift = Hypers.Flat(parent + self.name + '_shift')
+        if self.scale is None:
+            self.scale = Hypers.FlatExp(parent + self.name + '_scale')
+        self.hypers += [self.shift, self.scale]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.shift: 0.0, self.scale: 1.0}
+
+    def _p(self, values, t):
+        return t(value_of(self.shift, values)), t(value_of(self.scale, values))
+
+    def __call__(self, x, values=None):
+        shift, scale = self._p(values, x.dtype.type)
+        return scale * (x - shift)
+
+    def inv(self, y, values=None):
+        shift, scale = self._p(values, y.dtype.type)
+        return y / scale + shift
+
+    def logdet_dinv(self, y, values=None):
+        shift, scale = self._p(values, y.dtype.type)
+        return -y.dtype.type(y.shape[0]) * np.log(scale)
+
+
+class LogShifted(Mapping):
+    def __init__(self, y=None, name=None, shift=None):
+        super().__init__(y, name)
+        self.shift = shift
+
+    def check_hypers(self, parent=''):
+        if self.shift is None:
+            self.shift = Hypers.Flat(parent + self.name + '_shift')
+        self.hypers += [self.shift]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.shift: y.min() - 1}
+
+    def __call__(self, x, values=None):
+        return np.exp(x) + x.dtype.type(value_of(self.shift, values))
+
+    def inv(self, y, values=None):
+        t = y.dtype.type
+        return np.log(np.maximum(y - t(value_of(self.shift, values)), t(np.float32(1e-32))))
+
+    def logdet_dinv(self, y, values=None):
+        with np.errstate(all='ignore'):
+            return -np.sum(np.log(y - y.dtype.type(value_of(self.shift, values))))
+
+
+class BoxCoxLinear(Mapping):
+    def __init__(self, y=None, name=None, shift=None, scale=None, power=None):
+        super().__init__(y, name)
+        self.shift = shift
+        self.scale = scale
+        self.power = power
+
+    def check_hypers(self, parent=''):
+        if self.shift is None:
+            self.shift = Hypers.Flat(parent + self.name + '_shift')
+        if self.scale is None:
+            self.scale = Hypers.FlatExp(parent + self.name + '_scale')
+        if self.power is None:
+            self.power = Hypers.FlatExp(parent + self.name + '_power')
+        self.hypers += [self.shift, self.scale, self.power]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.shift: 1.0, self.scale: 1.0, self.power: 1.0}
+
+    def _p(self, values, t):
+        return (t(value_of(self.shift, values)), t(value_of(self.scale, values)),
+                t(value_of(self.power, values)))
+
+    def __call__(self, x, values=None):
+        t = x.dtype.type
+        shift, scale, power = self._p(values, t)
+        scaled = power * x + t(1)
+        transformed = np.sign(scaled) * np.abs(scaled) ** (t(1) / power)
+        return transformed / scale - shift
+
+    def inv(self, y, values=None):
+        t = y.dtype.type
+        shift, scale, power = self._p(values, t)
+        shifted = scale * (y + shift)
+        with np.errstate(all='ignore'):
+            if power < np.float32(1e-5):
+                return np.log(shifted)
+            return ((np.sign(shifted) * np.abs(shifted) ** power) - t(1)) / power
+
+    def logdet_dinv(self, y, values=None):
+        t = y.dtype.type
+        shift, scale, power = self._p(values, t)
+        with np.errstate(all='ignore'):
+            return (power - t(1)) * np.sum(np.log(np.abs(scale * (y + shift)))) + t(y.shape[0]) * np.log(scale)
+
+
+class ArcsinhLinear(Mapping):
+    def __init__(self, y=None, name=None, shift=None, scale=None):
+        super().__init__(y, name)
+        self.shift = shift
+        self.scale = scale
+
+    def check_hypers(self, parent=''):
+        if self.shift is None:
+            self.shift = Hypers.Flat(parent + self.name + '_shift')
+        if self.scale is None:
+            self.scale = Hypers.FlatExp(parent + self.name + '_scale')
+        self.hypers += [self.shift, self.scale]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.shift: np.mean(y), self.scale: np.std(y)}
+
+    def _p(self, values, t):
+        return t(value_of(self.shift, values)), t(value_of(self.scale, values))
+
+    def __call__(self, x, values=None):
+        shift, scale = self._p(values, x.dtype.type)
+        return np.sinh((x - shift) / scale)
+
+    def inv(self, y, values=None):
+        shift, scale = self._p(values, y.dtype.type)
+        return np.arcsinh(y) * scale + shift
+
+    def logdet_dinv(self, y, values=None):
+        t = y.dtype.type
+        shift, scale = self._p(values, t)
+        return t(y.shape[0]) * np.log(scale) - t(0.5) * np.sum(np.log1p(y ** 2))

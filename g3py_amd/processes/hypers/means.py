@@ -1,0 +1,62 @@
+"""Location functions on the path: Zero, Bias, Linear
+(g3py/processes/hypers/means.py:6-27, 117-159).  O(N d) host arithmetic feeding the device
+path; `eval` takes natural-space hyper values."""
+import numpy as np
+
+from . import Hypers, value_of
+
+
+class Mean(Hypers):
+    def eval(self, x, values):
+        raise NotImplementedError
+
+    def __call__(self, x, values=None):
+        x = np.asarray(x)
+        return self.eval(x[:, self.dims] if self.dims is not None else x, values or {})
+
+Location = Mean
+
+
+class Zero(Mean):
+    def eval(self, x, values):
+        return np.zeros(x.shape[0], dtype=x.dtype)
+
+
+class Bias(Mean):
+    def __init__(self, x=None, name=None, bias=None):
+        super().__init__(x, name)
+        self.bias = bias
+
+    def check_hypers(self, parent=''):
+        super().check_hypers(parent=parent)
+        if self.bias is None:
+            self.bias = Hypers.Flat(parent + self.name + '_Bias')
+        self.hypers += [self.bias]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.bias: y.mean()}
+
+    def eval(self, x, values):
+        return x.dtype.type(value_of(self.bias, values)) * np.ones(x.shape[0], dtype=x.dtype)
+
+
+class Linear(Mean):
+    def __init__(self, x=None, name=None, constant=None, coeff=None):
+        super().__init__(x, name)
+        self.constant = constant
+        self.coeff = coeff
+
+    def check_hypers(self, parent=''):
+        super().check_hypers(parent=parent)
+        if self.constant is None:
+            self.constant = Hypers.Flat(parent + self.name + '_Constant')
+        if self.coeff is None:
+            self.coeff = Hypers.Flat(parent + self.name + '_Coeff', shape=self.shape)
+        self.hypers += [self.constant, self.coeff]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.constant: y.mean(), self.coeff: y.mean() / x.mean(axis=0)}
+
+    def eval(self, x, values):
+        coeff = np.broadcast_to(np.asarray(value_of(self.coeff, values), dtype=x.dtype), (x.shape[1],))
+        return x.dtype.type(value_of(self.constant, values)) + np.dot(x, coeff)

@@ -1,0 +1,371 @@
+"""StochasticProcess: the user-facing API, parameter conventions and compiled-method dispatch
+of g3py/processes/stochastic.py:20-105, 150-201, 300-313, 385-430, 444-513, rebuilt on the
+HIP path.  Optimisers, MCMC drivers, plotting and pickling are out of scope.
+"""
+import types
+
+import numpy as np
+
+from ..libs import DictObj, clone
+from ..libs.tensors import makefn
+from .hypers import Model
+
+
+class GraphicalModel:
+    """The slice of g3py/bayesian/models.py:56-182 the path depends on: the variable registry,
+    default / current parameters and the dict <-> flat-array bijection (models.py:143-155)."""
+    active = None
+
+    def __init__(self, name='GM'):
+        self.name = name
+        self.model = Model(name)
+        self.components = DictObj()
+        self.current_params = None
+
+    def add_component(self, component):
+        self.components[component.name] = component
+
+    def compile_components(self, precompile=False):
+        pass
+
+    # ---- bijection (pm.DictToArrayBijection over vars in creation order)
+    @property
+    def ndim(self):
+        return self.model.ndim
+
+    def dict_to_array(self, params):
+        return np.concatenate([np.asarray(params[v.key], dtype=np.float64).reshape(-1)
+                               for v in self.model.vars]) if self.model.vars else np.zeros(0)
+
+    def array_to_dict(self, array):
+        array = np.asarray(array, dtype=np.float64).reshape(-1)
+        r, o = DictObj(), 0
+        for v in self.model.vars:
+            r[v.key] = array[o:o + v.size].reshape(v.shape)
+            o += v.size
+        return r
+
+    class _Bijection:
+        def __init__(self, gm):
+            self.map = gm.dict_to_array
+            self.rmap = gm.array_to_dict
+
+    @property
+    def bijection(self):
+        return GraphicalModel._Bijection(self)
+
+    # ---- parameters
+    def set_params(self, params=None):
+        self.current_params = None if params is None else DictObj(params)
+
+    @property
+    def params(self):
+        if self.current_params is not None:
+            return clone(self.current_params)
+        return self.params_default
+
+    @property
+    def params_test(self):
+        return DictObj(self.model.test_point)
+
+    @property
+    def params_default(self):
+        """models.py:174-182 + transformed_hypers (:46-53): defaults in transformed space"""
+        default = self.params_test
+        for name, component in self.components.items():
+            for k, v in component.default_hypers().items():
+                if k in self.model.vars:
+                    v = np.asarray(v, dtype=np.float64)
+                    with np.errstate(all='ignore'):
+                        default[k.key] = (np.log(v) if k.positive else v).reshape(k.shape)
+        return default
+
+    def transform_params(self, params, to_dict=True, to_transformed=True, complete=False):
+        """natural <-> transformed names and values (models.py:232-260)"""
+        if not isinstance(params, dict):
+            params = self.array_to_dict(params)
+        r = DictObj(self.params) if (complete or not to_dict) else DictObj()
+        by_name = {v.name: v for v in self.model.vars}
+        by_key = {v.key: v for v in self.model.vars}
+        for k, val in params.items():
+            if to_transformed and k in by_name and by_name[k].positive:
+                r[by_name[k].key] = np.log(val)
+            elif (not to_transformed) and k in by_key and by_key[k].positive:
+                r[by_key[k].name] = np.exp(val)
+            else:
+                r[k] = val
+        return r if to_dict else self.dict_to_array(r)
+
+
+class StochasticProcess:
+    """stochastic.py:20-105 (construction), :150-201 (space/observations), :385-430
+    (method dispatch), :444-513 (predict)."""
+
+    def __init__(self, space=None, order=None, inputs=None, outputs=None, hidden=None, index=None,
+                 name='SP', distribution=None, active=False, precompile=False, file=None, load=True,
+                 compile_logp=True, dtype=np.float64, device=None, *args, **kwargs):
+        ndim = 1
+        self.makefn = makefn
+        if space is not None:
+            if hasattr(space, 'shape'):
+                if len(space.shape) > 1:
+                    ndim = space.shape[1]
+            else:
+                ndim = int(space)
+        self.nspace = ndim
+        self.name = name
+        self.dtype = np.dtype(dtype)
+        self._device = device
+        dt = self.dtype
+        # the reference's Theano shared variables start as these 2-point dummies (:46-56)
+        self._order = np.array([0.0, 1.0], dtype=dt)
+        self._space = np.array([[0.0, 1.0]] * self.nspace, dtype=dt).T
+        self._index = np.array([0.0, 1.0], dtype=dt)
+        self._inputs = np.array([[0.0, 1.0]] * self.nspace, dtype=dt).T
+        self._outputs = np.array([0.0, 1.0], dtype=dt)
+        self.is_observed = False
+        self.np_hidden = None
+        self.distribution = distribution
+        if active is True:
+            if GraphicalModel.active is None:
+                GraphicalModel.active = GraphicalModel('GM_' + self.name)
+            self.active = GraphicalModel.active
+        elif active is False:
+            self.active = GraphicalModel('GM_' + self.name)
+        else:
+            self.active = active
+        self.active.add_component(self)
+        self.compiles = DictObj()
+        self.precompile = precompile
+        self.file = file   # accepted for signature compatibility; pickling is out of scope
+        with self.model:
+            self._check_hypers()
+            self.th_define_process()
+            self.active.compile_components()
+        self.set_space(space=space, hidden=hidden, order=order, inputs=inputs, outputs=outputs, index=index)
+        self._compile_methods(compile_logp)
+        if hidden is None:
+            self.hidden = hidden
+
+    # ---- parameters
+    def set_params(self, *args, **kwargs):
+        return self.active.set_params(*args, **kwargs)
+
+    def transform_params(self, *args, **kwargs):
+        return self.active.transform_params(*args, **kwargs)
+
+    @property
+    def model(self):
+        return self.active.model
+
+    @property
+    def params(self):
+        return self.active.params
+
+    @property
+    def params_default(self):
+        return self.active.params_default
+
+    @property
+    def params_test(self):
+        return self.active.params_test
+
+    def filter_params(self, params):
+        return {k: params[k] for k in self.model.test_point}   # models.py:471-473
+
+    # ---- space and observations (stochastic.py:150-201, 219-259: copy on set)
+    def set_space(self, space=None, hidden=None, order=None, inputs=None, outputs=None, index=None):
+        if space is not None:
+            space = np.asarray(space)
+            if len(space.shape) < 2:
+                space = space.reshape(len(space), 1)
+            self.space = space
+        if hidden is not None:
+            hidden = np.asarray(hidden)
+            if len(hidden.shape) > 1:
+                hidden = hidden.reshape(len(hidden))
+            self.hidden = hidden
+        if order is not None:
+            order = np.asarray(order)
+            if len(order.shape) > 1:
+                order = order.reshape(len(order))
+            self.order = order
+        elif self.nspace == 1:
+            self.order = self.space.reshape(len(self.space))
+        if inputs is not None:
+            inputs = np.asarray(inputs)
+            if len(inputs.shape) < 2:
+                inputs = inputs.reshape(len(inputs), 1)
+            self.inputs = inputs
+        if outputs is not None:
+            outputs = np.asarray(outputs)
+            if len(outputs.shape) > 1:
+                outputs = outputs.reshape(len(outputs))
+            self.outputs = outputs
+        if index is not None:
+            index = np.asarray(index)
+            if len(index.shape) > 1:
+                index = index.reshape(len(index))
+            self.index = index
+        elif self.nspace == 1:
+            self.index = self.inputs.reshape(len(self.inputs))
+        if len(self.order) != len(self.space):
+            self.order = np.arange(len(self.space))
+        if len(self.index) != len(self.inputs):
+            self.index = np.arange(len(self.inputs))
+
+    def observed(self, inputs=None, outputs=None, order=None, index=None, hidden=None):
+        self.set_space(inputs=inputs, outputs=outputs, order=order, index=index, hidden=hidden)
+        self.is_observed = not (inputs is None and outputs is None)
+
+    def _get(self, name):
+        return getattr(self, '_' + name).copy()
+
+    def _set(self, name, value):
+        setattr(self, '_' + name, np.array(value, dtype=self.dtype, copy=True))
+
+    space = property(lambda s: s._get('space'), lambda s, v: s._set('space', v))
+    inputs = property(lambda s: s._get('inputs'), lambda s, v: s._set('inputs', v))
+    outputs = property(lambda s: s._get('outputs'), lambda s, v: s._set('outputs', v))
+    order = property(lambda s: s._get('order'), lambda s, v: s._set('order', v))
+    index = property(lambda s: s._get('index'), lambda s, v: s._set('index', v))
+
+    @property
+    def hidden(self):
+        return self.np_hidden
+
+    @hidden.setter
+    def hidden(self, value):
+        self.np_hidden = value
+
+    # ---- to be provided by subclasses
+    def default_hypers(self):
+        return {}
+
+    def _check_hypers(self):
+        pass
+
+    def th_define_process(self):
+        pass
+
+    def sampler(self, samples=1, prior=False, noise=False):
+        pass
+
+    def quantiler(self, q=0.975, prior=False, noise=False, simulations=None):
+        pass
+
+    # names of the statistics a subclass implements as  fn(ctx, prior, noise, **kw)
+    _methods = ()
+
+    def _compile_methods(self, compile_logp=True):
+        """bind every statistic as a lazily 'compiled' method (stochastic.py:328-380)"""
+        if self.compiles is None:
+            self.compiles = DictObj()
+        for public, th_name in self._methods:
+            setattr(self, public, types.MethodType(self._method_name(th_name), self))
+        if compile_logp:
+            # the reference force-compiles logp on the 2-point dummy data here; our kernels are
+            # already compiled, so only the registry entries are created
+            for prior in (False, True):
+                self._compiled('th_logp', prior, False, True, (), {})
+
+    def _compiled(self, method, prior, noise, array, args, kwargs):
+        name = ('prior' if prior else 'posterior') + method.replace('th', '')
+        if noise:
+            name += '_noise'
+        if len(args) > 0:
+            name += str(args)
+        if len(kwargs) > 0:
+            name += str(kwargs)
+        if not hasattr(self.compiles, name):
+            impl = getattr(self, method)
+
+            def fn(space, inputs, outputs, vector, params, _impl=impl):
+                return _impl(space, inputs, outputs, vector, params, prior=prior, noise=noise, *args, **kwargs)
+            th_vars = [self.name + '_space_th', self.name + '_inputs_th', self.name + '_outputs_th',
+                       self.name + '_vector_th'] + [v.key for v in self.model.vars]
+            self.compiles[name] = self.makefn(th_vars, fn, givens=[('space', 'space_th'), ('inputs', 'inputs_th'),
+                                                                    ('outputs', 'outputs_th')],
+                                              bijection=None, precompile=self.precompile)
+        if array:
+            if not hasattr(self.compiles, 'array_' + name):
+                self.compiles['array_' + name] = self.compiles[name].clone(self.active.bijection.rmap)
+            name = 'array_' + name
+        return self.compiles[name]
+
+    @staticmethod
+    def _method_name(method=None):
+        def lambda_method(self, params=None, space=None, inputs=None, outputs=None, vector=[], prior=False,
+                          noise=False, array=False, *args, **kwargs):
+            if params is None:
+                if array:
+                    params = self.active.dict_to_array(self.params)
+                else:
+                    params = self.params
+            elif not array:
+                params = self.filter_params(params)
+            if inputs is None and not self.is_observed:
+                prior = True
+            if space is None:
+                space = self.space
+            if inputs is None:
+                inputs = self.inputs
+            if outputs is None:
+                outputs = self.outputs
+            kwargs.pop('simulations', None)   # accepted and unused, as in the reference's th_* methods
+            return self._compiled(method, prior, noise, array, args, kwargs)(params, space, inputs, outputs, vector)
+        return lambda_method
+
+    @property
+    def executed(self):
+        return {k: v.executed for k, v in self.compiles.items()}
+
+    # ---- predict (stochastic.py:444-513)
+    def predict(self, params=None, space=None, inputs=None, outputs=None, mean=True, std=True, var=False,
+                cov=False, median=False, quantiles=False, quantiles_noise=False, samples=0, distribution=False,
+                prior=False, noise=False, simulations=None):
+        if params is None:
+            params = self.params
+        if not self.is_observed:
+            prior = True
+        if space is None:
+            space = self.space
+        if inputs is None:
+            inputs = self.inputs
+        if outputs is None:
+            outputs = self.outputs
+        n_simulations = 1
+        if type(simulations) is int:
+            n_simulations = simulations
+            simulations = self.sampler(params, space, inputs, outputs, prior=prior, noise=noise, samples=simulations)
+        values = DictObj()
+        if mean:
+            values['mean'] = self.mean(params, space, inputs, outputs, prior=prior, noise=noise)
+        if var:
+            values['variance'] = self.variance(params, space, inputs, outputs, prior=prior, noise=noise)
+        if std:
+            values['std'] = self.std(params, space, inputs, outputs, prior=prior, noise=noise)
+        if cov:
+            values['covariance'] = self.covariance(params, space, inputs, outputs, prior=prior, noise=noise)
+        if median:
+            values['median'] = self.median(params, space, inputs, outputs, prior=prior, noise=noise)
+        if quantiles:
+            values['quantile_up'] = self.quantiler(params, space, inputs, outputs, q=0.975, prior=prior, noise=noise)
+            values['quantile_down'] = self.quantiler(params, space, inputs, outputs, q=0.025, prior=prior, noise=noise)
+        if quantiles_noise:
+            values['noise_std'] = self.std(params, space, inputs, outputs, prior=prior, noise=True)
+            values['noise_up'] = self.quantiler(params, space, inputs, outputs, q=0.975, prior=prior, noise=True)
+            values['noise_down'] = self.quantiler(params, space, inputs, outputs, q=0.025, prior=prior, noise=True)
+        if samples > 0:
+            values['samples'] = self.sampler(params, space, inputs, outputs, samples=samples, prior=prior, noise=noise)
+        if distribution:
+            values['logpredictive'] = lambda x: self.logpredictive(params, space, inputs, outputs, vector=x,
+                                                                   prior=prior, noise=True)
+        return values
+
+    def logp_chain(self, chain, prior=False):
+        """stochastic.py:515-520: one logp per row of a flat-parameter chain"""
+        out = np.empty(len(chain))
+        for i in range(len(out)):
+            out[i] = self.logp(chain[i], array=True, prior=prior)
+        return out

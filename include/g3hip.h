@@ -1,0 +1,214 @@
+/*
+ * g3hip.h -- C ABI of libg3hip.so: the MI355X (gfx950) implementation of g3py's GP
+ * inference hot path (Gram assembly + Cholesky + triangular solves for the log marginal
+ * likelihood and the posterior mean / variance / covariance / draws).
+ *
+ * The reference (griosd/g3py) is pure Python on Theano; it has no FFI.  Each entry point
+ * below names the reference seam it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a g3py maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - Every function returns an int status: 0 = success; negative -i = argument i is
+ *     invalid; G3_ERR_HIP = a HIP runtime error (text via g3_last_error); a positive
+ *     LAPACK-style `info` (1-based order of the first non-positive pivot) is reported
+ *     through the `info` out-parameter, never as the return value.
+ *   - Nothing throws or aborts across the ABI.
+ *   - All matrices are row-major (NumPy C order) with an explicit leading dimension `ld`
+ *     counted in elements.  "dev" pointers are HIP device pointers (e.g. from g3_malloc
+ *     or torch.Tensor.data_ptr()); "host" pointers are ordinary host memory, borrowed
+ *     for the duration of the call only.
+ *   - Work is enqueued on the context's HIP stream (g3_ctx_set_stream adopts a caller
+ *     stream such as torch's current stream).  Functions with host out-parameters
+ *     synchronise the stream before returning; functions with only device outputs are
+ *     asynchronous.
+ *   - One g3_ctx is single-threaded; distinct contexts may be used concurrently.
+ */
+#ifndef G3HIP_H
+#define G3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G3_OK 0
+#define G3_ERR_HIP (-1000)
+#define G3_ERR_NOMEM (-1001)
+
+typedef struct g3_ctx g3_ctx;
+
+typedef enum { G3_F64 = 0, G3_F32 = 1 } g3_dtype;
+
+/* ---- kernel description -------------------------------------------------------------
+ * A covariance function is passed as a sum of products of stationary "leaf" kernels
+ *      K(x1, x2) = shift + sum_p coef_p * prod_{t in p} leaf_t(x1, x2)
+ * which is what any tree of g3py's KernelSum / KernelProd / KernelScale / KernelShift
+ * (g3py/processes/hypers/kernels.py:192-244) over leaf kernels expands to.
+ * Leaf formulas follow kernels.py:360-487 and metrics.py:30-35,59-61,89-91,100-102; all
+ * hyper-parameters are in NATURAL space (the host applies exp() to `*_log_` values).
+ */
+#define G3_MAXD 32     /* max columns one leaf may use            */
+#define G3_MAXCOLS 60  /* max columns d of the N x d input        */
+#define G3_MAXLEAF 8   /* max distinct leaves in one program      */
+#define G3_MAXPROD 16  /* max product terms                       */
+#define G3_MAXFAC 4    /* max factors in one product term         */
+
+typedef enum {
+  G3_K_SE = 0,    /* var*exp(-sum_k 0.5*rate_k^2*dx_k^2)                 kernels.py:434-436, metrics.py:100-102 */
+  G3_K_OU = 1,    /* var*exp(-sum_k rate_k*|dx_k|)                       kernels.py:429-431, metrics.py:89-91   */
+  G3_K_MAT32 = 2, /* d=ARD_L2; s=sqrt(3d); var*(1+s)exp(-s)              kernels.py:406-412 */
+  G3_K_MAT52 = 3, /* s=sqrt(5d); var*(1+s+5d/3)exp(-s)                   kernels.py:415-421 */
+  G3_K_RQ = 4,    /* var*(1+d/alpha)^(-alpha)                            kernels.py:388-403 */
+  G3_K_COS = 5,   /* var*prod_k cos(2 pi dx_k f_k)                       kernels.py:462-467 */
+  G3_K_SIN = 6,   /* var*exp(+2 sum_k rate_k sin^2(pi dx_k f_k))         kernels.py:470-472 (sign as written) */
+  G3_K_SINC = 7,  /* var*prod_k [dx!=0 ? sin(2pi^2 dx f)/(2pi^2 f dx):1] kernels.py:475-482 */
+  G3_K_SM = 8,    /* var*exp(-2pi^2 sum dx^2 rate^2)*prod cos(2pi dx f)  kernels.py:485-487 */
+  G3_K_NOISE = 9, /* square: var*I ; cross: 0                            kernels.py:360-371 */
+  G3_K_WN = 10    /* square: var*I ; cross: var*#{k: dx_k==0}            kernels.py:374-385, metrics.py:30-35 */
+} g3_kind;
+
+typedef struct {
+  int32_t kind;             /* g3_kind */
+  int32_t ndims;            /* number of input columns used (x[:, dims], hypers/__init__.py:55-83) */
+  int32_t dims[G3_MAXD];    /* the column indices */
+  double var;
+  double alpha;             /* RQ only */
+  double rate[G3_MAXD];     /* per used column */
+  double freq[G3_MAXD];     /* periodic family */
+} g3_leaf;
+
+typedef struct {
+  double coef;
+  int32_t nfac;
+  int32_t fac[G3_MAXFAC];   /* leaf indices */
+  int32_t _pad[3];
+} g3_prod;
+
+typedef struct {
+  int32_t nleaf;
+  int32_t nprod;
+  double shift;
+  g3_leaf leaf[G3_MAXLEAF];
+  g3_prod prod[G3_MAXPROD];
+} g3_kernel_prog;
+
+/* g3_gram flags */
+#define G3_GRAM_LOWER 1u     /* symmetric case: tiles strictly above the diagonal are not written */
+#define G3_GRAM_SCRUB 2u     /* fuse tt_to_num: NaN->0, +-Inf->1e10 (g3py/libs/tensors.py:90-92) */
+#define G3_GRAM_PAD_EYE 4u   /* rows/cols in [n, npad) get the identity (keeps a padded factor exact) */
+
+/* ---- context and device memory ------------------------------------------------------ */
+int g3_ctx_create(int device, g3_ctx** out);
+int g3_ctx_destroy(g3_ctx* ctx);
+int g3_ctx_set_stream(g3_ctx* ctx, void* hip_stream /* hipStream_t, NULL = context's own */);
+int g3_ctx_sync(g3_ctx* ctx);
+const char* g3_last_error(g3_ctx* ctx);
+int g3_version(void);
+
+int g3_malloc(g3_ctx* ctx, size_t bytes, void** dev);
+int g3_free(g3_ctx* ctx, void* dev);
+int g3_memcpy_h2d(g3_ctx* ctx, void* dev, const void* host, size_t bytes);
+int g3_memcpy_d2h(g3_ctx* ctx, void* host, const void* dev, size_t bytes);
+int g3_memcpy_d2d(g3_ctx* ctx, void* dst, const void* src, size_t bytes);
+int g3_memset(g3_ctx* ctx, void* dev, int byte, size_t bytes);
+/* strided 2-D copy dev->dev (rows x cols elements), used to pad / unpad matrices */
+int g3_copy2d(g3_ctx* ctx, void* dst, int64_t ldd, const void* src, int64_t lds,
+              int64_t rows, int64_t cols, g3_dtype dt);
+
+/* ---- Gram assembly --------------------------------------------------------------------
+ * Replaces Kernel.cov(x1, x2=None) (kernels.py:48-49,106-110) + Metric.gram
+ * (metrics.py:11-13): K[i][j] = prog(X1[i], X2[j]); X2 == NULL selects the symmetric
+ * (square) case, which is what turns on the NOISE / WN diagonal.  The n1 x n2 x d broadcast
+ * intermediate of the reference is never formed.  K is (n1pad x n2pad), written for
+ * i < n1pad, j < n2pad; entries outside n1 x n2 are 0 (or the identity with PAD_EYE). */
+int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog_host,
+            const void* X1_dev, int64_t n1, int64_t ldx1,
+            const void* X2_dev, int64_t n2, int64_t ldx2, int d,
+            g3_dtype dt, void* K_dev, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags);
+/* diag(Kernel.cov(X)) without forming the matrix (for the posterior variance,
+ * g3py/processes/elliptical.py:94-97) */
+int g3_gram_diag(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev, int64_t n,
+                 int64_t ldx, int d, g3_dtype dt, void* diag_dev);
+
+/* tt_to_cov's diagonal lift (tensors.py:95-98), given a matrix already scrubbed by
+ * G3_GRAM_SCRUB: m = min diag; if m <= 0 add (1e-6f - m) to the diagonal. */
+int g3_cov_lift(g3_ctx* ctx, void* K_dev, int64_t n, int64_t ld, g3_dtype dt);
+/* tt_to_num over a dense n1 x n2 matrix (tensors.py:90-92) */
+int g3_scrub(g3_ctx* ctx, void* A_dev, int64_t n1, int64_t n2, int64_t ld, g3_dtype dt);
+
+/* ---- dense kernels ---------------------------------------------------------------------
+ * C[m x n] = alpha * A[m x k] * B[n x k]^T + beta * C   (all row-major, k contiguous).
+ * m, n multiples of 64, k a multiple of 16 (f64) / 32 (f32).  lower_only: only tiles on
+ * or below the diagonal are touched and elements above the diagonal are left unchanged. */
+int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
+               const void* B, int64_t ldb, int64_t m, int64_t n, int64_t k,
+               double alpha, double beta, g3_dtype dt, int lower_only);
+
+/* In-place lower Cholesky of the lower triangle of A (n x n, n a multiple of 64; the
+ * strict upper triangle is neither read nor written).  Replaces the dpotrf call at
+ * g3py/libs/tensors.py:198.  Blocked, recursive, right-looking: 64x64 diagonal blocks are
+ * factored (and inverted) by one workgroup, panels are solved by GEMM against the block
+ * inverses, trailing updates are MFMA SYRK/GEMM.  `invd_dev` (n/64 blocks of 64x64, may be
+ * NULL to use the context's own buffer) receives inv(L_kk) for every diagonal block, for
+ * reuse by g3_trsm_rlt.  *info_host = 0 or the 1-based index of the first bad pivot. */
+int g3_potrf(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, void* invd_dev,
+             int* info_host);
+
+/* CholeskyRobust.perform (tensors.py:197-222): non-destructive, never fails.
+ * L (lower, strict upper zeroed) <- chol(K); on info != 0 runs the reference's jitter
+ * schedule (dK = mean(diag)*1e-6, lift non-positive diagonals, up to `maxtries` (20)
+ * retries with dK *= 10) and finally the 1e-10*I fallback.  K and L are n x n with any n
+ * (padding is internal).  tries_host / fallback_host / jitter_host report what happened. */
+int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void* L_dev, int64_t ldl,
+                    int64_t n, g3_dtype dt, int maxtries, int* tries_host, int* fallback_host,
+                    double* jitter_host);
+
+/* Solve X * L^T = B in place (B is m x n: each ROW of B is one right-hand side, i.e.
+ * B^T <- solve_lower_triangular(L, B^T); tensors.py:265-270, gaussian.py:212).
+ * m, n multiples of 64.  invd_dev: block inverses from g3_potrf, or NULL to compute them. */
+int g3_trsm_rlt(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, void* B_dev, int64_t m,
+                int64_t ldb, g3_dtype dt, const void* invd_dev);
+
+/* ---- reductions (device in, host out; synchronising) ----------------------------------- */
+/* out[0] = sum_i log L[i][i], out[1] = sum_i a[i]^2, out[2] = #non-finite in a,
+ * out[3] = #non-finite or <= 0 on diag(L)   -- the pieces of logp_cho, gaussian.py:208-241 */
+int g3_logp_terms(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ld, const void* a_dev,
+                  g3_dtype dt, double out_host[4]);
+/* out = [min, mean, max] of diag(A) (jitter schedule inputs, tensors.py:203-206) */
+int g3_diag_stats(g3_ctx* ctx, const void* A_dev, int64_t n, int64_t ld, g3_dtype dt,
+                  double out_host[3]);
+int g3_diag_add(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, double value);
+/* For V (m x n, rows are L^-1 k_*): dot[i] = sum_j V[i][j]*a[j]; ss[i] = sum_j V[i][j]^2
+ * -- posterior mean and variance pieces (elliptical.py:81-97) in one pass over V. */
+int g3_rows_dot_ss(g3_ctx* ctx, const void* V_dev, int64_t m, int64_t n, int64_t ld,
+                   const void* a_dev, g3_dtype dt, void* dot_dev, void* ss_dev);
+
+/* ---- fused hot path (device-resident inputs) -------------------------------------------
+ * One evaluation of the GP log marginal likelihood pieces for
+ *     K = tt_to_cov(prog(X, X))   (prog already contains the Noise term, elliptical.py:26-31,70-71)
+ *     L = cholesky_robust(K); a = L^-1 delta          (gaussian.py:208-224)
+ * X_dev: N x d (row stride ldx), delta_dev: N (= T^-1(y) - m(X), computed by the host layer).
+ * K_dev: workspace / output, Npad x Npad with Npad = roundup(N, 64), ld = ldk; on return its
+ * lower triangle holds L.  a_dev (Npad) receives L^-1 delta.
+ * out_host[0] = sum log L_ii, [1] = a^T a, [2] = #non-finite in a, [3] = jitter tries,
+ * [4] = 1 if the 1e-10*I fallback was taken, [5] = potrf info of the first attempt. */
+int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev, int64_t N,
+                 int64_t ldx, int d, const void* delta_dev, g3_dtype dt, void* K_dev, int64_t ldk,
+                 void* a_dev, double out_host[6]);
+
+/* Posterior location / variance pieces at M test points given the factor from g3_gp_factor:
+ *     V = K(Xs, X) L^-T  (Mpad x Npad, in V_dev, ldv);  mu[i] = V[i,:] . a;  ss[i] = |V[i,:]|^2
+ * prog_cross: the kernel used for the cross covariance (with or without the Noise term,
+ * elliptical.py:78-79 -- Noise contributes 0 to a cross block either way). */
+int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_dev, int64_t M,
+                int64_t ldxs, const void* X_dev, int64_t N, int64_t ldx, int d, const void* L_dev,
+                int64_t ldl, const void* a_dev, g3_dtype dt, void* V_dev, int64_t ldv,
+                void* mu_dev, void* ss_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G3HIP_H */
