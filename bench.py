@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GP inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json: "GP logp+predict end-to-end sec and Cholesky TFLOP/s at N=32768
+fp64"): SE-kernel GaussianProcess, fp64, N=32768 observations in d=4, M=1024 prediction
+points, synthetic inputs (seed 1004) already resident in HBM.  One
+"step" = one full pass: Gram assembly -> blocked Cholesky -> L^-1 delta (log marginal
+likelihood) -> cross-Gram -> M-right-hand-side triangular solve -> posterior mean and variance.
+
+Prints ONE JSON line (rank 0).  `value` = algorithmic flops of the step / wall time of the
+step (whole job), `e2e_sec` and `cholesky_tflops` are the two halves of the baseline metric.
+`roofline` is measured live with HIP events around every launch of the dominant kernel (the
+MFMA GEMM that carries the panel updates of the blocked Cholesky); `cpu_baseline` times the
+CPU oracle (NumPy/SciPy restatement, same LAPACK entry points as the reference) on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, AMD public spec; see DESIGN.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synth(N, d, M, seed):
+    """SURVEY.md section 8(d)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Lbox = N ** (1.0 / d)
+    X = rng.uniform(0, Lbox, (N, d))
+    Xs = rng.uniform(0, Lbox, (M, d))
+    y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.standard_normal(N)
+    return X, y, Xs
+
+
+def step_flops(N, M):
+    """algorithmic flops of one step: potrf N^3/3, trsv N^2,
+    trsm N^2 M, mean+variance 2 N M"""
+    return N ** 3 / 3.0 + float(N) ** 2 + float(N) ** 2 * M + 2.0 * N * M
+
+
+def cpu_baseline(N, d, M, seed, n_cpu):
+    from oracle import g3_oracle as orc
+    X, y, Xs = synth(N, d, M, seed)
+    X, y = X[:n_cpu], y[:n_cpu]
+    t0 = time.perf_counter()
+    lp, mean, var, tm = orc.cpu_hot_path(X, y, Xs)
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return dict(value=step_flops(n_cpu, M) / dt / 1e12, unit='TFLOP/s', cores=int(cores), kind='port',
+                sample='one pass of the same workload cut to N=%d (d=%d, M=%d, same generator and seed), '
+                       'oracle.cpu_hot_path: NumPy Gram + scipy dpotrf + solve_triangular' % (n_cpu, d, M),
+                seconds=dt, potrf_gflops=(n_cpu ** 3 / 3.0) / tm['potrf'] / 1e9, phases_sec=tm), lp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=32768)
+    ap.add_argument('--d', type=int, default=4)
+    ap.add_argument('--m', type=int, default=1024)
+    ap.add_argument('--cpu-n', type=int, default=8192, help='N of the bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-prof', action='store_true', help='do not record HIP events in the timed region')
+    ap.add_argument('--nb', type=int, default=2048, help='block-column width of the multi-GPU distribution')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+
+    import g3py_amd as g3
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+
+    N, d, M, seed = args.n, args.d, args.m, 1004
+    X, y, Xs = synth(N, d, M, seed)
+    delta = y.copy()                      # Zero mean, identity mapping: delta = y
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    spec_n = ('sum', spec_f, ('NOISE', 0.1))
+    dev = g3.Device(local_rank)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)   # HIP events below see this stream
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, _lib.G3_RHS_PAD)
+    tdev = torch.device('cuda', local_rank)
+
+    def tens(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(tdev)
+
+    def wrap(t, rows, cols):
+        return dev.wrap(t.data_ptr(), rows, cols, t.stride(0) if t.dim() == 2 else cols, np.float64, keep=t)
+
+    Xt, Xst, dt_ = tens(X), tens(Xs), tens(delta[None, :])
+    Xd, Xsd, dd = wrap(Xt, N, d), wrap(Xst, M, d), wrap(dt_, 1, N)
+
+    if world == 1:
+        Kt = torch.empty((Np, Np), dtype=torch.float64, device=tdev)
+        at = torch.empty((1, Np), dtype=torch.float64, device=tdev)
+        Vt = torch.empty((Mp, Np), dtype=torch.float64, device=tdev)
+        mut = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
+        sst = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
+        Kd, ad, Vd, mud, ssd = wrap(Kt, Np, Np), wrap(at, 1, Np), wrap(Vt, Mp, Np), wrap(mut, 1, Mp), wrap(sst, 1, Mp)
+        prog_n, prog_f = compile_spec(spec_n, d), compile_spec(spec_f, d)
+        result = {}
+
+        def step():
+            st = dev.gp_factor(prog_n, Xd, N, d, dd, Kd, ad)
+            dev.gp_cross(prog_f, Xsd, M, Xd, N, d, Kd, ad, Vd, mud, ssd)
+            dev.sync()
+            result['logp'] = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
+            result['stats'] = st
+        parallelism = '1gpu'
+    else:
+        from g3py_amd.distributed import DistributedGP
+        dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, torch_device=tdev)
+        result = {}
+
+        def step():
+            result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
+        parallelism = '1d-block-cyclic x%d (nb=%d), RCCL panel broadcast' % (world, args.nb)
+
+    for _ in range(args.warmup):
+        step()
+    dev.prof_enable(not args.no_prof)
+    dev.prof_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dev.prof_collect()
+    dev.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        sec = elapsed / args.steps
+        flops = step_flops(N, M)
+        out = {
+            'metric': 'GP logp+predict end-to-end (Gram+Cholesky+solves), N=%d fp64: algorithmic TFLOP/s' % N,
+            'value': flops / sec / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'SE-kernel GaussianProcess fp64, N=%d d=%d, M=%d test points: Gram + blocked '
+                                   'Cholesky + L^-1 y (logp) + cross-Gram + %d-rhs trsm + posterior mean/variance'
+                                   % (N, d, M, M), 'N': N, 'd': d, 'M': M, 'parallelism': parallelism},
+            'e2e_sec': sec, 'logp': float(result['logp']),
+        }
+        ph = {k: v['ms'] / args.steps for k, v in prof.items() if v['count']}
+        out['phases_ms'] = ph
+        if prof['potrf']['count']:
+            out['cholesky_tflops'] = prof['potrf']['work'] / (prof['potrf']['ms'] * 1e-3) / 1e12 * (1.0 if world == 1 else 1.0)
+        g = prof['gemm_256x128']
+        if g['count']:
+            ach = g['work'] / (g['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                               'kernel': 'gemm_nt_kernel<double,256,128,64,64>', 'launches_per_step': g['count'] / args.steps,
+                               'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count']}
+        if world == 1 and args.cpu_n > 0:
+            cb, lp_cpu = cpu_baseline(N, d, M, seed, min(args.cpu_n, N))
+            out['cpu_baseline'] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

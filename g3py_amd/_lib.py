@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libg3hip.so')
 G3_MAXD, G3_MAXCOLS, G3_MAXLEAF, G3_MAXPROD, G3_MAXFAC = 32, 60, 8, 16, 4
 G3_F64, G3_F32 = 0, 1
 G3_GRAM_LOWER, G3_GRAM_SCRUB, G3_GRAM_PAD_EYE = 1, 2, 4
-G3_LEAF = 64
+G3_PAD = 256       # matrices are padded to a multiple of the panel block (G3_LB in the library)
+G3_RHS_PAD = 128   # right-hand-side blocks are padded to a multiple of the 128-row tile
 KINDS = dict(SE=0, OU=1, MAT32=2, MAT52=3, RQ=4, COS=5, SIN=6, SINC=7, SM=8, NOISE=9, WN=10)
 
 
@@ -70,8 +71,13 @@ _SIGS = {
                       C.POINTER(C.c_double)], C.c_int),
     'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P,
                      C.c_int, _P, _I64, _P, _P], C.c_int),
+    'g3_prof_enable': ([_P, C.c_int], C.c_int),
+    'g3_prof_reset': ([_P], C.c_int),
+    'g3_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
+PROF_TAGS = ('gemm_256x128', 'gram', 'potrf', 'trsv', 'cross_gram', 'trsm', 'reduce', 'gemm_128x128',
+             'gemm_64x64', 'leaf64')
 
 _lib = None
 
@@ -106,5 +112,5 @@ def dtype_code(dtype):
     raise G3Error('unsupported dtype %s' % dtype)
 
 
-def roundup(n, m=G3_LEAF):
+def roundup(n, m=G3_PAD):
     return (int(n) + m - 1) // m * m

@@ -17,6 +17,11 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   ctx->device = device;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority
+    e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, 2 * sizeof(g3_kernel_prog));
@@ -45,6 +50,17 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   if (ctx->h_prog) (void)hipHostFree(ctx->h_prog);
   if (ctx->invd) (void)hipFree(ctx->invd);
   if (ctx->work) (void)hipFree(ctx->work);
+  if (ctx->wscr) (void)hipFree(ctx->wscr);
+  if (ctx->prof_ev) {
+    for (int i = 0; i < ctx->prof_cap; ++i) if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
+    free(ctx->prof_ev);
+  }
+  if (ctx->prof_rec) free(ctx->prof_rec);
+  if (ctx->la_ev) {
+    for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
+    free(ctx->la_ev);
+  }
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return G3_OK;
@@ -55,6 +71,56 @@ extern "C" int g3_ctx_set_stream(g3_ctx* ctx, void* s) {
   G3_HIP(hipStreamSynchronize(ctx->stream));
   ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
   ctx->adopted = (s != nullptr);
+  return G3_OK;
+}
+
+// ----------------------------------------------------------------------------- profiling
+extern "C" int g3_prof_enable(g3_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  if (on && !ctx->prof_ev) {
+    ctx->prof_cap = 16384;
+    ctx->prof_ev = (hipEvent_t*)calloc(ctx->prof_cap, sizeof(hipEvent_t));
+    ctx->prof_rec = (decltype(ctx->prof_rec))calloc(ctx->prof_cap / 2, sizeof(*ctx->prof_rec));
+    if (!ctx->prof_ev || !ctx->prof_rec) return G3_ERR_NOMEM;
+    for (int i = 0; i < ctx->prof_cap; ++i) G3_HIP(hipEventCreate(&ctx->prof_ev[i]));
+  }
+  ctx->prof_on = on != 0;
+  return G3_OK;
+}
+extern "C" int g3_prof_reset(g3_ctx* ctx) {
+  if (!ctx) return -1;
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->prof_n = 0;
+  ctx->prof_nrec = 0;
+  return G3_OK;
+}
+int g3i_prof_begin(g3_ctx* ctx, int tag, double work) {
+  if (!ctx->prof_on || ctx->prof_n + 2 > ctx->prof_cap) return -1;
+  const int r = ctx->prof_nrec++;
+  ctx->prof_rec[r].e0 = ctx->prof_n++;
+  ctx->prof_rec[r].e1 = ctx->prof_n++;
+  ctx->prof_rec[r].tag = tag;
+  ctx->prof_rec[r].work = work;
+  (void)hipEventRecord(ctx->prof_ev[ctx->prof_rec[r].e0], ctx->stream);
+  return r;
+}
+void g3i_prof_end(g3_ctx* ctx, int rec) {
+  if (rec < 0) return;
+  (void)hipEventRecord(ctx->prof_ev[ctx->prof_rec[rec].e1], ctx->stream);
+}
+extern "C" int g3_prof_collect(g3_ctx* ctx, double* out) {
+  if (!ctx) return -1;
+  if (!out) return -2;
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3 * G3_PROF_NTAGS; ++i) out[i] = 0.0;
+  for (int r = 0; r < ctx->prof_nrec; ++r) {
+    float ms = 0.f;
+    G3_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[ctx->prof_rec[r].e0], ctx->prof_ev[ctx->prof_rec[r].e1]));
+    const int t = ctx->prof_rec[r].tag;
+    out[3 * t] += 1.0;
+    out[3 * t + 1] += (double)ms;
+    out[3 * t + 2] += ctx->prof_rec[r].work;
+  }
   return G3_OK;
 }
 
@@ -394,7 +460,7 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   if (N <= 0) return -4;
   if (!delta) return -7;
   if (!K) return -9;
-  const int64_t Np = g3_roundup(N, G3_LEAF);
+  const int64_t Np = g3_roundup(N, G3_LB);
   if (ldk < Np || ldk % (16 / (int64_t)g3_esize(dt))) return -10;
   if (!a) return -11;
   if (!out) return -12;
@@ -402,16 +468,28 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   if (rc) return rc;
   const unsigned gflags = G3_GRAM_LOWER | G3_GRAM_SCRUB | G3_GRAM_PAD_EYE;
   // K = tt_to_cov(cov(X))  (elliptical.py:70-71), lower triangle only
+  const double es_d = (double)g3_esize(dt);
   auto build = [&]() -> int {
+    // algorithmic bytes of the lower-triangle Gram: N d s read + N(N+1)/2 s written
+    const int pr = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * d * es_d + 0.5 * (double)N * (N + 1) * es_d);
     int r = g3_gram(ctx, prog, X, N, ldx, nullptr, 0, 0, d, dt, K, ldk, Np, Np, gflags);
     if (r) return r;
-    return g3_cov_lift(ctx, K, N, ldk, dt);
+    r = g3_cov_lift(ctx, K, N, ldk, dt);
+    g3i_prof_end(ctx, pr);
+    return r;
   };
   rc = build();
   if (rc) return rc;
   int info = 0;
-  rc = g3_potrf(ctx, K, Np, ldk, dt, ctx->invd, &info);
-  if (rc) return rc;
+  {
+    const int pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0);
+    rc = g3i_potrf(ctx, K, Np, ldk, dt, ctx->invd);
+    g3i_prof_end(ctx, pr);
+    if (rc) return rc;
+    G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    G3_HIP(hipStreamSynchronize(ctx->stream));
+    info = *ctx->h_info;
+  }
   double tries = 0, fallback = 0;
   const int info0 = info;
   if (info != 0) {
@@ -459,21 +537,30 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   rc = g3i_reset_info(ctx);
   if (rc) return rc;
   // a = L^-1 delta as a 64-row right-hand-side block (row 0 carries delta)
-  rc = g3i_ensure_work(ctx, (size_t)G3_LEAF * Np * g3_esize(dt));
+  const int64_t RB = 128;   // rows of the right-hand-side block that carries delta
+  rc = g3i_ensure_work(ctx, (size_t)RB * Np * g3_esize(dt));
   if (rc) return rc;
   const unsigned nb = (unsigned)((Np + 255) / 256);
   if (dt == G3_F64)
     hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)ctx->work,
-                       (const double*)delta, N, Np, (int64_t)G3_LEAF);
+                       (const double*)delta, N, Np, RB);
   else
     hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)ctx->work,
-                       (const float*)delta, N, Np, (int64_t)G3_LEAF);
+                       (const float*)delta, N, Np, RB);
   G3_LAUNCH_CHECK();
-  rc = g3i_trsm_rlt(ctx, K, Np, ldk, ctx->work, G3_LEAF, Np, dt, ctx->invd);
-  if (rc) return rc;
+  {
+    const int pr = g3i_prof_begin(ctx, G3_TAG_TRSV, (double)N * N);
+    rc = g3i_trsm_rlt(ctx, K, Np, ldk, ctx->work, RB, Np, dt, ctx->invd);
+    g3i_prof_end(ctx, pr);
+    if (rc) return rc;
+  }
   G3_HIP(hipMemcpyAsync(a, ctx->work, (size_t)Np * g3_esize(dt), hipMemcpyDeviceToDevice, ctx->stream));
-  rc = logp_terms_launch(ctx, K, N, ldk, a, dt);
-  if (rc) return rc;
+  {
+    const int pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 0.0);
+    rc = logp_terms_launch(ctx, K, N, ldk, a, dt);
+    g3i_prof_end(ctx, pr);
+    if (rc) return rc;
+  }
   double st4[4];
   rc = fetch_stats(ctx, st4, 4);
   if (rc) return rc;
@@ -497,19 +584,28 @@ extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* 
   if (!X) return -6;
   if (N <= 0) return -7;
   if (!L) return -10;
-  const int64_t Np = g3_roundup(N, G3_LEAF), Mp = g3_roundup(M, G3_LEAF);
+  const int64_t Np = g3_roundup(N, G3_LB), Mp = g3_roundup(M, 128);
   const int64_t al = 16 / (int64_t)g3_esize(dt);
   if (ldl < Np || ldl % al) return -11;
   if (!V) return -14;
   if (ldv < Np || ldv % al) return -15;
-  if (ctx->invd_bytes < (size_t)(Np / G3_LEAF) * G3_LEAF * G3_LEAF * g3_esize(dt)) return -10;
+  if (ctx->invd_bytes < (size_t)(Np / G3_LB) * G3_LB * G3_LB * g3_esize(dt)) return -10;
   // V = tt_to_num(cov(Xs, X))  (elliptical.py:78-79), then V <- V L^-T
+  const double es_d = (double)g3_esize(dt);
+  int pr = g3i_prof_begin(ctx, G3_TAG_CROSS_GRAM, (double)(N + M) * d * es_d + (double)N * M * es_d);
   int rc = g3_gram(ctx, prog, Xs, M, ldxs, X, N, ldx, d, dt, V, ldv, Mp, Np, G3_GRAM_SCRUB);
+  g3i_prof_end(ctx, pr);
   if (rc) return rc;
   rc = g3i_reset_info(ctx);
   if (rc) return rc;
+  pr = g3i_prof_begin(ctx, G3_TAG_TRSM, (double)N * N * M);
   rc = g3i_trsm_rlt(ctx, L, Np, ldl, V, Mp, ldv, dt, ctx->invd);
+  g3i_prof_end(ctx, pr);
   if (rc) return rc;
-  if (mu || ss) rc = rows_dot_ss_launch(ctx, V, M, N, ldv, a, dt, mu, ss);
+  if (mu || ss) {
+    pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 2.0 * N * M);
+    rc = rows_dot_ss_launch(ctx, V, M, N, ldv, a, dt, mu, ss);
+    g3i_prof_end(ctx, pr);
+  }
   return rc;
 }

@@ -176,8 +176,12 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
     attr_set = true;
   }
   dim3 grid((unsigned)(n / BN), (unsigned)(m / BM));
+  // algorithmic flops: 2 m n k, or m n k when only the lower triangle is wanted
+  const int pr = g3i_prof_begin(ctx, BM == 256 ? G3_TAG_GEMM_BIG : (BM == 128 ? G3_TAG_GEMM_MID : G3_TAG_GEMM_SMALL),
+                                (lower_only ? 1.0 : 2.0) * (double)m * (double)n * (double)k);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, ctx->stream, (T*)C, ldc, (const T*)A, lda,
                      (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info);
+  g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -185,24 +189,39 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
 template <typename T>
 static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                     int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
-                    int lower_only) {
+                    int lower_only, int wide) {
   // tile choice: big tiles when they still fill the chip, small tiles for the narrow
   // panel / leaf operations on the critical path of the factorisation
   const int64_t blocks128 = (m / 128) * (n / 128) / (lower_only ? 2 : 1);
   if (m % 256 == 0 && n % 128 == 0 && (m / 256) * (n / 128) / (lower_only ? 2 : 1) >= 512)
     return launch_cfg<T, 256, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  if (m % 128 == 0 && n % 128 == 0 && blocks128 >= 96)
+  if (n % 128 == 0 && m % 32 == 0 && blocks128 < 128 && (wide || (m / 64) * (n / 64) < 128))
+    // few tiles: thin 32 x 128 tiles spread a small problem over more CUs (one f64 tile of
+    // 128 x 128 keeps a single CU busy for ~2 us per 16-deep K step)
+    return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (m % 128 == 0 && n % 128 == 0 && (blocks128 >= 96 || wide))
     return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (wide) {  // the caller aliases C with A and needs one tile to span 128 output columns
+    snprintf(ctx->err, sizeof(ctx->err), "in-place panel GEMM needs m, n multiples of 128 (m=%lld n=%lld)",
+             (long long)m, (long long)n);
+    return G3_ERR_HIP;
+  }
   return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+}
+
+int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                   int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                   g3_dtype dt, int lower_only, int wide) {
+  if (m == 0 || n == 0) return G3_OK;
+  if (dt == G3_F64)
+    return launch_t<double>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only, wide);
+  return launch_t<float>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only, wide);
 }
 
 int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                 int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                 g3_dtype dt, int lower_only) {
-  if (m == 0 || n == 0) return G3_OK;
-  if (dt == G3_F64)
-    return launch_t<double>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  return launch_t<float>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  return g3i_gemm_nt_ex(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, dt, lower_only, 0);
 }
 
 extern "C" int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,

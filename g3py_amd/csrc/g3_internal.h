@@ -8,11 +8,16 @@
 #include "g3hip.h"
 
 #define G3_LEAF 64  // diagonal block factored (and inverted) by one workgroup
+#define G3_LB 256   // diagonal block whose explicit inverse drives the panel solves; matrices are padded to it
 
 struct g3_ctx {
   int device;
   hipStream_t stream;      // stream work is enqueued on
   hipStream_t own_stream;  // created by the context
+  hipStream_t side_stream; // low-priority stream carrying the bulk trailing updates (look-ahead)
+  hipEvent_t* la_ev;       // look-ahead events (2 per panel)
+  int la_nev;
+  int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
   bool adopted;            // stream belongs to the caller
   // small device scratch
   int* d_info;             // potrf info flag
@@ -25,11 +30,25 @@ struct g3_ctx {
   // block inverses of the last factorisation
   void* invd;
   size_t invd_bytes;
+  void* wscr;              // scratch of the block-inverse merges: Wt (LB x LB) + Tt (128 x 128)
   // padded workspace for g3_potrf_robust / g3_trsm on ragged sizes
   void* work;
   size_t work_bytes;
+  // optional profiling: HIP-event pairs around tagged regions (g3_prof_*)
+  bool prof_on;
+  hipEvent_t* prof_ev;
+  int prof_cap, prof_n;          // events allocated / used
+  struct { int e0, e1, tag; double work; }* prof_rec;
+  int prof_nrec;
   char err[512];
 };
+
+// profiling tags
+enum { G3_TAG_GEMM_BIG = 0, G3_TAG_GRAM = 1, G3_TAG_POTRF = 2, G3_TAG_TRSV = 3, G3_TAG_CROSS_GRAM = 4,
+       G3_TAG_TRSM = 5, G3_TAG_REDUCE = 6, G3_TAG_GEMM_MID = 7, G3_TAG_GEMM_SMALL = 8, G3_TAG_LEAF = 9,
+       G3_NTAGS = 10 };
+int g3i_prof_begin(g3_ctx* ctx, int tag, double work);   // returns record index or -1
+void g3i_prof_end(g3_ctx* ctx, int rec);
 
 #define G3_HIP(call)                                                                          \
   do {                                                                                        \
@@ -58,6 +77,10 @@ static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m 
 int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                 int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                 g3_dtype dt, int lower_only);
+// wide = 1: force a tile that spans 128 output columns (C may then alias A when n == 128)
+int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                   int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                   g3_dtype dt, int lower_only, int wide);
 int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd);
 int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,
                  int64_t ldb, g3_dtype dt, const void* invd);

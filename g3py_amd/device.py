@@ -77,6 +77,19 @@ class Device:
     def sync(self):
         _check(self, self.lib.g3_ctx_sync(self.ctx), 'g3_ctx_sync')
 
+    # ---- profiling (HIP events on the context's stream)
+    def prof_enable(self, on=True):
+        _check(self, self.lib.g3_prof_enable(self.ctx, int(on)), 'g3_prof_enable')
+
+    def prof_reset(self):
+        _check(self, self.lib.g3_prof_reset(self.ctx), 'g3_prof_reset')
+
+    def prof_collect(self):
+        out = (C.c_double * (3 * len(_lib.PROF_TAGS)))()
+        _check(self, self.lib.g3_prof_collect(self.ctx, out), 'g3_prof_collect')
+        return {t: dict(count=int(out[3 * i]), ms=out[3 * i + 1], work=out[3 * i + 2])
+                for i, t in enumerate(_lib.PROF_TAGS)}
+
     # ---- memory
     def alloc(self, rows, cols, dtype, ld=None, zero=False):
         ld = int(cols if ld is None else ld)

@@ -127,7 +127,7 @@ def solve_lower_triangular(L, b, device=None):
     B = (b[None, :] if vec else b.T)
     dev = device or Device.default()
     n, m = L.shape[0], B.shape[0]
-    npad, mpad = roundup(n), roundup(m)
+    npad, mpad = roundup(n), roundup(m, 128)
     Lp = np.eye(npad, dtype=L.dtype)
     Lp[:n, :n] = np.tril(L)
     Ld = dev.upload(Lp)

@@ -126,7 +126,7 @@ class EllipticalProcess(StochasticProcess):
         dev = self.device
         S = self._x(space)
         M = S.shape[0]
-        Mp = _lib.roundup(M)
+        Mp = _lib.roundup(M, _lib.G3_RHS_PAD)
         Sd = dev.upload(S)
         V = dev.alloc(Mp, c['Np'], self.dtype)
         mu = dev.alloc(1, Mp, self.dtype)
@@ -141,7 +141,7 @@ class EllipticalProcess(StochasticProcess):
         dev = self.device
         S = self._x(space)
         M, d = S.shape
-        Mp = _lib.roundup(M) if pad else M
+        Mp = _lib.roundup(M, _lib.G3_RHS_PAD) if pad else M
         Sd = dev.upload(S)
         K = dev.alloc(Mp, Mp, self.dtype)
         kern = self.f_kernel_noise if noise else self.f_kernel

@@ -85,7 +85,7 @@ class GaussianProcess(EllipticalProcess):
         loc = self.location(params, space, inputs, outputs, prior=prior, noise=noise)
         L = self.cholesky(params, space, inputs, outputs, prior=prior, noise=noise)
         dev = self.device
-        Mp, Sp = _lib.roundup(M), _lib.roundup(S)
+        Mp, Sp = _lib.roundup(M, _lib.G3_RHS_PAD), _lib.roundup(S, 64)
         Ld = dev.upload(L, pad_rows=Mp, pad_cols=Mp)
         Zt = dev.upload(np.ascontiguousarray(rand.T), pad_rows=Sp, pad_cols=Mp)
         out = dev.alloc(Sp, Mp, self.dtype)

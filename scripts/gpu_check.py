@@ -27,7 +27,7 @@ for dt, tol in ((np.float64, 1e-13), (np.float32, 1e-4)):
                           (2048, 1536, 128, False), (8192, 8192, 64, True)]:
         assert gemm_case(m, n, k, dt, lo) < tol
 
-for n in (64, 128, 192, 512, 1024, 4096):
+for n in (256, 512, 768, 1024, 4096, 6144, 8192):
     B = rng.standard_normal((n, n)); K = B @ B.T / n + np.eye(n)
     Kd = dev.upload(K)
     t0 = time.time(); info = dev.potrf(Kd, n); t1 = time.time()
@@ -35,14 +35,14 @@ for n in (64, 128, 192, 512, 1024, 4096):
     Lr = np.linalg.cholesky(K)
     print('potrf', n, 'info', info, 'err %.2e' % (np.abs(L - Lr).max()), 'time %.1f ms' % ((t1 - t0) * 1e3))
     assert info == 0 and np.abs(L - Lr).max() < 1e-11
-    Bm = rng.standard_normal((64, n))
+    Bm = rng.standard_normal((128, n))
     Ld = dev.upload(Lr); Bd = dev.upload(Bm)
-    dev.trsm_rlt(Ld, n, Bd, 64)
+    dev.trsm_rlt(Ld, n, Bd, 128)
     Xs = dev.download(Bd)
     print('trsm', n, 'err %.2e' % np.abs(Xs @ Lr.T - Bm).max())
     assert np.abs(Xs @ Lr.T - Bm).max() < 1e-10
 
-K = -np.eye(128); Kd = dev.upload(K); print('potrf nonPD info', dev.potrf(Kd, 128))
+K = -np.eye(256); Kd = dev.upload(K); print('potrf nonPD info', dev.potrf(Kd, 256))
 import __graft_entry__ as ge
 ge.smoke()
 print('ALL OK')
