@@ -94,6 +94,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
 
+    tdev0 = torch.device('cuda', local_rank)
     import g3py_amd as g3
     from g3py_amd import _lib
     from g3py_amd.device import compile_spec
@@ -104,6 +105,10 @@ def main():
     spec_f = ('SE', 1.0, np.ones(d), None)
     spec_n = ('sum', spec_f, ('NOISE', 0.1))
     dev = g3.Device(local_rank)
+    # the critical-path stream gets high priority; the library's side stream (bulk updates) is low
+    hp = torch.cuda.Stream(device=tdev0, priority=-1) if os.environ.get('G3_BENCH_HIPRIO', '1') == '1' else None
+    if hp is not None:
+        torch.cuda.set_stream(hp)
     dev.set_stream(torch.cuda.current_stream().cuda_stream)   # HIP events below see this stream
     Np, Mp = _lib.roundup(N), _lib.roundup(M, _lib.G3_RHS_PAD)
     tdev = torch.device('cuda', local_rank)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libg3hip.so')
 G3_MAXD, G3_MAXCOLS, G3_MAXLEAF, G3_MAXPROD, G3_MAXFAC = 32, 60, 8, 16, 4
 G3_F64, G3_F32 = 0, 1
 G3_GRAM_LOWER, G3_GRAM_SCRUB, G3_GRAM_PAD_EYE = 1, 2, 4
-G3_PAD = 256       # matrices are padded to a multiple of the panel block (G3_LB in the library)
+G3_PAD = 128       # matrices are padded to a multiple of the panel block (G3_LB in the library)
 G3_RHS_PAD = 128   # right-hand-side blocks are padded to a multiple of the 128-row tile
 KINDS = dict(SE=0, OU=1, MAT32=2, MAT52=3, RQ=4, COS=5, SIN=6, SINC=7, SM=8, NOISE=9, WN=10)
 

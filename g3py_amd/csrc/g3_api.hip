@@ -1,6 +1,7 @@
 // Context, device memory, element-wise / reduction kernels and the fused hot-path entry
 // points of libg3hip (see include/g3hip.h for the contract of each function).
 #include "g3_internal.h"
+#include <stdlib.h>
 
 // ----------------------------------------------------------------------------- context
 extern "C" int g3_version(void) { return 100; }
@@ -20,7 +21,22 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   if (e == hipSuccess) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority
-    e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
+    // G3_BMASK (experiment): "stride:S" clears every S-th CU bit, "first:K" clears the first K
+    // bits of the side stream's CU mask, reserving those CUs for the critical-path stream
+    const char* bm = getenv("G3_BMASK");
+    if (bm && *bm) {
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
+      int v = atoi(strchr(bm, ':') ? strchr(bm, ':') + 1 : "0");
+      if (!strncmp(bm, "stride", 6) && v > 0) {
+        for (int b = 0; b < 256; b += v) mask[b >> 5] &= ~(1u << (b & 31));
+      } else if (!strncmp(bm, "first", 5)) {
+        for (int b = 0; b < v && b < 256; ++b) mask[b >> 5] &= ~(1u << (b & 31));
+      }
+      e = hipExtStreamCreateWithCUMask(&ctx->side_stream, 8, mask);
+    } else {
+      e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
+    }
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));

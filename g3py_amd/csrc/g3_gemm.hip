@@ -17,39 +17,18 @@
 //   * Global -> register -> LDS staging, double-buffered, one barrier per K tile; the
 //     f64 MFMA is 64 cycles per instruction, so the loop is matrix-pipe bound.
 #include "g3_internal.h"
+#include <stdlib.h>
 
-template <typename T>
-struct MfmaT;
-template <>
-struct MfmaT<double> {
-  typedef double acc_t __attribute__((ext_vector_type(4)));
-  typedef double chunk_t __attribute__((ext_vector_type(2)));
-  static constexpr int EPC = 2;  // elements per 16-byte chunk
-  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <>
-struct MfmaT<float> {
-  typedef float acc_t __attribute__((ext_vector_type(4)));
-  typedef float chunk_t __attribute__((ext_vector_type(4)));
-  static constexpr int EPC = 4;
-  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
-  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
-};
+#include "g3_mfma.h"
 
 constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
+constexpr int GROUP_M = 4; // row-blocks per raster group
 constexpr int NCH = 8;     // 16-byte chunks per row
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
 gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
-               int K, T alpha, T beta, int lower_only, const int* __restrict__ info) {
+               int K, T alpha, T beta, int lower_only, const int* __restrict__ info, int tiles_m, int tiles_n) {
   using M = MfmaT<T>;
   using chunk_t = typename M::chunk_t;
   using acc_t = typename M::acc_t;
@@ -61,7 +40,55 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   constexpr int CA = BM * NCH / NT, CB = BN * NCH / NT;
   static_assert(BM * NCH % NT == 0 && BN * NCH % NT == 0, "tile/threads mismatch");
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // ---- tile assignment: XCD-aware, grouped raster over the ACTIVE tiles only.
+  // Workgroups are dealt round-robin over the 8 XCDs, so ids {x, x+8, ...} share an L2;
+  // remap so that each XCD walks a contiguous range of "virtual" ids, and order virtual
+  // ids in groups of GROUP_M row-blocks, column-major inside a group: the ~32 tiles an XCD
+  // works on at any time then form a GROUP_M x 8 patch that shares 4 A panels and 8 B
+  // panels through its L2 instead of streaming 32 distinct B panels from HBM.
+  int bm, bn;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    // groups of GROUP_M row-blocks; group g has nc(g) active column-blocks
+    int g = 0, base = 0;
+    if (!lower_only) {
+      const int per = GROUP_M * tiles_n;
+      g = v / per;
+      base = g * per;
+    } else {
+      // nc(g) = min(tiles_n, RATIO * GROUP_M * (g + 1)), RATIO = BM / BN column tiles per row tile;
+      // quadratic prefix until saturation at g_sat, linear after
+      constexpr int RATIO = (BM >= BN) ? BM / BN : 1;
+      const int step = RATIO * GROUP_M;                       // nc grows by `step` per group
+      const int g_sat = (tiles_n + step - 1) / step - 1;      // first group with nc == tiles_n (maybe)
+      // prefix(g) = GROUP_M * step * g (g + 1) / 2 for g <= g_sat
+      const long long pre_sat = (long long)GROUP_M * step * g_sat * (g_sat + 1) / 2;
+      if (v < pre_sat) {
+        // solve GROUP_M*step*g(g+1)/2 <= v
+        const double a = 0.5 * GROUP_M * step;
+        g = (int)((-a + sqrt(a * a + 4.0 * a * (double)v)) / (2.0 * a));
+        while ((long long)GROUP_M * step * (g + 1) * (g + 2) / 2 <= v) ++g;
+        while ((long long)GROUP_M * step * g * (g + 1) / 2 > v) --g;
+        base = (int)((long long)GROUP_M * step * g * (g + 1) / 2);
+      } else {
+        const int per = GROUP_M * tiles_n;
+        g = g_sat + (int)((v - pre_sat) / per);
+        base = (int)(pre_sat + (long long)(g - g_sat) * per);
+      }
+    }
+    const int w = v - base;                 // index inside the group, column-major
+    const int rows_in_group = min(GROUP_M, tiles_m - g * GROUP_M);
+    bn = w / GROUP_M;
+    bm = g * GROUP_M + (w - bn * GROUP_M);
+    if (rows_in_group < GROUP_M) {          // ragged last group: re-derive with its own height
+      bn = w / rows_in_group;
+      bm = g * GROUP_M + (w - bn * rows_in_group);
+    }
+    if (bm >= tiles_m || bn >= tiles_n) return;
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
   if (lower_only && n0 >= m0 + BM) return;
   if (info != nullptr && *info != 0) return;
 
@@ -175,12 +202,30 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  dim3 grid((unsigned)(n / BN), (unsigned)(m / BM));
+  // number of virtual tile ids (see the kernel's raster): groups of GROUP_M row-blocks, each
+  // with nc(g) column-blocks; the last group may be ragged
+  const int tiles_m = (int)(m / BM), tiles_n = (int)(n / BN);
+  long long nv = 0;
+  {
+    constexpr int RATIO = (BM >= BN) ? BM / BN : 1;
+    const int ngroups = (tiles_m + GROUP_M - 1) / GROUP_M;
+    for (int g = 0; g < ngroups; ++g) {
+      const int rows = (g == ngroups - 1) ? tiles_m - g * GROUP_M : GROUP_M;
+      long long nc = tiles_n;
+      if (lower_only) {
+        const long long lim = (long long)RATIO * GROUP_M * (g + 1);
+        if (lim < nc) nc = lim;
+      }
+      // the kernel's prefix formula assumes full groups except the last one
+      nv += (g == ngroups - 1) ? (long long)rows * nc : (long long)GROUP_M * nc;
+    }
+  }
+  dim3 grid((unsigned)nv);
   // algorithmic flops: 2 m n k, or m n k when only the lower triangle is wanted
   const int pr = g3i_prof_begin(ctx, BM == 256 ? G3_TAG_GEMM_BIG : (BM == 128 ? G3_TAG_GEMM_MID : G3_TAG_GEMM_SMALL),
                                 (lower_only ? 1.0 : 2.0) * (double)m * (double)n * (double)k);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, ctx->stream, (T*)C, ldc, (const T*)A, lda,
-                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info);
+                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info, tiles_m, tiles_n);
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -193,8 +238,20 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   // tile choice: big tiles when they still fill the chip, small tiles for the narrow
   // panel / leaf operations on the critical path of the factorisation
   const int64_t blocks128 = (m / 128) * (n / 128) / (lower_only ? 2 : 1);
-  if (m % 256 == 0 && n % 128 == 0 && (m / 256) * (n / 128) / (lower_only ? 2 : 1) >= 512)
+  static int forced = -1;   // G3_GEMM_CFG: development override of the tile choice
+  if (forced < 0) {
+    const char* e = getenv("G3_GEMM_CFG");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 1 && m % 256 == 0 && n % 128 == 0)
     return launch_cfg<T, 256, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (forced == 2 && m % 128 == 0 && n % 128 == 0)
+    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (forced == 4 && n % 128 == 0)
+    return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  // (the 256 x 128 tile, one block per CU, measured 4-5 % slower than 128 x 128 at two blocks
+  //  per CU on every large shape once the raster keeps operands in L2; kept for experiments)
   if (n % 128 == 0 && m % 32 == 0 && blocks128 < 128 && (wide || (m / 64) * (n / 64) < 128))
     // few tiles: thin 32 x 128 tiles spread a small problem over more CUs (one f64 tile of
     // 128 x 128 keeps a single CU busy for ~2 us per 16-deep K step)

@@ -11,15 +11,10 @@
 // forms its inverse W = L^-1 (forward elimination on [A | I]); every panel solve is then a
 // GEMM against W^T, so all O(N^3) work runs in the MFMA GEMM of g3_gemm.hip.
 #include "g3_internal.h"
+#include "g3_mfma.h"
 #include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------
-// 64 x 64 leaf: FACTOR = true  : A <- chol(A) (lower, strict upper zeroed), W <- inv(L)
-//               FACTOR = false : A holds L already;                         W <- inv(L)
-// W is written at stride ldw and, transposed, into Wt at stride ldwt.
-// 256 threads as a 16 x 16 grid, each owning a 4 x 4 register micro-tile of A and of W.
-// Per elimination step only column j of A and row j of W travel through LDS (double
-// buffered: one barrier per step).
 __device__ __forceinline__ double fast_rsqrt(double p) {
   double y = __builtin_amdgcn_rsq(p);
   y = y * fma(-0.5 * p * y, y, 1.5);
@@ -43,23 +38,23 @@ __device__ __forceinline__ float fast_rcp(float p) {
   return y;
 }
 
+// ---- 64 x 64 elimination sweep (device function, 512 threads as a 16 x 32 grid, each owning
+// a 4 x 2 register micro-tile of A and of W).  FACTOR: A <- chol(A) and W <- inv(L);
+// otherwise A already holds L and only W is formed.  Per elimination step only column j of A
+// and row j of W travel through LDS (double buffered: one barrier per step).  W is written at
+// stride ldw and, if Wt != nullptr, transposed at stride ldwt.
+constexpr int LEAF_THREADS = 512;
 template <typename T, bool FACTOR>
-__global__ void __launch_bounds__(256)
-leaf64_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, T* Wt, int64_t ldwt,
-              int64_t w_stride, int* info, int64_t row_base) {
-  if (FACTOR && *info != 0) return;
-  A += (int64_t)blockIdx.x * a_stride;
-  W += (int64_t)blockIdx.x * w_stride;
-  Wt += (int64_t)blockIdx.x * w_stride;
-  __shared__ T colbuf[2][G3_LEAF];
-  __shared__ T rowbuf[2][G3_LEAF];
-  const int tid = threadIdx.x, ti = tid >> 4, tk = tid & 15;
-  T a[4][4], w[4][4];
+__device__ __forceinline__ void leaf64_sweep(T* A, int64_t ld, T* W, int64_t ldw, T* Wt, int64_t ldwt,
+                                             int* info, int64_t row_base, T (*colbuf)[G3_LEAF],
+                                             T (*rowbuf)[G3_LEAF]) {
+  const int tid = threadIdx.x, ti = tid >> 5, tk = tid & 31;   // rows 4*ti.., cols 2*tk..
+  T a[4][2], w[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = 4 * ti + r, col = 4 * tk + c;
+    for (int c = 0; c < 2; ++c) {
+      const int row = 4 * ti + r, col = 2 * tk + c;
       a[r][c] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
       w[r][c] = (row == col) ? T(1) : T(0);
     }
@@ -68,20 +63,21 @@ leaf64_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, T* Wt, int6
     for (int s = 0; s < 4; ++s) {
       const int j = 4 * jj + s;
       const int buf = s & 1;
-      if (tk == jj) {
+      const int ctk = 2 * jj + (s >> 1), cc = s & 1;   // owner column group / column in tile
+      if (tk == ctk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) colbuf[buf][4 * ti + r] = a[r][s];
+        for (int r = 0; r < 4; ++r) colbuf[buf][4 * ti + r] = a[r][cc];
       }
       if (ti == jj) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rowbuf[buf][4 * tk + c] = w[s][c];
+        for (int c = 0; c < 2; ++c) rowbuf[buf][2 * tk + c] = w[s][c];
       }
       __syncthreads();
       T p = colbuf[buf][j];
       T rp, dg;
       if (FACTOR) {
         if (!(p > T(0))) {  // also catches NaN
-          if (tid == 0) atomicCAS(info, 0, (int)(row_base + (int64_t)blockIdx.x * G3_LEAF + j + 1));
+          if (tid == 0) atomicCAS(info, 0, (int)(row_base + j + 1));
           p = T(1);
         }
         // 1/sqrt(p) from the hardware estimate + two Newton steps (full precision, no fp64
@@ -93,60 +89,138 @@ leaf64_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, T* Wt, int6
         dg = p;
         rp = fast_rcp(p);
       }
-      T li[4], lk[4], wj[4];
+      T li[4], lk[2], wj[2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         li[r] = colbuf[buf][4 * ti + r];
-        lk[r] = colbuf[buf][4 * tk + r];
-        wj[r] = rowbuf[buf][4 * tk + r] * rp;
-        if (FACTOR) {
-          li[r] *= rp;
-          lk[r] *= rp;
-        }
+        if (FACTOR) li[r] *= rp;
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        lk[c] = colbuf[buf][2 * tk + c];
+        if (FACTOR) lk[c] *= rp;
+        wj[c] = rowbuf[buf][2 * tk + c] * rp;
       }
       // masked operands instead of per-element predicates: rows <= j and columns <= j of the
       // trailing update contribute exactly zero
-      T lim[4], lkm[4];
+      T lim[4], lkm[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        lim[r] = ((4 * ti + r) > j) ? li[r] : T(0);
-        lkm[r] = ((4 * tk + r) > j) ? lk[r] : T(0);
-      }
+      for (int r = 0; r < 4; ++r) lim[r] = ((4 * ti + r) > j) ? li[r] : T(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) lkm[c] = ((2 * tk + c) > j) ? lk[c] : T(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 2; ++c) {
           if (FACTOR) a[r][c] = fma(-lim[r], lkm[c], a[r][c]);
           w[r][c] = fma(-lim[r], wj[c], w[r][c]);
         }
-      if (FACTOR && tk == jj) {
+      if (FACTOR && tk == ctk) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 4 * ti + r;
-          if (row > j) a[r][s] = li[r];
-          else if (row == j) a[r][s] = dg;
+          if (row > j) a[r][cc] = li[r];
+          else if (row == j) a[r][cc] = dg;
         }
       }
       if (ti == jj) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) w[s][c] = wj[c];
+        for (int c = 0; c < 2; ++c) w[s][c] = wj[c];
       }
     }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = 4 * ti + r, col = 4 * tk + c;
+    for (int c = 0; c < 2; ++c) {
+      const int row = 4 * ti + r, col = 2 * tk + c;
       const T wv = (row >= col) ? w[r][c] : T(0);
       if (FACTOR) A[(int64_t)row * ld + col] = (row >= col) ? a[r][c] : T(0);
       W[(int64_t)row * ldw + col] = wv;
-      Wt[(int64_t)col * ldwt + row] = wv;
+      if (Wt) Wt[(int64_t)col * ldwt + row] = wv;
     }
 }
 
+// C[64 x 64] = alpha * A[64 x 64] * B[64 x 64]^T + beta * C by the 8 waves of the workgroup,
+// operands straight from global memory / L2 (one scalar per lane per MFMA, no LDS staging:
+// the whole product is 32 KB per operand).  Wave w owns output tiles 2w and 2w+1 of the
+// 4 x 4 grid of 16 x 16 tiles.  C may alias A: every wave finishes its loads before the
+// barrier that precedes the stores.
+template <typename T>
+__device__ __forceinline__ void tile_gemm64(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+                                            T alpha, T beta, bool lower_only) {
+  using M = MfmaT<T>;
+  using acc_t = typename M::acc_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, kq = lane >> 4;
+  acc_t acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tile = 2 * wave + t, tr = tile >> 2, tc = tile & 3;
+    acc[t] = acc_t{0, 0, 0, 0};
+    if (lower_only && tc > tr) continue;
+    const T* a = A + (int64_t)(16 * tr + fr) * lda + kq;
+    const T* b = B + (int64_t)(16 * tc + fr) * ldb + kq;
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) acc[t] = M::mfma(a[k], b[k], acc[t]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tile = 2 * wave + t, tr = tile >> 2, tc = tile & 3;
+    if (lower_only && tc > tr) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * tr + M::row(lane, r), col = 16 * tc + fr;
+      if (lower_only && col > row) continue;
+      T* p = C + (int64_t)row * ldc + col;
+      T v = alpha * acc[t][r];
+      if (beta != T(0)) v += beta * (*p);
+      *p = v;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- fused diagonal block: one workgroup factors a 128 x 128 block and forms its inverse
+//   L11 = chol(A11), W11 = inv(L11)          (64-wide sweep)
+//   L21 = A21 W11^T ; A22 -= L21 L21^T        (MFMA tile products)
+//   L22 = chol(A22), W22 = inv(L22)           (64-wide sweep)
+//   W21 = -W22 (L21 W11)                      (two MFMA tile products)
+// W (128 x 128, stride ldw) receives [[W11, 0], [W21, W22]]; scr holds W11^T and (L21 W11)^T.
+// FACTOR = false: A already holds L, only W is formed.  One block per 128-block (batched via
+// blockIdx.x with the given strides).
+template <typename T, bool FACTOR>
+__global__ void __launch_bounds__(LEAF_THREADS)
+diag128_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, T* scr,
+               int* info, int64_t row_base) {
+  if (FACTOR && *info != 0) return;
+  A += (int64_t)blockIdx.x * a_stride;
+  W += (int64_t)blockIdx.x * w_stride;
+  scr += (int64_t)blockIdx.x * (2 * 64 * 64);
+  row_base += (int64_t)blockIdx.x * G3_LB;
+  __shared__ T colbuf[2][G3_LEAF];
+  __shared__ T rowbuf[2][G3_LEAF];
+  T* W11t = scr;
+  T* Tt = scr + 64 * 64;
+  T* A21 = A + 64 * ld;
+  T* A22 = A21 + 64;
+  T* W22 = W + 64 * ldw + 64;
+  leaf64_sweep<T, FACTOR>(A, ld, W, ldw, W11t, 64, info, row_base, colbuf, rowbuf);
+  __syncthreads();
+  if (FACTOR) {
+    tile_gemm64<T>(A21, ld, A21, ld, W, ldw, T(1), T(0), false);        // L21 = A21 W11^T (in place)
+    tile_gemm64<T>(A22, ld, A21, ld, A21, ld, T(-1), T(1), true);       // A22 -= L21 L21^T
+  }
+  leaf64_sweep<T, FACTOR>(A22, ld, W22, ldw, (T*)nullptr, 0, info, row_base + 64, colbuf, rowbuf);
+  __syncthreads();
+  tile_gemm64<T>(Tt, 64, W11t, 64, A21, ld, T(1), T(0), false);         // Tt = (L21 W11)^T
+  tile_gemm64<T>(W + 64 * ldw, ldw, W22, ldw, Tt, 64, T(-1), T(0), false);   // W21 = -W22 (L21 W11)
+  // the upper-right 64 x 64 block of W must read as zero
+  for (int e = threadIdx.x; e < 64 * 64; e += LEAF_THREADS) W[(int64_t)(e >> 6) * ldw + 64 + (e & 63)] = T(0);
+}
+
 constexpr int64_t LB = G3_LB;
-constexpr int64_t LF = G3_LEAF;
 
 static int64_t split_point(int64_t n, int64_t unit) {
   // n is a multiple of `unit` and > unit; split near the middle on a coarse power-of-two
@@ -158,84 +232,24 @@ static int64_t split_point(int64_t n, int64_t unit) {
   return n1;
 }
 
-// ---- inside one LB x LB diagonal block: 64-wide recursion against the 64 x 64 inverses that
-// sit on the diagonal of that block's W (stride LB)
-template <typename T>
-static int trsm_rec64(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64_t m, int64_t ldb,
-                      const T* W, g3_dtype dt) {
-  if (n == LF)  // B <- B W^T in place: the 64 x 64 tile spans all 64 output columns
-    return g3i_gemm_nt(ctx, B, ldb, B, ldb, W, LB, m, LF, LF, 1.0, 0.0, dt, 0);
-  const int64_t n1 = split_point(n, LF), n2 = n - n1;
-  int rc = trsm_rec64<T>(ctx, L, n1, ldl, B, m, ldb, W, dt);
-  if (rc) return rc;
-  rc = g3i_gemm_nt(ctx, B + n1, ldb, B, ldb, L + n1 * ldl, ldl, m, n2, n1, -1.0, 1.0, dt, 0);
-  if (rc) return rc;
-  return trsm_rec64<T>(ctx, L + n1 * ldl + n1, n2, ldl, B + n1, m, ldb, W + n1 * (LB + 1), dt);
-}
-
-template <typename T>
-static int potrf_rec64(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, T* Wt, int64_t row_base, g3_dtype dt) {
-  if (n == LF) {
-    const int pr = g3i_prof_begin(ctx, G3_TAG_LEAF, 64.0 * 64.0 * 64.0 / 3.0);
-    hipLaunchKernelGGL((leaf64_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, A, ld, (int64_t)0, W, LB,
-                       Wt, LB, (int64_t)0, ctx->d_info, row_base);
-    g3i_prof_end(ctx, pr);
-    G3_LAUNCH_CHECK();
-    return G3_OK;
-  }
-  const int64_t n1 = split_point(n, LF), n2 = n - n1;
-  int rc = potrf_rec64<T>(ctx, A, n1, ld, W, Wt, row_base, dt);
-  if (rc) return rc;
-  T* A21 = A + n1 * ld;
-  T* A22 = A21 + n1;
-  rc = trsm_rec64<T>(ctx, A, n1, ld, A21, n2, ld, W, dt);
-  if (rc) return rc;
-  rc = g3i_gemm_nt(ctx, A22, ld, A21, ld, A21, ld, n2, n2, n1, -1.0, 1.0, dt, 1);
-  if (rc) return rc;
-  return potrf_rec64<T>(ctx, A22, n2, ld, W + n1 * (LB + 1), Wt + n1 * (LB + 1), row_base + n1, dt);
-}
-
-// W (LB x LB) <- inv(L) given the 64 x 64 diagonal inverses in W and their transposes in Wt:
-// inv([[L11,0],[L21,L22]]) = [[W1,0],[-W2 L21 W1, W2]], first on 128-blocks, then on the block.
-template <typename T>
-static int merge_inverse(g3_ctx* ctx, const T* L, int64_t ld, T* W, T* Wt, T* Tt, g3_dtype dt) {
-  int rc;
-  for (int64_t o = 0; o < LB; o += 128) {
-    const T* L21 = L + (o + 64) * ld + o;
-    T* W2 = W + (o + 64) * (LB + 1);
-    rc = g3i_gemm_nt(ctx, Tt, 128, Wt + o * (LB + 1), LB, L21, ld, 64, 64, 64, 1.0, 0.0, dt, 0);   // (L21 W1)^T
-    if (rc) return rc;
-    rc = g3i_gemm_nt(ctx, W + (o + 64) * LB + o, LB, W2, LB, Tt, 128, 64, 64, 64, -1.0, 0.0, dt, 0);  // W21
-    if (rc) return rc;
-    rc = g3i_gemm_nt(ctx, Wt + o * LB + o + 64, LB, Tt, 128, W2, LB, 64, 64, 64, -1.0, 0.0, dt, 0);   // W21^T
-    if (rc) return rc;
-  }
-  rc = g3i_gemm_nt(ctx, Tt, 128, Wt, LB, L + 128 * ld, ld, 128, 128, 128, 1.0, 0.0, dt, 0);
-  if (rc) return rc;
-  return g3i_gemm_nt(ctx, W + 128 * LB, LB, W + 128 * (LB + 1), LB, Tt, 128, 128, 128, 128, -1.0, 0.0, dt, 0);
-}
-
 template <typename T>
 static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_dtype dt) {
-  T* Wt = (T*)ctx->wscr;
-  T* Tt = Wt + LB * LB;
-  int rc = potrf_rec64<T>(ctx, A, LB, ld, W, Wt, row_base, dt);
-  if (rc) return rc;
-  return merge_inverse<T>(ctx, A, ld, W, Wt, Tt, dt);
+  const int pr = g3i_prof_begin(ctx, G3_TAG_LEAF, 128.0 * 128.0 * 128.0 / 3.0);
+  hipLaunchKernelGGL((diag128_kernel<T, true>), dim3(1), dim3(LEAF_THREADS), 0, ctx->stream, A, ld, (int64_t)0, W,
+                     LB, (int64_t)0, (T*)ctx->wscr, ctx->d_info, row_base);
+  g3i_prof_end(ctx, pr);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
 }
 
 // ---- across LB blocks
 template <typename T>
 static int trsm_rec(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64_t m, int64_t ldb,
                     const T* W, g3_dtype dt) {
-  if (n == LB) {
-    // B <- B W^T with W lower triangular, in place: 128-column output tiles in DESCENDING
-    // order, each reading only the columns at or left of itself (one tile spans its 128
-    // output columns, so a workgroup has read its rows before it overwrites them)
-    int rc = g3i_gemm_nt_ex(ctx, B + 128, ldb, B, ldb, W + 128 * LB, LB, m, 128, 256, 1.0, 0.0, dt, 0, 1);
-    if (rc) return rc;
-    return g3i_gemm_nt_ex(ctx, B, ldb, B, ldb, W, LB, m, 128, 128, 1.0, 0.0, dt, 0, 1);
-  }
+  if (n == LB)
+    // B <- B W^T in place: one tile spans the 128 output columns, so a workgroup has read
+    // its rows before it overwrites them
+    return g3i_gemm_nt_ex(ctx, B, ldb, B, ldb, W, LB, m, LB, LB, 1.0, 0.0, dt, 0, 1);
   const int64_t n1 = split_point(n, LB), n2 = n - n1;
   int rc = trsm_rec<T>(ctx, L, n1, ldl, B, m, ldb, W, dt);
   if (rc) return rc;
@@ -265,12 +279,20 @@ int g3i_reset_info(g3_ctx* ctx) {
 }
 
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt) {
-  if (!ctx->wscr) {
-    const size_t wb = (size_t)(LB * LB + 128 * 128) * sizeof(double);
-    G3_HIP(hipMalloc(&ctx->wscr, wb));
-    G3_HIP(hipMemset(ctx->wscr, 0, wb));   // the never-written blocks of Wt must read as zero
-  }
   size_t need = (size_t)(n / LB) * LB * LB * g3_esize(dt);
+  // scratch of the fused diagonal kernel: W11^T and (L21 W11)^T, one pair per block so the
+  // batched inverse-only launch (g3i_trtri_blocks) can run all blocks at once
+  const size_t wneed = (size_t)(n / LB) * 2 * 64 * 64 * sizeof(double);
+  if (ctx->wscr_bytes < wneed) {
+    if (ctx->wscr) {
+      G3_HIP(hipStreamSynchronize(ctx->stream));
+      G3_HIP(hipFree(ctx->wscr));
+      ctx->wscr = nullptr;
+      ctx->wscr_bytes = 0;
+    }
+    G3_HIP(hipMalloc(&ctx->wscr, wneed));
+    ctx->wscr_bytes = wneed;
+  }
   if (ctx->invd_bytes >= need) return G3_OK;
   if (ctx->invd) {
     G3_HIP(hipStreamSynchronize(ctx->stream));
@@ -293,13 +315,6 @@ int g3i_ensure_work(g3_ctx* ctx, size_t bytes) {
   }
   G3_HIP(hipMalloc(&ctx->work, bytes));
   ctx->work_bytes = bytes;
-  return G3_OK;
-}
-
-static int zero_wt_scratch(g3_ctx* ctx) {
-  // Wt is typed by the caller; zero the whole scratch so stale data of another dtype or of a
-  // previous block never leaks into the blocks the merges read but nobody writes
-  G3_HIP(hipMemsetAsync(ctx->wscr, 0, (size_t)(LB * LB + 128 * 128) * sizeof(double), ctx->stream));
   return G3_OK;
 }
 
@@ -378,14 +393,10 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
 int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd) {
   G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (n == 0) return G3_OK;
-  // strictly-upper 64-blocks of every W are read as zeros by the merges and the panel GEMMs
-  G3_HIP(hipMemsetAsync(invd, 0, (size_t)(n / LB) * LB * LB * g3_esize(dt), ctx->stream));
-  int rc = zero_wt_scratch(ctx);
-  if (rc) return rc;
   int64_t NB = ctx->nb_lookahead;
   if (NB <= 0) {
     const char* e = getenv("G3_NB");
-    NB = e ? atoll(e) : 2048;
+    NB = e ? atoll(e) : 1024;
   }
   NB = g3_roundup(NB < LB ? LB : NB, LB);
   if (n >= 3 * NB) {
@@ -404,30 +415,19 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
   return trsm_rec<float>(ctx, (const float*)L, n, ldl, (float*)B, m, ldb, (const float*)invd, dt);
 }
 
-template <typename T>
-static int trtri_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* W, g3_dtype dt) {
-  T* Wt = (T*)ctx->wscr;
-  T* Tt = Wt + LB * LB;
-  for (int64_t b = 0; b < n / LB; ++b) {
-    const T* Lb = L + b * LB * (ldl + 1);
-    T* Wb = W + b * LB * LB;
-    hipLaunchKernelGGL((leaf64_kernel<T, false>), dim3((unsigned)(LB / LF)), dim3(256), 0, ctx->stream,
-                       const_cast<T*>(Lb), ldl, LF * (ldl + 1), Wb, LB, Wt, LB, LF * (LB + 1), ctx->d_info,
-                       (int64_t)0);
-    G3_LAUNCH_CHECK();
-    int rc = merge_inverse<T>(ctx, Lb, ldl, Wb, Wt, Tt, dt);
-    if (rc) return rc;
-  }
-  return G3_OK;
-}
-
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd) {
   if (n == 0) return G3_OK;
-  G3_HIP(hipMemsetAsync(invd, 0, (size_t)(n / LB) * LB * LB * g3_esize(dt), ctx->stream));
-  int rc = zero_wt_scratch(ctx);
-  if (rc) return rc;
-  if (dt == G3_F64) return trtri_t<double>(ctx, (const double*)L, n, ldl, (double*)invd, dt);
-  return trtri_t<float>(ctx, (const float*)L, n, ldl, (float*)invd, dt);
+  const unsigned nb = (unsigned)(n / LB);
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((diag128_kernel<double, false>), dim3(nb), dim3(LEAF_THREADS), 0, ctx->stream,
+                       (double*)const_cast<void*>(L), ldl, LB * (ldl + 1), (double*)invd, LB, LB * LB,
+                       (double*)ctx->wscr, ctx->d_info, (int64_t)0);
+  else
+    hipLaunchKernelGGL((diag128_kernel<float, false>), dim3(nb), dim3(LEAF_THREADS), 0, ctx->stream,
+                       (float*)const_cast<void*>(L), ldl, LB * (ldl + 1), (float*)invd, LB, LB * LB,
+                       (float*)ctx->wscr, ctx->d_info, (int64_t)0);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
 }
 
 static int read_info(g3_ctx* ctx, int* info_host) {

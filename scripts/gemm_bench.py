@@ -1,0 +1,35 @@
+"""Time g3_gemm_nt on MI355X for given shapes (development aid).
+usage: python scripts/gemm_bench.py  [m n k lower] ...   (G3_GEMM_CFG=1..4 forces a tile config)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import g3py_amd as g3
+
+shapes = [(16384, 16384, 2048, 1), (16384, 16384, 16384, 1), (8192, 8192, 2048, 1), (16384, 2048, 2048, 0),
+          (4096, 4096, 4096, 1), (16384, 128, 256, 0), (1024, 8192, 8192, 0)]
+if len(sys.argv) > 4:
+    a = list(map(int, sys.argv[1:]))
+    shapes = [tuple(a[i:i + 4]) for i in range(0, len(a), 4)]
+dev = g3.Device(0)
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
+dev.set_stream(st.cuda_stream)
+for (m, n, k, lower) in shapes:
+    A = torch.rand((max(m, n), k), dtype=torch.float64, device='cuda') - 0.5
+    C = torch.rand((m, n), dtype=torch.float64, device='cuda')
+    Ad = dev.wrap(A.data_ptr(), max(m, n), k, k, np.float64)
+    Cd = dev.wrap(C.data_ptr(), m, n, n, np.float64)
+    for _ in range(2):
+        dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=1.0, lower_only=bool(lower))
+    torch.cuda.synchronize()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=1.0, lower_only=bool(lower))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = (1.0 if lower else 2.0) * m * n * k
+    print('m %6d n %6d k %6d lower %d cfg %s: %8.3f ms  %6.2f TFLOP/s' % (m, n, k, lower, os.environ.get('G3_GEMM_CFG', 'auto'), ms, fl / ms / 1e9))

@@ -27,7 +27,7 @@ for dt, tol in ((np.float64, 1e-13), (np.float32, 1e-4)):
                           (2048, 1536, 128, False), (8192, 8192, 64, True)]:
         assert gemm_case(m, n, k, dt, lo) < tol
 
-for n in (256, 512, 768, 1024, 4096, 6144, 8192):
+for n in (128, 256, 384, 512, 768, 1024, 4096, 6144, 8192):
     B = rng.standard_normal((n, n)); K = B @ B.T / n + np.eye(n)
     Kd = dev.upload(K)
     t0 = time.time(); info = dev.potrf(Kd, n); t1 = time.time()
