@@ -1,0 +1,118 @@
+"""GPU parity of the Gram kernels against the oracle's golden fixtures and the live oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ZOO = ['SE', 'OU', 'MAT32', 'MAT52', 'RQ', 'COS', 'SIN', 'SINC', 'SM', 'WN', 'MAT52+COS', 'SE*COS', '2*SE+0.1',
+       '(SE+OU)*(MAT32+0.5)', 'SE[dims]']
+
+
+def _zoo(d):
+    from oracle.gen_golden import kernel_zoo
+    return kernel_zoo(d)
+
+
+def _gram(dev, spec, X1, X2=None, dtype=np.float64, flags=0, pad=None):
+    from g3py_amd.device import compile_spec
+    X1 = np.asarray(X1, dtype=dtype)
+    d = X1.shape[1]
+    prog = compile_spec(spec, d)
+    A = dev.upload(X1)
+    B = dev.upload(np.asarray(X2, dtype=dtype)) if X2 is not None else None
+    n1 = X1.shape[0]
+    n2 = n1 if X2 is None else len(X2)
+    p1, p2 = (pad or n1), (pad or n2) if X2 is None else n2
+    out = dev.alloc(p1, p2, dtype, zero=True)
+    dev.gram(prog, A, B, d, out, p1, p2, flags)
+    return dev.download(out)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import g3py_amd as g3
+    return g3.Device.default()
+
+
+@pytest.mark.parametrize('d', [1, 3, 8])
+@pytest.mark.parametrize('name', ZOO)
+def test_gram_matches_golden(dev, golden_dir, d, name):
+    g = np.load(os.path.join(golden_dir, 'oracle_kernels.npz'))
+    X, Xs = g['d%d_X' % d], g['d%d_Xs' % d]
+    spec = _zoo(d)[name]
+    got = _gram(dev, spec, X)
+    ref = g['d%d_%s_sym' % (d, name)]
+    np.testing.assert_allclose(got, ref, rtol=2e-12, atol=1e-13 * max(1.0, np.abs(ref).max()))
+    got = _gram(dev, spec, Xs, X)
+    ref = g['d%d_%s_cross' % (d, name)]
+    np.testing.assert_allclose(got, ref, rtol=2e-12, atol=1e-13 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('name', ['SE', 'MAT52+COS', 'SM'])
+def test_gram_fp32(dev, name):
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(11)
+    X = rng.uniform(0, 3, (70, 3))
+    spec = _zoo(3)[name]
+    got = _gram(dev, spec, X, dtype=np.float32)
+    ref = orc.kernel_cov(spec, X)
+    np.testing.assert_allclose(got, ref, rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 65, 130, 257])
+def test_gram_ragged_sizes_and_padding(dev, n):
+    import g3py_amd._lib as lib
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(n)
+    X = rng.uniform(0, 2, (n, 4))
+    spec = orc.with_noise(('SE', 1.0, np.ones(4), None), 0.1)       # the SE fast path
+    pad = lib.roundup(n)
+    K = _gram(dev, spec, X, flags=lib.G3_GRAM_PAD_EYE | lib.G3_GRAM_SCRUB, pad=pad)
+    np.testing.assert_allclose(K[:n, :n], orc.kernel_cov(spec, X), rtol=1e-13)
+    np.testing.assert_array_equal(K[n:, n:], np.eye(pad - n))
+    assert not K[:n, n:].any() and not K[n:, :n].any()
+    # LOWER: tiles strictly above the diagonal are left untouched (zero-initialised here)
+    Kl = _gram(dev, spec, X, flags=lib.G3_GRAM_LOWER, pad=pad)
+    np.testing.assert_allclose(np.tril(Kl[:n, :n]), np.tril(orc.kernel_cov(spec, X)), rtol=1e-13)
+
+
+def test_gram_scrub_fuses_tt_to_num(dev):
+    import g3py_amd._lib as lib
+    from oracle import g3_oracle as orc
+    X = np.array([[0.0], [1.0], [np.nan], [np.inf]])
+    spec = ('SE', 1.0, np.array([1.0]), None)
+    with np.errstate(all='ignore'):
+        ref = orc.tt_to_num(orc.kernel_cov(spec, X))
+    got = _gram(dev, spec, X, flags=lib.G3_GRAM_SCRUB)
+    np.testing.assert_allclose(got, ref)
+
+
+def test_kernel_objects_cov_and_algebra(dev):
+    """Kernel.cov / operators (kernels.py:45-75,106-110) through the product classes"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(2)
+    X, X2 = rng.uniform(0, 3, (50, 2)), rng.uniform(0, 3, (20, 2))
+    r = np.array([0.7, 1.1])
+    k = 2.0 * g3.SE(X, var=1.3, metric=g3.ARD_L2(X, rate=r)) + g3.COS(X, var=0.4, freq=np.array([0.2, 0.3])) * \
+        g3.OU(X, var=1.0, metric=g3.ARD_L1(X, rate=r)) + 0.25
+    spec = ('shift', 0.25, ('sum', ('scale', 2.0, ('SE', 1.3, r, None)),
+                            ('prod', ('COS', 0.4, np.array([0.2, 0.3]), None), ('OU', 1.0, r, None))))
+    np.testing.assert_allclose(k.cov(X), orc.kernel_cov(spec, X), rtol=1e-12)
+    np.testing.assert_allclose(k(X2, X), orc.kernel_cov(spec, X2, X), rtol=1e-12)
+    kn = g3.KernelSum(g3.SE(X, var=1.0, metric=g3.ARD_L2(X, rate=r)), g3.KernelNoise(name='Noise', var=0.3))
+    np.testing.assert_allclose(np.diag(kn.cov(X)) - np.diag(kn.cov(X, X)), 0.3)     # noise only when square
+    assert 'SE' in str(k) and isinstance(3 * g3.SE(X), g3.KernelScale) and isinstance(g3.SE(X) * g3.OU(X), g3.KernelProd)
+
+
+def test_gram_diag(dev):
+    from oracle import g3_oracle as orc
+    from g3py_amd.device import compile_spec
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0, 3, (77, 3))
+    spec = orc.with_noise(_zoo(3)['MAT52+COS'], 0.2)
+    out = dev.alloc(1, 77, np.float64)
+    dev.gram_diag(compile_spec(spec, 3), dev.upload(X), 3, out)
+    np.testing.assert_allclose(dev.download(out)[0], np.diag(orc.kernel_cov(spec, X)), rtol=1e-13)

@@ -1,0 +1,155 @@
+"""GPU parity tests of the low-level C-ABI kernels (GEMM, Cholesky, triangular solve, scrubs)
+against NumPy/SciPy on the same seeded inputs.  All calls go through libg3hip.so."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import g3py_amd as g3
+    return g3.Device.default()
+
+
+TOL = {np.float64: 5e-13, np.float32: 2e-4}
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+@pytest.mark.parametrize('m,n,k,lower', [(64, 64, 64, False), (128, 64, 128, False), (192, 192, 64, True),
+                                         (32 * 5, 128, 256, False), (1536, 1536, 256, True),
+                                         (2048, 1536, 128, False), (4096, 4096, 96, True),
+                                         (2176, 384, 512, True)])
+def test_gemm_nt(dev, dt, m, n, k, lower):
+    if m % 64 or n % 64:
+        pytest.skip('tile multiple')
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    A = rng.standard_normal((m, k)).astype(dt)
+    B = rng.standard_normal((n, k)).astype(dt)      # asymmetric operands: a transposed C would show
+    C = rng.standard_normal((m, n)).astype(dt)
+    Ad, Bd, Cd = dev.upload(A), dev.upload(B), dev.upload(C)
+    dev.gemm_nt(Cd, Ad, Bd, m, n, k, alpha=-0.5, beta=1.0, lower_only=lower)
+    got = dev.download(Cd)
+    ref = C.astype(np.float64) - 0.5 * A.astype(np.float64) @ B.astype(np.float64).T
+    if lower:
+        ref = np.where(np.tril(np.ones((m, n), bool)), ref, C)
+    assert np.abs(got - ref).max() <= TOL[dt] * np.abs(ref).max() * max(1, k / 64)
+
+
+def test_gemm_identity_layout(dev):
+    # A = I with asymmetric B catches a row<->col swap of the MFMA accumulator layout
+    n = 128
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    Cd = dev.alloc(n, n, np.float64, zero=True)
+    dev.gemm_nt(Cd, dev.upload(np.eye(n)), dev.upload(B), n, n, n)
+    np.testing.assert_array_equal(dev.download(Cd), B.T)
+
+
+def test_gemm_argument_errors(dev):
+    import g3py_amd as g3
+    a = dev.alloc(64, 64, np.float64)
+    with pytest.raises(g3.G3Error):
+        dev.gemm_nt(a, a, a, 60, 64, 64)        # m not a tile multiple
+    with pytest.raises(g3.G3Error):
+        dev.gemm_nt(a, a, a, 64, 64, 8)         # k not a multiple of 16
+
+
+def _spd(rng, n, dt=np.float64):
+    B = rng.standard_normal((n, max(8, n // 4)))
+    return (B @ B.T / B.shape[1] + np.eye(n)).astype(dt)
+
+
+@pytest.mark.parametrize('n', [128, 256, 384, 640, 1024, 2048, 3072, 4224])
+def test_potrf_matches_lapack(dev, n):
+    rng = np.random.default_rng(n)
+    K = _spd(rng, n)
+    Kd = dev.upload(K)
+    assert dev.potrf(Kd, n) == 0
+    L = np.tril(dev.download(Kd))
+    Lr = scipy.linalg.cholesky(K, lower=True)
+    assert np.abs(L - Lr).max() < 1e-12 * n ** 0.5
+    # strict upper triangle is never touched
+    np.testing.assert_array_equal(np.triu(dev.download(Kd), 1), np.triu(K, 1))
+
+
+def test_potrf_fp32(dev):
+    rng = np.random.default_rng(5)
+    K = _spd(rng, 512, np.float32)
+    Kd = dev.upload(K)
+    assert dev.potrf(Kd, 512) == 0
+    L = np.tril(dev.download(Kd)).astype(np.float64)
+    assert np.abs(L @ L.T - K).max() < 5e-5
+
+
+def test_potrf_info_on_bad_pivot(dev):
+    rng = np.random.default_rng(1)
+    K = _spd(rng, 512)
+    K[300, 300] = -5.0
+    assert dev.potrf(dev.upload(K), 512) == 301          # LAPACK-style 1-based pivot index
+    K2 = _spd(rng, 256)
+    K2[10, 3] = K2[3, 10] = np.nan
+    assert dev.potrf(dev.upload(K2), 256) != 0
+
+
+@pytest.mark.parametrize('n,m', [(128, 128), (384, 256), (1024, 128), (2048, 384)])
+def test_trsm_rlt(dev, n, m):
+    rng = np.random.default_rng(n + m)
+    L = scipy.linalg.cholesky(_spd(rng, n), lower=True)
+    B = rng.standard_normal((m, n))
+    Bd = dev.upload(B)
+    dev.trsm_rlt(dev.upload(L), n, Bd, m)
+    X = dev.download(Bd)
+    ref = scipy.linalg.solve_triangular(L, B.T, lower=True).T
+    assert np.abs(X - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_potrf_robust_follows_reference_schedule(dev, golden_dir):
+    """CholeskyRobust (g3py/libs/tensors.py:197-222): jitter schedule, lift of non-positive
+    diagonals and the 1e-10*I fallback, against oracle fixtures."""
+    g = np.load(os.path.join(golden_dir, 'oracle_jitter.npz'))
+    for i in (1, 2, 3, 4):
+        K = g['K%d' % i]
+        n = K.shape[0]
+        Kd, Ld = dev.upload(K), dev.alloc(n, n, np.float64)
+        tries, fallback, jitter = dev.potrf_robust(Kd, Ld, n)
+        assert tries == int(g['tries%d' % i]) and fallback == bool(g['fallback%d' % i])
+        L = dev.download(Ld)
+        np.testing.assert_allclose(L, g['L%d' % i], rtol=1e-7, atol=1e-9)
+        np.testing.assert_array_equal(dev.download(Kd), K)      # non-destructive
+
+
+def test_scrub_and_cov_lift(dev):
+    a = np.array([[np.nan, np.inf, 1.0], [-np.inf, 2.0, 3.0], [0.5, -1.0, 4.0]])
+    d = dev.upload(a)
+    dev.scrub(d, 3, 3)
+    r = dev.download(d)
+    assert r[0, 0] == 0 and r[0, 1] == np.float32(1e10) and r[1, 0] == np.float32(1e10)
+    c = np.array([[-0.5, 0.1], [0.1, 1.0]])
+    d = dev.upload(c)
+    dev.cov_lift(d, 2)
+    np.testing.assert_allclose(np.diag(dev.download(d)), [np.float32(1e-6), 1.5 + np.float32(1e-6)])
+    d = dev.upload(np.eye(3) * 2)
+    dev.cov_lift(d, 3)
+    np.testing.assert_array_equal(dev.download(d), np.eye(3) * 2)
+
+
+def test_reference_named_tensor_helpers():
+    """the device-backed equivalents of tensors.py helpers keep the reference's semantics"""
+    import g3py_amd as g3
+    rng = np.random.default_rng(3)
+    K = _spd(rng, 100)
+    L = g3.cholesky_robust(K)
+    np.testing.assert_allclose(L, scipy.linalg.cholesky(K, lower=True), atol=1e-12)
+    b = rng.standard_normal(100)
+    np.testing.assert_allclose(g3.solve_lower_triangular(L, b), scipy.linalg.solve_triangular(L, b, lower=True),
+                               atol=1e-11)
+    with pytest.raises(AssertionError):
+        g3.cholesky_robust(np.ones(4))                         # tensors.py:194 (2-D only)
+    out = [[None]]
+    g3.cholesky_robust.perform(None, [K], out)                 # Theano Op protocol
+    np.testing.assert_allclose(out[0][0], L)
+    assert g3.cholesky_robust.infer_shape(None, [(100, 100)]) == [(100, 100)]
+    np.testing.assert_array_equal(g3.tt_to_num(np.array([np.nan, np.inf, 1.0])), [0, np.float32(1e10), 1.0])

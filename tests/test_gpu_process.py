@@ -1,0 +1,162 @@
+"""GPU parity of the g3py-compatible process API (GaussianProcess / WarpedGaussianProcess)
+against the oracle's golden fixtures and the reference's own gpmm.py outputs.
+Tolerances: fp64 logp 1e-8 relative (BASELINE.json), means/variances 1e-8 absolute*scale."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(gp, **nat):
+    """natural-space keyword values -> the reference's transformed-space params dict"""
+    p = gp.params_test
+    by = {v.name: v for v in gp.model.vars}
+    for k, val in nat.items():
+        v = by[gp.name + '_' + k]
+        p[v.key] = (np.log(val) if v.positive else np.asarray(val, dtype=float)) * np.ones(v.shape)
+    return p
+
+
+@pytest.mark.parametrize('name', ['se_d1', 'se_d3', 'se_d4', 'ou_d2'])
+def test_gp_matches_reference_gpmm(golden_dir, name):
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'gpmm_%s.npz' % name))
+    X, y, Xs = g['X'], g['y'], g['Xs']
+    kern = g3.SE(X) if str(g['kind']) == 'SE' else g3.OU(X)
+    gp = g3.GaussianProcess(space=Xs, location=g3.Zero(), kernel=kern)
+    gp.observed(X, y)
+    kn = kern.name
+    p = _params(gp, **{kn + '_var': float(g['var']), kn + '_rate': g['rate'], 'Noise_var': float(g['noise'])})
+    lp = gp.logp(p)
+    assert abs(lp - float(g['logp'])) <= 1e-9 * abs(float(g['logp']))
+    pred = gp.predict(p, var=True, cov=True)
+    np.testing.assert_allclose(pred.mean, g['mean'], atol=1e-8)
+    np.testing.assert_allclose(pred.variance, np.maximum(g['variance'], 0), atol=1e-8)
+    np.testing.assert_allclose(pred.covariance, g['covariance'], atol=1e-8)
+    np.testing.assert_allclose(pred.std, np.sqrt(np.maximum(g['variance'], 0)), atol=1e-7)
+    # the factor itself
+    np.testing.assert_allclose(gp.cholesky(p, space=X, prior=True, noise=True), g['L'], atol=1e-9)
+
+
+PROCS = {
+    'gp_se_bias': lambda g3, X: (g3.GaussianProcess, dict(location=g3.Bias(), kernel=g3.SE(X)),
+                                 dict(SE_var=1.1, SE_rate=[0.9, 1.2], Noise_var=0.1, Bias_Bias=0.3)),
+    'gp_mat52cos_zero': lambda g3, X: (g3.GaussianProcess, dict(location=g3.Zero(), kernel=g3.MAT52(X) + g3.COS(X)),
+                                       dict(MAT52_var=1.0, MAT52_rate=[0.9, 1.2], COS_var=0.5,
+                                            COS_freq=[0.125, 0.125], Noise_var=0.1)),
+    'gp_se_linear': lambda g3, X: (g3.GaussianProcess, dict(location=g3.Linear(), kernel=g3.SE(X)),
+                                   dict(SE_var=0.7, SE_rate=[0.9, 1.2], Noise_var=0.05, Linear_Constant=0.1,
+                                        Linear_Coeff=[0.02, -0.03])),
+    'wgp_boxcox': lambda g3, X: (g3.WarpedGaussianProcess,
+                                 dict(location=g3.Bias(), kernel=g3.SE(X), mapping=g3.BoxCoxLinear()),
+                                 dict(SE_var=1.0, SE_rate=[0.9, 1.2], Noise_var=0.1, Bias_Bias=0.2,
+                                      BoxCoxLinear_shift=1.0, BoxCoxLinear_scale=1.0, BoxCoxLinear_power=1.2)),
+    'wgp_arcsinh': lambda g3, X: (g3.WarpedGaussianProcess,
+                                  dict(location=g3.Zero(), kernel=g3.SE(X), mapping=g3.ArcsinhLinear()),
+                                  dict(SE_var=1.0, SE_rate=[0.9, 1.2], Noise_var=0.1, ArcsinhLinear_shift=0.1,
+                                       ArcsinhLinear_scale=0.8)),
+    'wgp_logshift': lambda g3, X: (g3.WarpedGaussianProcess,
+                                   dict(location=g3.Zero(), kernel=g3.OU(X), mapping=g3.LogShifted()),
+                                   dict(OU_var=1.0, OU_rate=[0.9, 1.2], Noise_var=0.1, LogShifted_shift=-0.5)),
+    'wgp_linear': lambda g3, X: (g3.WarpedGaussianProcess,
+                                 dict(location=g3.Zero(), kernel=g3.RQ(X), mapping=g3.LinearMapping()),
+                                 dict(RQ_var=1.0, RQ_rate=[0.9, 1.2], RQ_alpha=1.5, Noise_var=0.1,
+                                      LinearMapping_shift=0.2, LinearMapping_scale=1.5)),
+}
+
+
+@pytest.mark.parametrize('name', sorted(PROCS))
+def test_process_matches_oracle_fixture(golden_dir, name):
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs, Z, y = g['X'], g['Xs'], g['Z'], g[name + '_y']
+    cls, kw, nat = PROCS[name](g3, X)
+    gp = cls(space=Xs, **kw)
+    gp.observed(X, y)
+    p = _params(gp, **nat)
+    ref = float(g[name + '_logp'])
+    assert abs(gp.logp(p) - ref) <= 1e-8 * abs(ref)
+    assert abs(gp.loglike(p) - ref) <= 1e-8 * abs(ref)
+    scale = max(1.0, np.abs(g[name + '_mean_n0']).max())
+    for noise in (False, True):
+        s = '_n%d' % noise
+        np.testing.assert_allclose(gp.mean(p, noise=noise), g[name + '_mean' + s], atol=1e-8 * scale)
+        np.testing.assert_allclose(gp.median(p, noise=noise), g[name + '_median' + s], atol=1e-8 * scale)
+        np.testing.assert_allclose(gp.variance(p, noise=noise), g[name + '_var' + s], atol=1e-7 * scale ** 2)
+        np.testing.assert_allclose(gp.kernel(p, noise=noise), g[name + '_cov' + s], atol=1e-8)
+        np.testing.assert_allclose(gp.quantiler(p, q=0.975, noise=noise), g[name + '_q975' + s], atol=1e-7 * scale)
+        got = gp.sampler(p, samples=Z.shape[1], noise=noise, rand=Z)
+        np.testing.assert_allclose(got, g[name + '_samples' + s], atol=2e-6 * scale)
+    np.testing.assert_allclose(gp.mean(p, prior=True), g[name + '_prior_mean'], atol=1e-9 * scale)
+    np.testing.assert_allclose(gp.variance(p, prior=True, noise=True), g[name + '_prior_var_n1'], atol=1e-8 * scale ** 2)
+    lpred = gp.logpredictive(p, vector=g[name + '_median_n0'])
+    assert abs(lpred - float(g[name + '_logpred'])) <= 1e-7 * abs(float(g[name + '_logpred']))
+
+
+def test_api_surface_and_dispatch(golden_dir):
+    """names, defaults, method registry and predict() keys of stochastic.py:385-513"""
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'gpmm_se_d1.npz'))
+    X, y, Xs = g['X'], g['y'], g['Xs']
+    gp = g3.GP(space=Xs[:, 0], location=g3.Bias(), kernel=g3.SE(X))     # 1-D space is reshaped to a column
+    assert gp.space.shape == (len(Xs), 1) and not gp.is_observed
+    assert [v.key for v in gp.model.vars] == ['GP_Bias_Bias', 'GP_SE_var_log_', 'GP_SE_rate_log_', 'GP_Noise_var_log_']
+    pr = gp.predict()                                 # unobserved: falls back to the prior (stochastic.py:395-396,475-476)
+    assert set(pr) == {'mean', 'std'} and 'prior_mean' in gp.compiles and 'prior_std' in gp.compiles
+    gp.observed(X, y)
+    d = gp.params_default                            # defaults of kernels.py:33-40, metrics.py:104-108, means.py:133-134
+    assert np.isclose(d['GP_SE_var_log_'], np.log(y.var())) and np.isclose(d['GP_Bias_Bias'], y.mean())
+    assert np.isclose(d['GP_SE_rate_log_'][0], np.log(0.5 / np.abs(X[1:] - X[:-1]).mean()))
+    p = gp.params
+    out = gp.predict(p, var=True, cov=True, median=True, quantiles=True, quantiles_noise=True, samples=3, distribution=True)
+    assert set(out) == {'mean', 'variance', 'std', 'covariance', 'median', 'quantile_up', 'quantile_down',
+                        'noise_std', 'noise_up', 'noise_down', 'samples', 'logpredictive'}
+    assert out.samples.shape == (len(Xs), 3) and np.all(out.quantile_up >= out.quantile_down)
+    assert np.all(out.noise_std >= out.std - 1e-12) and np.isfinite(out.logpredictive(out.mean))
+    for k in ('posterior_mean', 'posterior_std', 'posterior_kernel_sd_noise', 'posterior_location', 'posterior_mapping'):
+        assert k in gp.compiles, k
+    # array=True goes through the dict<->array bijection (models.py:143-155)
+    a = gp.active.dict_to_array(p)
+    assert np.isclose(gp.logp(a, array=True), gp.logp(p)) and 'array_posterior_logp' in gp.compiles
+    assert gp.executed['posterior_logp'] >= 1
+    np.testing.assert_allclose(gp.logp_chain(np.stack([a, a])), [gp.logp(p)] * 2)
+    with pytest.raises(KeyError):
+        gp.logp({'GP_SE_var_log_': 0.0})             # filter_params needs every model variable
+    # prior logp: Flat priors -> 0; FlatExp variables below 1e-6 -> -inf (hypers/__init__.py:199-200)
+    assert gp.logp(p, prior=True) == 0
+    q = dict(p); q['GP_Noise_var_log_'] = np.log(1e-7)
+    assert gp.logp(q) == -np.inf
+    # non-finite observation -> the -1e30 sentinel (gaussian.py:238-241)
+    y2 = y.copy(); y2[3] = np.inf
+    assert gp.logp(p, outputs=y2) == np.float32(-1e30)
+    assert not hasattr(g3.WGP(space=Xs, location=g3.Zero(), kernel=g3.SE(X), mapping=g3.BoxCoxLinear()), 'covariance')
+
+
+def test_jitter_path_through_process():
+    """duplicate inputs without noise make K singular: the reference's jitter schedule rescues it"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(0)
+    X = np.repeat(rng.uniform(0, 3, (40, 1)), 2, axis=0)
+    y = np.sin(X[:, 0])
+    gp = g3.GaussianProcess(space=X, location=g3.Zero(), kernel=g3.SE(X), noisy=False)
+    gp.observed(X, y)
+    p = _params(gp, SE_var=1.0, SE_rate=[1.0])
+    ref = orc.GP(('SE', 1.0, np.array([1.0]), None), None).logp(X, y)
+    got = gp.logp(p)
+    assert gp._cache['stats']['tries'] >= 1
+    assert abs(got - ref) <= 1e-5 * abs(ref)         # identical jitter; rank-deficient => looser tolerance
+
+
+def test_fp32_process_close_to_fp64(golden_dir):
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'gpmm_se_d3.npz'))
+    X, y, Xs = g['X'], g['y'], g['Xs']
+    gp = g3.GaussianProcess(space=Xs, location=g3.Zero(), kernel=g3.SE(X), dtype=np.float32)
+    gp.observed(X, y)
+    p = _params(gp, SE_var=float(g['var']), SE_rate=g['rate'], Noise_var=float(g['noise']))
+    lp = gp.logp(p)
+    assert lp.dtype == np.float32 and abs(lp - float(g['logp'])) <= 1e-4 * abs(float(g['logp']))
+    np.testing.assert_allclose(gp.mean(p), g['mean'], atol=2e-3)

@@ -1,0 +1,119 @@
+"""Full-size checks at BASELINE.json's configurations through size-independent properties,
+plus direct oracle parity where the CPU oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth(N, d, M, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Lbox = N ** (1.0 / d)
+    X = rng.uniform(0, Lbox, (N, d))
+    Xs = rng.uniform(0, Lbox, (M, d))
+    y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.standard_normal(N)
+    return X, y, Xs
+
+
+def _factor(dev, spec, X, y):
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d = X.shape
+    Np = _lib.roundup(N)
+    Xd, dd = dev.upload(X), dev.upload(y)
+    K, a = dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64)
+    st = dev.gp_factor(compile_spec(spec, d), Xd, N, d, dd, K, a)
+    lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
+    return lp, st, K, a, Xd
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import g3py_amd as g3
+    return g3.Device.default()
+
+
+def test_config1_n512_d1(dev):
+    """BASELINE config 1 (N=512, d=1): the reference's own CPU-runnable case"""
+    from oracle import g3_oracle as orc
+    X, y, Xs = _synth(512, 1, 64, 1001)
+    spec = orc.with_noise(('SE', 1.0, np.ones(1), None), 0.1)
+    lp, st, *_ = _factor(dev, spec, X, y)
+    ref = orc.GP(('SE', 1.0, np.ones(1), None), 0.1).logp(X, y)
+    assert abs(lp - ref) <= 1e-8 * abs(ref)
+
+
+def test_config2_n8192_d4_vs_oracle(dev):
+    """BASELINE config 2 (SE fp64, N=8192 d=4): logp, mean, variance against the CPU oracle"""
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d, M = 8192, 4, 256
+    X, y, Xs = _synth(N, d, M, 1002)
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    lp, st, K, a, Xd = _factor(dev, orc.with_noise(spec_f, 0.1), X, y)
+    lp_ref, mean_ref, var_ref, _ = orc.cpu_hot_path(X, y, Xs)
+    assert st['info'] == 0 and abs(lp - lp_ref) <= 1e-8 * abs(lp_ref)
+    Mp, Np = _lib.roundup(M, 128), _lib.roundup(N)
+    V, mu, ss = dev.alloc(Mp, Np, np.float64), dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
+    dev.gp_cross(compile_spec(spec_f, d), dev.upload(Xs), M, Xd, N, d, K, a, V, mu, ss)
+    np.testing.assert_allclose(dev.download(mu, 1, M)[0], mean_ref, atol=1e-8)
+    np.testing.assert_allclose(np.maximum(1.0 - dev.download(ss, 1, M)[0], 0), var_ref, atol=1e-8)
+
+
+def _row(dev, K, i, n):
+    import ctypes as C
+    out = np.empty(n)
+    rc = dev.lib.g3_memcpy_d2h(dev.ctx, out.ctypes.data, K.offset(i), n * 8)
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize('N,d,kind', [(16384, 8, 'mat52+cos'), (32768, 4, 'se')])
+def test_full_size_factor_properties(dev, N, d, kind):
+    """BASELINE configs 3 and 4 on one GPU.  Size-independent properties:
+    (1) L L^T reproduces K on sampled entries, (2) L (L^-1 y) = y round trip,
+    (3) logp is invariant under a permutation of the observations."""
+    from oracle import g3_oracle as orc
+    X, y, _ = _synth(N, d, 8, 1000 + (3 if d == 8 else 4))
+    if kind == 'se':
+        spec_f = ('SE', 1.0, np.ones(d), None)
+    else:
+        spec_f = ('sum', ('MAT52', 1.0, np.ones(d), None), ('COS', 0.5, np.full(d, 0.125), None))
+    spec = orc.with_noise(spec_f, 0.1)
+    lp, st, K, a, Xd = _factor(dev, spec, X, y)
+    assert st['info'] == 0 and st['nonfinite'] == 0 and np.isfinite(lp)
+    rng = np.random.default_rng(0)
+    rows = sorted(rng.choice(N, 12, replace=False))
+    Lrows = {i: np.concatenate([_row(dev, K, i, i + 1), np.zeros(N - i - 1)]) for i in rows}
+    for i in rows:
+        for j in rows:
+            if j > i:
+                continue
+            kij = orc.kernel_cov(spec, X[[i]], None)[0, 0] if i == j else orc.kernel_cov(spec_f, X[[i]], X[[j]])[0, 0]
+            assert abs(Lrows[i][:j + 1].dot(Lrows[j][:j + 1]) - kij) <= 1e-11 * (1 + abs(kij))
+    av = dev.download(a, 1, N)[0]
+    for i in rows:                                   # row i of L times a gives back y_i
+        assert abs(Lrows[i][:i + 1].dot(av[:i + 1]) - y[i]) <= 1e-9
+    if N <= 16384:
+        perm = rng.permutation(N)
+        lp2, *_ = _factor(dev, spec, X[perm], y[perm])
+        assert abs(lp2 - lp) <= 1e-9 * abs(lp)
+
+
+def test_potrf_blocking_invariance(dev, monkeypatch):
+    """the look-ahead panel width must not change the factor beyond rounding"""
+    import scipy.linalg
+    rng = np.random.default_rng(9)
+    n = 4096
+    B = rng.standard_normal((n, 512))
+    K = B @ B.T / 512 + np.eye(n)
+    res = []
+    for nb in ('512', '1024', '4096'):
+        monkeypatch.setenv('G3_NB', nb)
+        Kd = dev.upload(K)
+        assert dev.potrf(Kd, n) == 0
+        res.append(np.tril(dev.download(Kd)))
+    ref = scipy.linalg.cholesky(K, lower=True)
+    for L in res:
+        assert np.abs(L - ref).max() < 1e-11

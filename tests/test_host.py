@@ -1,0 +1,157 @@
+"""CPU tests of the host logic: parameter naming / ordering / defaults, the dict<->array
+bijection, set_space rules, kernel algebra -> g3_kernel_prog lowering.  No GPU calls."""
+import numpy as np
+import pytest
+
+import g3py_amd as g3
+from g3py_amd.device import compile_spec, _expand
+from oracle import g3_oracle as orc
+
+
+def _eval_prog(prog, X1, X2=None):
+    """evaluate a g3_kernel_prog on the CPU with the oracle's leaf formulas (test-only)"""
+    from g3py_amd._lib import KINDS
+    inv = {v: k for k, v in KINDS.items()}
+    n1 = len(X1)
+    n2 = n1 if X2 is None else len(X2)
+    leaf_vals = []
+    for i in range(prog.nleaf):
+        L = prog.leaf[i]
+        kind = inv[L.kind]
+        dims = np.array([L.dims[k] for k in range(L.ndims)])
+        rate = np.array([L.rate[k] for k in range(L.ndims)])
+        freq = np.array([L.freq[k] for k in range(L.ndims)])
+        spec = {'SE': (kind, L.var, rate, dims), 'OU': (kind, L.var, rate, dims), 'MAT32': (kind, L.var, rate, dims),
+                'MAT52': (kind, L.var, rate, dims), 'RQ': (kind, L.var, rate, L.alpha, dims),
+                'COS': (kind, L.var, freq, dims), 'SINC': (kind, L.var, freq, dims),
+                'SIN': (kind, L.var, freq, rate, dims), 'SM': (kind, L.var, freq, rate, dims),
+                'NOISE': (kind, L.var), 'WN': (kind, L.var, dims)}[kind]
+        leaf_vals.append(orc.kernel_cov(spec, X1, X2))
+    out = np.full((n1, n2), prog.shift)
+    for p in range(prog.nprod):
+        t = np.full((n1, n2), prog.prod[p].coef)
+        for f in range(prog.prod[p].nfac):
+            t = t * leaf_vals[prog.prod[p].fac[f]]
+        out = out + t
+    return out
+
+
+def test_sum_of_products_lowering_matches_tree():
+    rng = np.random.default_rng(0)
+    X, X2 = rng.uniform(0, 3, (30, 3)), rng.uniform(0, 3, (11, 3))
+    r, f = np.array([0.6, 1.0, 1.4]), np.array([0.1, 0.2, 0.3])
+    trees = [
+        ('sum', ('SE', 1.3, r, None), ('NOISE', 0.2)),
+        ('prod', ('sum', ('SE', 1.0, r, None), ('OU', 0.5, r, None)), ('shift', 0.5, ('MAT32', 0.7, r, None))),
+        ('shift', 0.1, ('scale', 2.0, ('prod', ('COS', 1.0, f, None), ('SE', 1.0, r[:2], np.array([0, 2]))))),
+        ('prod', ('shift', 1.0, ('SM', 0.4, f, r, None)), ('shift', 2.0, ('RQ', 0.9, r, 1.5, None))),
+    ]
+    for tree in trees:
+        prog = compile_spec(tree, 3)
+        np.testing.assert_allclose(_eval_prog(prog, X), orc.kernel_cov(tree, X), rtol=1e-13)
+        np.testing.assert_allclose(_eval_prog(prog, X2, X), orc.kernel_cov(tree, X2, X), rtol=1e-13)
+
+
+def test_lowering_limits():
+    r = np.ones(2)
+    big = ('SE', 1.0, r, None)
+    for _ in range(9):
+        big = ('sum', big, ('SE', 1.0, r, None))
+    with pytest.raises(g3.G3Error):
+        compile_spec(big, 2)
+    with pytest.raises(g3.G3Error):
+        compile_spec(('SE', 1.0, np.ones(3), np.array([0, 1, 5])), 3)      # column out of range
+    with pytest.raises(g3.G3Error):
+        compile_spec(('SE', 1.0, np.ones(70), None), 70)                   # too many columns
+
+
+def test_parameter_names_order_and_defaults():
+    rng = np.random.default_rng(1)
+    X = rng.uniform(0, 5, (25, 2))
+    y = np.sin(X.sum(1)) + 3.0
+    gp = g3.WGP(space=X, location=g3.Linear(), kernel=g3.MAT52(X) * g3.SIN(X) + g3.RQ(X),
+                mapping=g3.BoxCoxLinear())
+    keys = [v.key for v in gp.model.vars]
+    assert keys == ['WGP_Linear_Constant', 'WGP_Linear_Coeff', 'WGP_MAT52_var_log_', 'WGP_MAT52_rate_log_',
+                    'WGP_SIN_freq_log_', 'WGP_SIN_rate_log_', 'WGP_RQ_var_log_',   # KernelProd fixes k2.var = 1 (kernels.py:217-219)
+                    'WGP_RQ_rate_log_', 'WGP_RQ_alpha_log_', 'WGP_Noise_var_log_', 'WGP_BoxCoxLinear_shift',
+                    'WGP_BoxCoxLinear_scale_log_', 'WGP_BoxCoxLinear_power_log_'], keys
+    assert gp.active.ndim == 1 + 2 + 1 + 2 + 2 + 2 + 1 + 2 + 1 + 1 + 3
+    gp.observed(X, y)
+    d = gp.params_default
+    assert np.isclose(d['WGP_Noise_var_log_'], np.log(y.var()))
+    np.testing.assert_allclose(d['WGP_Linear_Coeff'], y.mean() / X.mean(axis=0))
+    np.testing.assert_allclose(np.exp(d['WGP_SIN_freq_log_']), 1 / (X.max(0) - X.min(0)))
+    assert d['WGP_RQ_alpha_log_'] == 0 and d['WGP_BoxCoxLinear_shift'] == 1
+    # bijection round trip in creation order (models.py:143-155)
+    a = gp.active.dict_to_array(d)
+    assert a.shape == (gp.active.ndim,)
+    back = gp.active.array_to_dict(a)
+    for k in d:
+        np.testing.assert_allclose(back[k], d[k])
+    # natural <-> transformed names
+    nat = gp.transform_params(d, to_transformed=False)
+    assert np.isclose(nat['WGP_Noise_var'], y.var()) and 'WGP_Noise_var_log_' not in nat
+    # set_params / params
+    gp.set_params(d)
+    assert gp.params == d
+    gp.set_params(None)
+    assert set(gp.params_test) == set(keys) and all(np.all(v == 0) for v in gp.params_test.values())
+
+
+def test_set_space_rules_and_copy_semantics():
+    x = np.linspace(0, 1, 7)
+    gp = g3.GP(space=x, location=g3.Zero(), kernel=g3.SE(x[:, None]))
+    assert gp.space.shape == (7, 1) and gp.nspace == 1
+    np.testing.assert_array_equal(gp.order, x)
+    gp.observed(x[:3], np.zeros((3, 1)))
+    assert gp.inputs.shape == (3, 1) and gp.outputs.shape == (3,) and gp.is_observed
+    np.testing.assert_array_equal(gp.index, x[:3])
+    s = gp.space
+    s[0, 0] = 99.0                      # getters return copies (borrow=False, stochastic.py:219-259)
+    assert gp.space[0, 0] == 0.0
+    gp.observed()
+    assert not gp.is_observed
+    x2 = np.random.default_rng(0).uniform(size=(9, 3))
+    gp2 = g3.GP(space=x2, location=g3.Zero(), kernel=g3.SE(x2))
+    assert gp2.nspace == 3 and len(gp2.order) == 9
+
+
+def test_method_registry_names():
+    x = np.linspace(0, 1, 5)[:, None]
+    gp = g3.GP(space=x, location=g3.Zero(), kernel=g3.SE(x))
+    assert set(gp.compiles) == {'posterior_logp', 'array_posterior_logp', 'prior_logp', 'array_prior_logp'}
+    m = gp._compiled('th_kernel_sd', False, True, False, (), {})
+    assert m is gp.compiles['posterior_kernel_sd_noise'] and m.executed == 0
+    for name in ('mean', 'median', 'variance', 'std', 'covariance', 'logpredictive', 'logp', 'loglike', 'location',
+                 'kernel', 'cholesky', 'kernel_diag', 'kernel_sd', 'cholesky_diag', 'mapping', 'mapping_inv',
+                 'quantiler', 'sampler', 'predict'):
+        assert callable(getattr(gp, name)), name
+    assert g3.GP is g3.GaussianProcess and g3.WGP is g3.WarpedGaussianProcess
+
+
+def test_makefn_protocol():
+    calls = []
+    fn = g3.makefn(['v'], lambda s, i, o, v, p: calls.append((s, i, o, v, p)) or 7)
+    assert fn({'a': 1}, 's', 'i', 'o') == 7 and fn.executed == 1
+    c = fn.clone(lambda arr: {'a': arr[0]})
+    assert c({0: 5}.get(0) and [5], 's', 'i', 'o') == 7 and calls[-1][4] == {'a': 5}
+    assert c.executed == 2 and fn.executed == 1          # the clone copies the counter, then counts on its own
+
+
+def test_mappings_and_means_match_oracle():
+    y = np.linspace(0.6, 3.0, 9)
+    vals = {'m_shift': 1.0, 'm_scale': 0.7, 'm_power': 1.2}
+    with g3.Model('t'):
+        m = g3.BoxCoxLinear(name='m')
+        m.check_hypers('')
+    o = orc.Mapping(('BoxCoxLinear', 1.0, 0.7, 1.2))
+    np.testing.assert_allclose(m.inv(y, vals), o.inv(y))
+    np.testing.assert_allclose(m(o.inv(y), vals), y)
+    assert np.isclose(m.logdet_dinv(y, vals), o.logdet_dinv(y))
+    x = np.random.default_rng(0).uniform(size=(6, 2))
+    with g3.Model('t2'):
+        lin = g3.Linear(x, name='L')
+        lin.check_hypers('')
+    np.testing.assert_allclose(lin(x, {'L_Constant': 0.5, 'L_Coeff': np.array([1.0, -2.0])}),
+                               orc.mean_eval(('Linear', 0.5, np.array([1.0, -2.0]), None), x))
