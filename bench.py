@@ -128,13 +128,15 @@ def main():
         Vt = torch.empty((Mp, Np), dtype=torch.float64, device=tdev)
         mut = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
         sst = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
+        Wt_ = torch.empty((Np, 128), dtype=torch.float64, device=tdev)
+        Wd = wrap(Wt_, Np, 128)
         Kd, ad, Vd, mud, ssd = wrap(Kt, Np, Np), wrap(at, 1, Np), wrap(Vt, Mp, Np), wrap(mut, 1, Mp), wrap(sst, 1, Mp)
         prog_n, prog_f = compile_spec(spec_n, d), compile_spec(spec_f, d)
         result = {}
 
         def step():
-            st = dev.gp_factor(prog_n, Xd, N, d, dd, Kd, ad)
-            dev.gp_cross(prog_f, Xsd, M, Xd, N, d, Kd, ad, Vd, mud, ssd)
+            st = dev.gp_factor(prog_n, Xd, N, d, dd, Kd, Wd, ad)
+            dev.gp_cross(prog_f, Xsd, M, Xd, N, d, Kd, Wd, ad, Vd, mud, ssd)
             dev.sync()
             result['logp'] = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
             result['stats'] = st

@@ -469,7 +469,7 @@ __global__ void pad_row_kernel(T* dst, const T* src, int64_t n, int64_t npad, in
 
 extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N,
                             int64_t ldx, int d, const void* delta, g3_dtype dt, void* K, int64_t ldk,
-                            void* a, double out[6]) {
+                            void* invd, void* a, double out[6]) {
   if (!ctx) return -1;
   if (!prog) return -2;
   if (!X) return -3;
@@ -478,9 +478,10 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   if (!K) return -9;
   const int64_t Np = g3_roundup(N, G3_LB);
   if (ldk < Np || ldk % (16 / (int64_t)g3_esize(dt))) return -10;
-  if (!a) return -11;
-  if (!out) return -12;
-  int rc = g3i_ensure_invd(ctx, Np, dt);
+  if (!invd) return -11;
+  if (!a) return -12;
+  if (!out) return -13;
+  int rc = g3i_ensure_invd(ctx, Np, dt);   // sizes the fused diagonal kernel's scratch
   if (rc) return rc;
   const unsigned gflags = G3_GRAM_LOWER | G3_GRAM_SCRUB | G3_GRAM_PAD_EYE;
   // K = tt_to_cov(cov(X))  (elliptical.py:70-71), lower triangle only
@@ -499,7 +500,7 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   int info = 0;
   {
     const int pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0);
-    rc = g3i_potrf(ctx, K, Np, ldk, dt, ctx->invd);
+    rc = g3i_potrf(ctx, K, Np, ldk, dt, invd);
     g3i_prof_end(ctx, pr);
     if (rc) return rc;
     G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -528,7 +529,7 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
       }
       rc = g3_diag_add(ctx, K, N, ldk, dt, lift + dK);
       if (rc) return rc;
-      rc = g3_potrf(ctx, K, Np, ldk, dt, ctx->invd, &info);
+      rc = g3_potrf(ctx, K, Np, ldk, dt, invd, &info);
       if (rc) return rc;
       if (info == 0) { ok = true; break; }
       dK *= c10;
@@ -546,7 +547,7 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
       }
       rc = g3i_reset_info(ctx);
       if (rc) return rc;
-      rc = g3i_trtri_blocks(ctx, K, Np, ldk, dt, ctx->invd);
+      rc = g3i_trtri_blocks(ctx, K, Np, ldk, dt, invd);
       if (rc) return rc;
     }
   }
@@ -566,7 +567,7 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   G3_LAUNCH_CHECK();
   {
     const int pr = g3i_prof_begin(ctx, G3_TAG_TRSV, (double)N * N);
-    rc = g3i_trsm_rlt(ctx, K, Np, ldk, ctx->work, RB, Np, dt, ctx->invd);
+    rc = g3i_trsm_rlt(ctx, K, Np, ldk, ctx->work, RB, Np, dt, invd);
     g3i_prof_end(ctx, pr);
     if (rc) return rc;
   }
@@ -591,8 +592,8 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
 
 extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* Xs, int64_t M,
                            int64_t ldxs, const void* X, int64_t N, int64_t ldx, int d, const void* L,
-                           int64_t ldl, const void* a, g3_dtype dt, void* V, int64_t ldv, void* mu,
-                           void* ss) {
+                           int64_t ldl, const void* invd, const void* a, g3_dtype dt, void* V, int64_t ldv,
+                           void* mu, void* ss) {
   if (!ctx) return -1;
   if (!prog) return -2;
   if (!Xs) return -3;
@@ -605,7 +606,7 @@ extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* 
   if (ldl < Np || ldl % al) return -11;
   if (!V) return -14;
   if (ldv < Np || ldv % al) return -15;
-  if (ctx->invd_bytes < (size_t)(Np / G3_LB) * G3_LB * G3_LB * g3_esize(dt)) return -10;
+  if (!invd) return -12;
   // V = tt_to_num(cov(Xs, X))  (elliptical.py:78-79), then V <- V L^-T
   const double es_d = (double)g3_esize(dt);
   int pr = g3i_prof_begin(ctx, G3_TAG_CROSS_GRAM, (double)(N + M) * d * es_d + (double)N * M * es_d);
@@ -615,7 +616,7 @@ extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* 
   rc = g3i_reset_info(ctx);
   if (rc) return rc;
   pr = g3i_prof_begin(ctx, G3_TAG_TRSM, (double)N * N * M);
-  rc = g3i_trsm_rlt(ctx, L, Np, ldl, V, Mp, ldv, dt, ctx->invd);
+  rc = g3i_trsm_rlt(ctx, L, Np, ldl, V, Mp, ldv, dt, invd);
   g3i_prof_end(ctx, pr);
   if (rc) return rc;
   if (mu || ss) {

@@ -135,7 +135,7 @@ __device__ __forceinline__ void leaf64_sweep(T* A, int64_t ld, T* W, int64_t ldw
     for (int c = 0; c < 2; ++c) {
       const int row = 4 * ti + r, col = 2 * tk + c;
       const T wv = (row >= col) ? w[r][c] : T(0);
-      if (FACTOR) A[(int64_t)row * ld + col] = (row >= col) ? a[r][c] : T(0);
+      if (FACTOR && row >= col) A[(int64_t)row * ld + col] = a[r][c];   // strict upper: never written
       W[(int64_t)row * ldw + col] = wv;
       if (Wt) Wt[(int64_t)col * ldwt + row] = wv;
     }

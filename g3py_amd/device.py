@@ -187,17 +187,21 @@ class Device:
                                      ss.ptr if ss is not None else None)
         _check(self, rc, 'g3_rows_dot_ss')
 
-    def gp_factor(self, prog, X, N, d, delta, K, a):
+    def alloc_inverses(self, Np, dtype):
+        """buffer for the 128 x 128 diagonal-block inverses that belong to one factor"""
+        return self.alloc(Np // _lib.G3_PAD * _lib.G3_PAD, _lib.G3_PAD, dtype)
+
+    def gp_factor(self, prog, X, N, d, delta, K, W, a):
         out = (C.c_double * 6)()
         rc = self.lib.g3_gp_factor(self.ctx, C.byref(prog), X.ptr, N, X.ld, d, delta.ptr,
-                                   _lib.dtype_code(K.dtype), K.ptr, K.ld, a.ptr, out)
+                                   _lib.dtype_code(K.dtype), K.ptr, K.ld, W.ptr, a.ptr, out)
         _check(self, rc, 'g3_gp_factor')
         return dict(logdet=out[0], quad=out[1], nonfinite=out[2], tries=int(out[3]),
                     fallback=bool(out[4]), info=int(out[5]))
 
-    def gp_cross(self, prog, Xs, M, X, N, d, L, a, V, mu, ss):
+    def gp_cross(self, prog, Xs, M, X, N, d, L, W, a, V, mu, ss):
         rc = self.lib.g3_gp_cross(self.ctx, C.byref(prog), Xs.ptr, M, Xs.ld, X.ptr, N, X.ld, d, L.ptr, L.ld,
-                                  a.ptr if a is not None else None, _lib.dtype_code(L.dtype), V.ptr, V.ld,
+                                  W.ptr, a.ptr if a is not None else None, _lib.dtype_code(L.dtype), V.ptr, V.ld,
                                   mu.ptr if mu is not None else None, ss.ptr if ss is not None else None)
         _check(self, rc, 'g3_gp_cross')
 

@@ -101,7 +101,8 @@ class EllipticalProcess(StochasticProcess):
         Xd = dev.upload(X)
         Kd = dev.alloc(Np, Np, self.dtype)
         ad = dev.alloc(1, Np, self.dtype)
-        c = dict(key=key, X=X.copy(), y=y.copy(), N=N, d=d, Np=Np, Xd=Xd, Kd=Kd, ad=ad, mu=mu, det_m=det_m,
+        Wd = dev.alloc_inverses(Np, self.dtype)
+        c = dict(key=key, X=X.copy(), y=y.copy(), N=N, d=d, Np=Np, Xd=Xd, Kd=Kd, Wd=Wd, ad=ad, mu=mu, det_m=det_m,
                  delta=delta, delta_post=mapped_num - mu, stats=None, which=None)
         c['same_delta'] = bool(np.array_equal(c['delta'], c['delta_post']))
         self._cache = c
@@ -116,7 +117,7 @@ class EllipticalProcess(StochasticProcess):
         finite = np.all(np.isfinite(dl))
         dvec = dev.upload(np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
         prog = self._prog(self.f_kernel_noise, values, c['d'])
-        st = dev.gp_factor(prog, c['Xd'], c['N'], c['d'], dvec, c['Kd'], c['ad'])
+        st = dev.gp_factor(prog, c['Xd'], c['N'], c['d'], dvec, c['Kd'], c['Wd'], c['ad'])
         st['delta_finite'] = bool(finite)
         c['stats'], c['which'] = st, which
         return st
@@ -132,7 +133,7 @@ class EllipticalProcess(StochasticProcess):
         mu = dev.alloc(1, Mp, self.dtype)
         ss = dev.alloc(1, Mp, self.dtype)
         kern = self.f_kernel_noise if noise else self.f_kernel
-        dev.gp_cross(self._prog(kern, values, c['d']), Sd, M, c['Xd'], c['N'], c['d'], c['Kd'], c['ad'], V, mu, ss)
+        dev.gp_cross(self._prog(kern, values, c['d']), Sd, M, c['Xd'], c['N'], c['d'], c['Kd'], c['Wd'], c['ad'], V, mu, ss)
         return V, dev.download(mu, 1, M)[0], dev.download(ss, 1, M)[0], M, Mp
 
     def _prior_gram(self, values, space, noise, pad=False):

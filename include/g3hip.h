@@ -197,7 +197,7 @@ int g3_rows_dot_ss(g3_ctx* ctx, const void* V_dev, int64_t m, int64_t n, int64_t
  * [4] = 1 if the 1e-10*I fallback was taken, [5] = potrf info of the first attempt. */
 int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev, int64_t N,
                  int64_t ldx, int d, const void* delta_dev, g3_dtype dt, void* K_dev, int64_t ldk,
-                 void* a_dev, double out_host[6]);
+                 void* invd_dev, void* a_dev, double out_host[6]);
 
 /* Posterior location / variance pieces at M test points given the factor from g3_gp_factor:
  *     V = K(Xs, X) L^-T  (Mpad x Npad, in V_dev, ldv);  mu[i] = V[i,:] . a;  ss[i] = |V[i,:]|^2
@@ -205,7 +205,7 @@ int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev
  * elliptical.py:78-79 -- Noise contributes 0 to a cross block either way). */
 int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_dev, int64_t M,
                 int64_t ldxs, const void* X_dev, int64_t N, int64_t ldx, int d, const void* L_dev,
-                int64_t ldl, const void* a_dev, g3_dtype dt, void* V_dev, int64_t ldv,
+                int64_t ldl, const void* invd_dev, const void* a_dev, g3_dtype dt, void* V_dev, int64_t ldv,
                 void* mu_dev, void* ss_dev);
 
 /* ---- profiling (bench.py's live roofline measurement) -------------------------------------

@@ -21,10 +21,10 @@ def _factor(dev, spec, X, y):
     N, d = X.shape
     Np = _lib.roundup(N)
     Xd, dd = dev.upload(X), dev.upload(y)
-    K, a = dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64)
-    st = dev.gp_factor(compile_spec(spec, d), Xd, N, d, dd, K, a)
+    K, a, W = dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64), dev.alloc_inverses(Np, np.float64)
+    st = dev.gp_factor(compile_spec(spec, d), Xd, N, d, dd, K, W, a)
     lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
-    return lp, st, K, a, Xd
+    return lp, st, (K, W), a, Xd
 
 
 @pytest.fixture(scope='module')
@@ -56,15 +56,15 @@ def test_config2_n8192_d4_vs_oracle(dev):
     assert st['info'] == 0 and abs(lp - lp_ref) <= 1e-8 * abs(lp_ref)
     Mp, Np = _lib.roundup(M, 128), _lib.roundup(N)
     V, mu, ss = dev.alloc(Mp, Np, np.float64), dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
-    dev.gp_cross(compile_spec(spec_f, d), dev.upload(Xs), M, Xd, N, d, K, a, V, mu, ss)
+    dev.gp_cross(compile_spec(spec_f, d), dev.upload(Xs), M, Xd, N, d, K[0], K[1], a, V, mu, ss)
     np.testing.assert_allclose(dev.download(mu, 1, M)[0], mean_ref, atol=1e-8)
     np.testing.assert_allclose(np.maximum(1.0 - dev.download(ss, 1, M)[0], 0), var_ref, atol=1e-8)
 
 
 def _row(dev, K, i, n):
     import ctypes as C
-    out = np.empty(n)
-    rc = dev.lib.g3_memcpy_d2h(dev.ctx, out.ctypes.data, K.offset(i), n * 8)
+    out = np.empty(int(n))
+    rc = dev.lib.g3_memcpy_d2h(dev.ctx, out.ctypes.data, int(K[0].offset(int(i))), int(n) * 8)
     assert rc == 0
     return out
 
