@@ -32,6 +32,19 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, AMD publi
 HBM_PEAK_GBS = 8000.0
 
 
+def _traffic():
+    """HBM bytes per bulk-GEMM launch from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 for gfx950), or None"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+    if not fs:
+        return None
+    try:
+        return float(json.load(open(fs[-1]))['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def synth(N, d, M, seed):
     """SURVEY.md section 8(d)"""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -60,6 +73,10 @@ def cpu_baseline(N, d, M, seed, n_cpu):
         cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
     return dict(value=step_flops(n_cpu, M) / dt / 1e12, unit='TFLOP/s', cores=int(cores), kind='port',
                 sample='one pass of the same workload cut to N=%d (d=%d, M=%d, same generator and seed), '
                        'oracle.cpu_hot_path: NumPy Gram + scipy dpotrf + solve_triangular' % (n_cpu, d, M),
@@ -188,13 +205,17 @@ def main():
         out['phases_ms'] = ph
         if prof['potrf']['count']:
             out['cholesky_tflops'] = prof['potrf']['work'] / (prof['potrf']['ms'] * 1e-3) / 1e12 * (1.0 if world == 1 else 1.0)
-        g = prof['gemm_256x128']
+        g = prof['gemm_bulk']
         if g['count']:
             ach = g['work'] / (g['ms'] * 1e-3) / 1e12
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
-                               'kernel': 'gemm_nt_kernel<double,256,128,64,64>', 'launches_per_step': g['count'] / args.steps,
-                               'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count']}
+                               'frac': ach / FP64_MATRIX_PEAK_TFLOPS, 'traffic': _traffic(),
+                               'kernel': 'gemm_nt_kernel<double,128,128,64,64>, launches with >= 1024 tiles '
+                                         '(bulk panel updates of the blocked Cholesky and of the trsm)',
+                               'launches_per_step': g['count'] / args.steps,
+                               'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],
+                               'note': 'HIP events per launch on the launching stream; launches on the two '
+                                       'look-ahead streams overlap, so summed launch time exceeds wall time'}
         if world == 1 and args.cpu_n > 0:
             cb, lp_cpu = cpu_baseline(N, d, M, seed, min(args.cpu_n, N))
             out['cpu_baseline'] = cb

@@ -76,8 +76,8 @@ _SIGS = {
     'g3_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
-PROF_TAGS = ('gemm_256x128', 'gram', 'potrf', 'trsv', 'cross_gram', 'trsm', 'reduce', 'gemm_128x128',
-             'gemm_64x64', 'leaf64')
+PROF_TAGS = ('gemm_bulk', 'gram', 'potrf', 'trsv', 'cross_gram', 'trsm', 'reduce', 'gemm_mid',
+             'gemm_small', 'diag128')
 
 _lib = None
 

@@ -101,6 +101,7 @@ extern "C" int g3_prof_enable(g3_ctx* ctx, int on) {
     for (int i = 0; i < ctx->prof_cap; ++i) G3_HIP(hipEventCreate(&ctx->prof_ev[i]));
   }
   ctx->prof_on = on != 0;
+  ctx->prof_level = on;
   return G3_OK;
 }
 extern "C" int g3_prof_reset(g3_ctx* ctx) {
@@ -112,6 +113,8 @@ extern "C" int g3_prof_reset(g3_ctx* ctx) {
 }
 int g3i_prof_begin(g3_ctx* ctx, int tag, double work) {
   if (!ctx->prof_on || ctx->prof_n + 2 > ctx->prof_cap) return -1;
+  // level 1 (default): phases and the large GEMM launches only; level 2 adds every small launch
+  if (ctx->prof_level < 2 && (tag == G3_TAG_GEMM_SMALL || tag == G3_TAG_LEAF || tag == G3_TAG_GEMM_MID)) return -1;
   const int r = ctx->prof_nrec++;
   ctx->prof_rec[r].e0 = ctx->prof_n++;
   ctx->prof_rec[r].e1 = ctx->prof_n++;

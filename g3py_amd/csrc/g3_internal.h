@@ -37,6 +37,7 @@ struct g3_ctx {
   size_t work_bytes;
   // optional profiling: HIP-event pairs around tagged regions (g3_prof_*)
   bool prof_on;
+  int prof_level;
   hipEvent_t* prof_ev;
   int prof_cap, prof_n;          // events allocated / used
   struct { int e0, e1, tag; double work; }* prof_rec;

@@ -213,9 +213,10 @@ int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_de
  * the MFMA GEMM (one tag per tile configuration) and around the phases of g3_gp_factor /
  * g3_gp_cross.  g3_prof_collect synchronises and returns, per tag t (G3_PROF_NTAGS of them):
  * out[3t] = number of regions, out[3t+1] = summed milliseconds, out[3t+2] = summed
- * algorithmic work (flops, or bytes for the Gram tags).  Tags: 0 GEMM 256x128 tile,
- * 1 Gram, 2 potrf (whole factorisation), 3 trsv (L^-1 delta), 4 cross Gram, 5 trsm (predict),
- * 6 reductions, 7 GEMM 128x128 tile, 8 GEMM 64x64 tile, 9 leaf kernels. */
+ * algorithmic work (flops, or bytes for the Gram tags).  Tags: 0 MFMA GEMM, 128x128 tile,
+ * launches with >= 1024 tiles (the bulk panel updates), 1 Gram, 2 potrf (whole factorisation),
+ * 3 trsv (L^-1 delta), 4 cross Gram, 5 trsm (predict), 6 reductions; and with on = 2 also
+ * 7 other 128x128-tile GEMM launches, 8 small-tile GEMM launches, 9 fused diagonal-block kernels. */
 #define G3_PROF_NTAGS 10
 int g3_prof_enable(g3_ctx* ctx, int on);
 int g3_prof_reset(g3_ctx* ctx);
