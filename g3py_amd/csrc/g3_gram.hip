@@ -316,7 +316,7 @@ extern "C" int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X1, 
   if (validate_prog(prog, d)) return -2;
   if (!K) return -11;
   if (n1pad < n1) return -13;
-  if (n2pad < n2) return -14;
+  if (n2pad < n2 && !sym) return -14;   // symmetric case: n2pad < n1 limits the columns written
   if (ldk < n2pad) return -12;
   if (!sym && (flags & G3_GRAM_LOWER)) return -15;
   if (n1pad == 0 || n2pad == 0) return G3_OK;

@@ -278,21 +278,26 @@ int g3i_reset_info(g3_ctx* ctx) {
   return G3_OK;
 }
 
-int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt) {
-  size_t need = (size_t)(n / LB) * LB * LB * g3_esize(dt);
-  // scratch of the fused diagonal kernel: W11^T and (L21 W11)^T, one pair per block so the
-  // batched inverse-only launch (g3i_trtri_blocks) can run all blocks at once
-  const size_t wneed = (size_t)(n / LB) * 2 * 64 * 64 * sizeof(double);
-  if (ctx->wscr_bytes < wneed) {
-    if (ctx->wscr) {
-      G3_HIP(hipStreamSynchronize(ctx->stream));
-      G3_HIP(hipFree(ctx->wscr));
-      ctx->wscr = nullptr;
-      ctx->wscr_bytes = 0;
-    }
-    G3_HIP(hipMalloc(&ctx->wscr, wneed));
-    ctx->wscr_bytes = wneed;
+// scratch of the fused diagonal kernel: W11^T and (L21 W11)^T, one pair per block so the batched
+// inverse-only launch (g3i_trtri_blocks) can run all blocks at once
+static int ensure_scratch(g3_ctx* ctx, int64_t n) {
+  const size_t wneed = (size_t)(n / LB > 0 ? n / LB : 1) * 2 * 64 * 64 * sizeof(double);
+  if (ctx->wscr_bytes >= wneed) return G3_OK;
+  if (ctx->wscr) {
+    G3_HIP(hipStreamSynchronize(ctx->stream));
+    G3_HIP(hipFree(ctx->wscr));
+    ctx->wscr = nullptr;
+    ctx->wscr_bytes = 0;
   }
+  G3_HIP(hipMalloc(&ctx->wscr, wneed));
+  ctx->wscr_bytes = wneed;
+  return G3_OK;
+}
+
+int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt) {
+  int rc = ensure_scratch(ctx, n);
+  if (rc) return rc;
+  size_t need = (size_t)(n / LB) * LB * LB * g3_esize(dt);
   if (ctx->invd_bytes >= need) return G3_OK;
   if (ctx->invd) {
     G3_HIP(hipStreamSynchronize(ctx->stream));
@@ -393,6 +398,10 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
 int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd) {
   G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (n == 0) return G3_OK;
+  {
+    int rc0 = ensure_scratch(ctx, LB);   // the factorisation runs one diagonal block at a time
+    if (rc0) return rc0;
+  }
   int64_t NB = ctx->nb_lookahead;
   if (NB <= 0) {
     const char* e = getenv("G3_NB");
@@ -417,6 +426,10 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
 
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd) {
   if (n == 0) return G3_OK;
+  {
+    int rc0 = ensure_scratch(ctx, n);
+    if (rc0) return rc0;
+  }
   const unsigned nb = (unsigned)(n / LB);
   if (dt == G3_F64)
     hipLaunchKernelGGL((diag128_kernel<double, false>), dim3(nb), dim3(LEAF_THREADS), 0, ctx->stream,

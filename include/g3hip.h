@@ -123,7 +123,9 @@ int g3_copy2d(g3_ctx* ctx, void* dst, int64_t ldd, const void* src, int64_t lds,
  * (metrics.py:11-13): K[i][j] = prog(X1[i], X2[j]); X2 == NULL selects the symmetric
  * (square) case, which is what turns on the NOISE / WN diagonal.  The n1 x n2 x d broadcast
  * intermediate of the reference is never formed.  K is (n1pad x n2pad), written for
- * i < n1pad, j < n2pad; entries outside n1 x n2 are 0 (or the identity with PAD_EYE). */
+ * i < n1pad, j < n2pad; entries outside n1 x n2 are 0 (or the identity with PAD_EYE).  In the
+ * symmetric case n2pad may be smaller than n1: only the first n2pad columns are then written (a
+ * block column of the covariance, as the multi-GPU path stores it). */
 int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog_host,
             const void* X1_dev, int64_t n1, int64_t ldx1,
             const void* X2_dev, int64_t n2, int64_t ldx2, int d,
