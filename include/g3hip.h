@@ -149,13 +149,15 @@ int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
                const void* B, int64_t ldb, int64_t m, int64_t n, int64_t k,
                double alpha, double beta, g3_dtype dt, int lower_only);
 
-/* In-place lower Cholesky of the lower triangle of A (n x n, n a multiple of 64; the
+/* In-place lower Cholesky of the lower triangle of A (n x n, n a multiple of 128; the
  * strict upper triangle is neither read nor written).  Replaces the dpotrf call at
- * g3py/libs/tensors.py:198.  Blocked, recursive, right-looking: 64x64 diagonal blocks are
- * factored (and inverted) by one workgroup, panels are solved by GEMM against the block
- * inverses, trailing updates are MFMA SYRK/GEMM.  `invd_dev` (n/64 blocks of 64x64, may be
- * NULL to use the context's own buffer) receives inv(L_kk) for every diagonal block, for
- * reuse by g3_trsm_rlt.  *info_host = 0 or the 1-based index of the first bad pivot. */
+ * g3py/libs/tensors.py:198.  Blocked right-looking sweep over 1024-wide panels with one-panel
+ * look-ahead on two HIP streams (recursive inside a panel): every 128x128 diagonal block is
+ * factored AND inverted by one fused workgroup kernel, panels are solved by in-place GEMM
+ * against the block inverses, trailing updates are MFMA SYRK/GEMM.  `invd_dev` (n/128 blocks
+ * of 128x128, may be NULL to use the context's own buffer) receives inv(L_kk) for every
+ * diagonal block, for reuse by g3_trsm_rlt.  *info_host = 0 or the 1-based index of the first
+ * non-positive (or NaN) pivot. */
 int g3_potrf(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, void* invd_dev,
              int* info_host);
 
@@ -170,7 +172,8 @@ int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void* L_dev, in
 
 /* Solve X * L^T = B in place (B is m x n: each ROW of B is one right-hand side, i.e.
  * B^T <- solve_lower_triangular(L, B^T); tensors.py:265-270, gaussian.py:212).
- * m, n multiples of 64.  invd_dev: block inverses from g3_potrf, or NULL to compute them. */
+ * n a multiple of 128, m a multiple of 128.  invd_dev: block inverses from g3_potrf, or NULL to
+ * compute them from L. */
 int g3_trsm_rlt(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, void* B_dev, int64_t m,
                 int64_t ldb, g3_dtype dt, const void* invd_dev);
 
@@ -193,8 +196,9 @@ int g3_rows_dot_ss(g3_ctx* ctx, const void* V_dev, int64_t m, int64_t n, int64_t
  *     K = tt_to_cov(prog(X, X))   (prog already contains the Noise term, elliptical.py:26-31,70-71)
  *     L = cholesky_robust(K); a = L^-1 delta          (gaussian.py:208-224)
  * X_dev: N x d (row stride ldx), delta_dev: N (= T^-1(y) - m(X), computed by the host layer).
- * K_dev: workspace / output, Npad x Npad with Npad = roundup(N, 64), ld = ldk; on return its
- * lower triangle holds L.  a_dev (Npad) receives L^-1 delta.
+ * K_dev: workspace / output, Npad x Npad with Npad = roundup(N, 128), ld = ldk; on return its
+ * lower triangle holds L.  invd_dev (Npad/128 blocks of 128x128) receives the diagonal-block
+ * inverses that g3_gp_cross needs.  a_dev (Npad) receives L^-1 delta.
  * out_host[0] = sum log L_ii, [1] = a^T a, [2] = #non-finite in a, [3] = jitter tries,
  * [4] = 1 if the 1e-10*I fallback was taken, [5] = potrf info of the first attempt. */
 int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev, int64_t N,
@@ -202,7 +206,8 @@ int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev
                  void* invd_dev, void* a_dev, double out_host[6]);
 
 /* Posterior location / variance pieces at M test points given the factor from g3_gp_factor:
- *     V = K(Xs, X) L^-T  (Mpad x Npad, in V_dev, ldv);  mu[i] = V[i,:] . a;  ss[i] = |V[i,:]|^2
+ *     V = K(Xs, X) L^-T  (Mpad x Npad with Mpad = roundup(M, 128), in V_dev, ldv);
+ *     mu[i] = V[i,:] . a;  ss[i] = |V[i,:]|^2
  * prog_cross: the kernel used for the cross covariance (with or without the Noise term,
  * elliptical.py:78-79 -- Noise contributes 0 to a cross block either way). */
 int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_dev, int64_t M,
