@@ -88,12 +88,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=32768)
-    ap.add_argument('--d', type=int, default=4)
-    ap.add_argument('--m', type=int, default=1024)
+    ap.add_argument('--points', dest='n', type=int, default=32768, help='N observations')
+    ap.add_argument('--dims', dest='d', type=int, default=4, help='input columns d')
+    ap.add_argument('--queries', dest='m', type=int, default=1024, help='M prediction points')
     ap.add_argument('--cpu-n', type=int, default=8192, help='N of the bounded CPU-baseline sample (0 = skip)')
-    ap.add_argument('--no-prof', action='store_true', help='do not record HIP events in the timed region')
-    ap.add_argument('--nb', type=int, default=2048, help='block-column width of the multi-GPU distribution')
+    ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
+    ap.add_argument('--panel', dest='nb', type=int, default=2048, help='block-column width of the multi-GPU distribution')
     args = ap.parse_args()
 
     import torch
@@ -106,9 +106,15 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    # one rank per GPU; G3_DIST_BACKEND=gloo (rehearsal of N>1 on a one-GPU box) lets ranks share a device
+    backend = os.environ.get('G3_DIST_BACKEND', 'nccl')
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
 
     tdev0 = torch.device('cuda', local_rank)

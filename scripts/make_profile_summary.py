@@ -61,7 +61,7 @@ if traffic:
            'correction': 'FETCH_SIZE x2 (gfx950 wide-stream undercount), WRITE_SIZE x1; separate --pmc passes'}
     json.dump(out, open('profiles/%s_traffic.json' % tag, 'w'), indent=1)
     lines += ['', '## HBM traffic of the bulk GEMM launches (PMC, separate passes)', '',
-              '`rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` on `python3 bench.py --steps 1 --warmup 0 --cpu-n 0 --no-prof`.',
+              '`rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` on `python3 bench.py --steps 1 --warmup 0 --cpu-n 0 --skip-events`.',
               'Per launch (average over %d launches): fetch %.3f GB (FETCH_SIZE x 2, gfx950 correction), write %.3f GB.' % (f['launches'], fetch_b / 1e9, write_b / 1e9),
               'Calibration on a known byte count: the Gram kernels wrote %.4f GB by WRITE_SIZE vs %.4f GB expected.' % ((cal or 0) / 1e9, out['gram_write_bytes_expected'] / 1e9)]
 open('profiles/%s_summary.md' % tag, 'w').write('\n'.join(lines) + '\n')
