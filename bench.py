@@ -146,20 +146,20 @@ def main():
     Xd, Xsd, dd = wrap(Xt, N, d), wrap(Xst, M, d), wrap(dt_, 1, N)
 
     if world == 1:
-        Kt = torch.empty((Np, Np), dtype=torch.float64, device=tdev)
+        Kt = torch.empty((Np + 128 + Mp, Np), dtype=torch.float64, device=tdev)   # covariance + right-hand-side rows
         at = torch.empty((1, Np), dtype=torch.float64, device=tdev)
         Vt = torch.empty((Mp, Np), dtype=torch.float64, device=tdev)
         mut = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
         sst = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
         Wt_ = torch.empty((Np, 128), dtype=torch.float64, device=tdev)
         Wd = wrap(Wt_, Np, 128)
-        Kd, ad, Vd, mud, ssd = wrap(Kt, Np, Np), wrap(at, 1, Np), wrap(Vt, Mp, Np), wrap(mut, 1, Mp), wrap(sst, 1, Mp)
+        Kd, ad, Vd, mud, ssd = wrap(Kt, Np + 128 + Mp, Np), wrap(at, 1, Np), wrap(Vt, Mp, Np), wrap(mut, 1, Mp), wrap(sst, 1, Mp)
         prog_n, prog_f = compile_spec(spec_n, d), compile_spec(spec_f, d)
         result = {}
 
         def step():
-            st = dev.gp_factor(prog_n, Xd, N, d, dd, Kd, Wd, ad)
-            dev.gp_cross(prog_f, Xsd, M, Xd, N, d, Kd, Wd, ad, Vd, mud, ssd)
+            # Gram + tall Cholesky: the delta row and the K(Xs, X) rows ride through the factorisation
+            st = dev.gp_factor_predict(prog_n, prog_f, Xd, N, d, dd, Xsd, M, Kd, Wd, ad, mud, ssd)
             dev.sync()
             result['logp'] = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
             result['stats'] = st

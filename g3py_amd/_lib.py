@@ -69,6 +69,8 @@ _SIGS = {
     'g3_rows_dot_ss': ([_P, _P, _I64, _I64, _I64, _P, C.c_int, _P, _P], C.c_int),
     'g3_gp_factor': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, _P, C.c_int, _P, _I64, _P, _P,
                       C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_factor_predict': ([_P, C.POINTER(KernelProg), C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, _P, _P, _I64,
+                              _I64, C.c_int, _P, _I64, _P, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _P], C.c_int),
     'g3_prof_enable': ([_P, C.c_int], C.c_int),

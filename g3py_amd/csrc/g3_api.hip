@@ -463,32 +463,51 @@ extern "C" int g3_rows_dot_ss(g3_ctx* ctx, const void* V, int64_t m, int64_t n, 
 
 // ----------------------------------------------------------------------------- fused path
 template <typename T>
-__global__ void pad_row_kernel(T* dst, const T* src, int64_t n, int64_t npad, int64_t rows) {
-  // dst is rows x npad: row 0 = [src, 0...], other rows 0
+__global__ void pad_row_kernel(T* dst, int64_t ld, const T* src, int64_t n, int64_t npad, int64_t rows) {
+  // dst is rows x npad (row stride ld): row 0 = [src, 0...], other rows 0
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
-  for (int64_t r = 0; r < rows; ++r) dst[r * npad + j] = (r == 0 && j < n) ? src[j] : T(0);
+  for (int64_t r = 0; r < rows; ++r) dst[r * ld + j] = (r == 0 && j < n) ? src[j] : T(0);
 }
 
-extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N,
-                            int64_t ldx, int d, const void* delta, g3_dtype dt, void* K, int64_t ldk,
-                            void* invd, void* a, double out[6]) {
-  if (!ctx) return -1;
-  if (!prog) return -2;
-  if (!X) return -3;
-  if (N <= 0) return -4;
-  if (!delta) return -7;
-  if (!K) return -9;
-  const int64_t Np = g3_roundup(N, G3_LB);
-  if (ldk < Np || ldk % (16 / (int64_t)g3_esize(dt))) return -10;
-  if (!invd) return -11;
-  if (!a) return -12;
-  if (!out) return -13;
+// Shared implementation of g3_gp_factor / g3_gp_factor_predict.  K_dev is a tall buffer:
+//   rows [0, Np)            the covariance, then its factor (lower triangle)
+//   rows [Np, Np+128)       right-hand-side block whose first row is delta -> a = L^-1 delta
+//   rows [Np+128, +Mp)      K(Xs, X) -> V = K(Xs, X) L^-T            (only when M > 0)
+// The right-hand-side rows are carried through the factorisation itself (g3i_potrf_tall): the
+// panel solves and trailing updates that factor K also perform the forward substitutions.
+static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N, int64_t ldx, int d,
+                          const void* delta, g3_dtype dt, void* K, int64_t ldk, void* invd, void* a, double out[6],
+                          const g3_kernel_prog* prog_cross, const void* Xs, int64_t M, int64_t ldxs, void* mu,
+                          void* ss) {
+  const int64_t Np = g3_roundup(N, G3_LB), RB = 128, Mp = M > 0 ? g3_roundup(M, 128) : 0;
+  const int64_t E = RB + Mp;
+  const size_t es = g3_esize(dt);
+  const double es_d = (double)es;
+  char* rhs = (char*)K + (size_t)Np * ldk * es;            // delta block
+  char* Vp = rhs + (size_t)RB * ldk * es;                  // cross-covariance rows
   int rc = g3i_ensure_invd(ctx, Np, dt);   // sizes the fused diagonal kernel's scratch
   if (rc) return rc;
   const unsigned gflags = G3_GRAM_LOWER | G3_GRAM_SCRUB | G3_GRAM_PAD_EYE;
+  auto build_rhs = [&]() -> int {
+    const unsigned nb = (unsigned)((Np + 255) / 256);
+    if (dt == G3_F64)
+      hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)rhs, ldk,
+                         (const double*)delta, N, Np, RB);
+    else
+      hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)rhs, ldk,
+                         (const float*)delta, N, Np, RB);
+    G3_LAUNCH_CHECK();
+    if (M > 0) {
+      // V = tt_to_num(cov(Xs, X))  (elliptical.py:78-79)
+      const int pr = g3i_prof_begin(ctx, G3_TAG_CROSS_GRAM, (double)(N + M) * d * es_d + (double)N * M * es_d);
+      int r = g3_gram(ctx, prog_cross, Xs, M, ldxs, X, N, ldx, d, dt, Vp, ldk, Mp, Np, G3_GRAM_SCRUB);
+      g3i_prof_end(ctx, pr);
+      if (r) return r;
+    }
+    return G3_OK;
+  };
   // K = tt_to_cov(cov(X))  (elliptical.py:70-71), lower triangle only
-  const double es_d = (double)g3_esize(dt);
   auto build = [&]() -> int {
     // algorithmic bytes of the lower-triangle Gram: N d s read + N(N+1)/2 s written
     const int pr = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * d * es_d + 0.5 * (double)N * (N + 1) * es_d);
@@ -496,20 +515,24 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
     if (r) return r;
     r = g3_cov_lift(ctx, K, N, ldk, dt);
     g3i_prof_end(ctx, pr);
-    return r;
+    if (r) return r;
+    return build_rhs();
+  };
+  auto factor = [&](int* info) -> int {
+    const int pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0 + (double)N * N * (1 + M));
+    int r = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, E);
+    g3i_prof_end(ctx, pr);
+    if (r) return r;
+    G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    G3_HIP(hipStreamSynchronize(ctx->stream));
+    *info = *ctx->h_info;
+    return G3_OK;
   };
   rc = build();
   if (rc) return rc;
   int info = 0;
-  {
-    const int pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0);
-    rc = g3i_potrf(ctx, K, Np, ldk, dt, invd);
-    g3i_prof_end(ctx, pr);
-    if (rc) return rc;
-    G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    G3_HIP(hipStreamSynchronize(ctx->stream));
-    info = *ctx->h_info;
-  }
+  rc = factor(&info);
+  if (rc) return rc;
   double tries = 0, fallback = 0;
   const int info0 = info;
   if (info != 0) {
@@ -532,15 +555,14 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
       }
       rc = g3_diag_add(ctx, K, N, ldk, dt, lift + dK);
       if (rc) return rc;
-      rc = g3_potrf(ctx, K, Np, ldk, dt, invd, &info);
+      rc = factor(&info);
       if (rc) return rc;
       if (info == 0) { ok = true; break; }
       dK *= c10;
     }
     if (!ok) {
       fallback = 1;
-      // 1e-10 * I (tensors.py:221); W = 1e10 * I
-      const size_t es = g3_esize(dt);
+      // 1e-10 * I (tensors.py:221); right-hand sides are solved against it separately
       G3_HIP(hipMemset2DAsync(K, (size_t)ldk * es, 0, (size_t)Np * es, (size_t)Np, ctx->stream));
       rc = g3_diag_add(ctx, K, N, ldk, dt, (double)1e-10f);
       if (rc) return rc;
@@ -552,32 +574,19 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
       if (rc) return rc;
       rc = g3i_trtri_blocks(ctx, K, Np, ldk, dt, invd);
       if (rc) return rc;
+      rc = build_rhs();
+      if (rc) return rc;
+      rc = g3i_trsm_rlt(ctx, K, Np, ldk, rhs, E, ldk, dt, invd);
+      if (rc) return rc;
     }
   }
   rc = g3i_reset_info(ctx);
   if (rc) return rc;
-  // a = L^-1 delta as a 64-row right-hand-side block (row 0 carries delta)
-  const int64_t RB = 128;   // rows of the right-hand-side block that carries delta
-  rc = g3i_ensure_work(ctx, (size_t)RB * Np * g3_esize(dt));
-  if (rc) return rc;
-  const unsigned nb = (unsigned)((Np + 255) / 256);
-  if (dt == G3_F64)
-    hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)ctx->work,
-                       (const double*)delta, N, Np, RB);
-  else
-    hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)ctx->work,
-                       (const float*)delta, N, Np, RB);
-  G3_LAUNCH_CHECK();
+  G3_HIP(hipMemcpyAsync(a, rhs, (size_t)Np * es, hipMemcpyDeviceToDevice, ctx->stream));
   {
-    const int pr = g3i_prof_begin(ctx, G3_TAG_TRSV, (double)N * N);
-    rc = g3i_trsm_rlt(ctx, K, Np, ldk, ctx->work, RB, Np, dt, invd);
-    g3i_prof_end(ctx, pr);
-    if (rc) return rc;
-  }
-  G3_HIP(hipMemcpyAsync(a, ctx->work, (size_t)Np * g3_esize(dt), hipMemcpyDeviceToDevice, ctx->stream));
-  {
-    const int pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 0.0);
+    const int pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 2.0 * N * M);
     rc = logp_terms_launch(ctx, K, N, ldk, a, dt);
+    if (!rc && M > 0 && (mu || ss)) rc = rows_dot_ss_launch(ctx, Vp, M, N, ldk, a, dt, mu, ss);
     g3i_prof_end(ctx, pr);
     if (rc) return rc;
   }
@@ -591,6 +600,45 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
   out[4] = fallback;
   out[5] = (double)info0;
   return G3_OK;
+}
+
+extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N,
+                            int64_t ldx, int d, const void* delta, g3_dtype dt, void* K, int64_t ldk,
+                            void* invd, void* a, double out[6]) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!X) return -3;
+  if (N <= 0) return -4;
+  if (!delta) return -7;
+  if (!K) return -9;
+  const int64_t Np = g3_roundup(N, G3_LB);
+  if (ldk < Np || ldk % (16 / (int64_t)g3_esize(dt))) return -10;
+  if (!invd) return -11;
+  if (!a) return -12;
+  if (!out) return -13;
+  return gp_factor_impl(ctx, prog, X, N, ldx, d, delta, dt, K, ldk, invd, a, out, nullptr, nullptr, 0, 0, nullptr,
+                        nullptr);
+}
+
+extern "C" int g3_gp_factor_predict(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross,
+                                    const void* X, int64_t N, int64_t ldx, int d, const void* delta,
+                                    const void* Xs, int64_t M, int64_t ldxs, g3_dtype dt, void* K, int64_t ldk,
+                                    void* invd, void* a, void* mu, void* ss, double out[6]) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!prog_cross) return -3;
+  if (!X) return -4;
+  if (N <= 0) return -5;
+  if (!delta) return -8;
+  if (!Xs) return -9;
+  if (M <= 0) return -10;
+  if (!K) return -13;
+  const int64_t Np = g3_roundup(N, G3_LB);
+  if (ldk < Np || ldk % (16 / (int64_t)g3_esize(dt))) return -14;
+  if (!invd) return -15;
+  if (!a) return -16;
+  if (!out) return -19;
+  return gp_factor_impl(ctx, prog, X, N, ldx, d, delta, dt, K, ldk, invd, a, out, prog_cross, Xs, M, ldxs, mu, ss);
 }
 
 extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* Xs, int64_t M,

@@ -331,7 +331,8 @@ int g3i_ensure_work(g3_ctx* ctx, size_t bytes) {
 // launches: block column k+2 first (its completion event is what stream A waits for before
 // it touches that column), then the rest.
 template <typename T>
-static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t NB, g3_dtype dt) {
+static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t NB, g3_dtype dt, int64_t E) {
+  const int64_t R = n + E;   // rows: the square part plus E appended right-hand-side rows
   const int nblk = (int)((n + NB - 1) / NB);
   if (ctx->la_nev < 2 * nblk) {
     if (ctx->la_ev) {
@@ -356,7 +357,7 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
     T* Akk = A + r(k) * ld + r(k);
     int e = potrf_rec<T>(ctx, Akk, nbk(k), ld, W + (r(k) / LB) * LB * LB, r(k), dt);
     if (e) return e;
-    if (r(k + 1) < n) e = trsm_rec<T>(ctx, Akk, nbk(k), ld, A + r(k + 1) * ld + r(k), n - r(k + 1), ld,
+    if (r(k + 1) < R) e = trsm_rec<T>(ctx, Akk, nbk(k), ld, A + r(k + 1) * ld + r(k), R - r(k + 1), ld,
                                       W + (r(k) / LB) * LB * LB, dt);
     return e;
   };
@@ -369,11 +370,11 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
     G3_HIP(hipStreamWaitEvent(sB, evP[k], 0));
     ctx->stream = sB;
     if (r2 < n) {
-      rc = g3i_gemm_nt(ctx, A + r2 * ld + r2, ld, A + r2 * ld + r0, ld, A + r2 * ld + r0, ld, n - r2, r3 - r2, kk,
+      rc = g3i_gemm_nt(ctx, A + r2 * ld + r2, ld, A + r2 * ld + r0, ld, A + r2 * ld + r0, ld, R - r2, r3 - r2, kk,
                        -1.0, 1.0, dt, 1);
       if (!rc && hipEventRecord(evB[k], sB) != hipSuccess) rc = G3_ERR_HIP;
       if (!rc && r3 < n)
-        rc = g3i_gemm_nt(ctx, A + r3 * ld + r3, ld, A + r3 * ld + r0, ld, A + r3 * ld + r0, ld, n - r3, n - r3, kk,
+        rc = g3i_gemm_nt(ctx, A + r3 * ld + r3, ld, A + r3 * ld + r0, ld, A + r3 * ld + r0, ld, R - r3, n - r3, kk,
                          -1.0, 1.0, dt, 1);
     } else if (hipEventRecord(evB[k], sB) != hipSuccess) {
       rc = G3_ERR_HIP;
@@ -382,7 +383,7 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
     if (rc) return rc;
     // stream A: look-ahead on block column k+1
     if (k >= 1) G3_HIP(hipStreamWaitEvent(sA, evB[k - 1], 0));
-    rc = g3i_gemm_nt(ctx, A + r1 * ld + r1, ld, A + r1 * ld + r0, ld, A + r1 * ld + r0, ld, n - r1, r2 - r1, kk,
+    rc = g3i_gemm_nt(ctx, A + r1 * ld + r1, ld, A + r1 * ld + r0, ld, A + r1 * ld + r0, ld, R - r1, r2 - r1, kk,
                      -1.0, 1.0, dt, 1);
     if (rc) return rc;
     rc = panel(k + 1);
@@ -396,6 +397,13 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
 }
 
 int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd) {
+  return g3i_potrf_tall(ctx, A, n, ld, dt, invd, 0);
+}
+
+// Cholesky of the leading n x n block of a tall (n + E) x n matrix whose last E rows are
+// right-hand sides B: on return those rows hold B L^-T (the forward substitution rides along
+// with the panel solves and trailing updates of the factorisation -- no separate trsm pass).
+int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd, int64_t E) {
   G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (n == 0) return G3_OK;
   {
@@ -409,11 +417,14 @@ int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* in
   }
   NB = g3_roundup(NB < LB ? LB : NB, LB);
   if (n >= 3 * NB) {
-    if (dt == G3_F64) return potrf_lookahead<double>(ctx, (double*)A, n, ld, (double*)invd, NB, dt);
-    return potrf_lookahead<float>(ctx, (float*)A, n, ld, (float*)invd, NB, dt);
+    if (dt == G3_F64) return potrf_lookahead<double>(ctx, (double*)A, n, ld, (double*)invd, NB, dt, E);
+    return potrf_lookahead<float>(ctx, (float*)A, n, ld, (float*)invd, NB, dt, E);
   }
-  if (dt == G3_F64) return potrf_rec<double>(ctx, (double*)A, n, ld, (double*)invd, 0, dt);
-  return potrf_rec<float>(ctx, (float*)A, n, ld, (float*)invd, 0, dt);
+  int rc;
+  if (dt == G3_F64) rc = potrf_rec<double>(ctx, (double*)A, n, ld, (double*)invd, 0, dt);
+  else rc = potrf_rec<float>(ctx, (float*)A, n, ld, (float*)invd, 0, dt);
+  if (rc || E == 0) return rc;
+  return g3i_trsm_rlt(ctx, A, n, ld, (char*)A + (size_t)n * ld * g3_esize(dt), E, ld, dt, invd);
 }
 
 int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,

@@ -192,10 +192,23 @@ class Device:
         return self.alloc(Np // _lib.G3_PAD * _lib.G3_PAD, _lib.G3_PAD, dtype)
 
     def gp_factor(self, prog, X, N, d, delta, K, W, a):
+        """K must have roundup(N) + 128 rows (the trailing block carries delta through the factorisation)"""
+        if K.rows < roundup(N) + _lib.G3_RHS_PAD:
+            raise G3Error('g3_gp_factor needs a K buffer with roundup(N) + 128 rows')
         out = (C.c_double * 6)()
         rc = self.lib.g3_gp_factor(self.ctx, C.byref(prog), X.ptr, N, X.ld, d, delta.ptr,
                                    _lib.dtype_code(K.dtype), K.ptr, K.ld, W.ptr, a.ptr, out)
         _check(self, rc, 'g3_gp_factor')
+        return dict(logdet=out[0], quad=out[1], nonfinite=out[2], tries=int(out[3]),
+                    fallback=bool(out[4]), info=int(out[5]))
+
+    def gp_factor_predict(self, prog, prog_cross, X, N, d, delta, Xs, M, K, W, a, mu, ss):
+        """K must have roundup(N) + 128 + roundup(M, 128) rows"""
+        out = (C.c_double * 6)()
+        rc = self.lib.g3_gp_factor_predict(self.ctx, C.byref(prog), C.byref(prog_cross), X.ptr, N, X.ld, d, delta.ptr,
+                                           Xs.ptr, M, Xs.ld, _lib.dtype_code(K.dtype), K.ptr, K.ld, W.ptr, a.ptr,
+                                           mu.ptr, ss.ptr, out)
+        _check(self, rc, 'g3_gp_factor_predict')
         return dict(logdet=out[0], quad=out[1], nonfinite=out[2], tries=int(out[3]),
                     fallback=bool(out[4]), info=int(out[5]))
 

@@ -99,7 +99,7 @@ class EllipticalProcess(StochasticProcess):
         mapped_num = np.where(np.isnan(mapped), 0, np.where(np.isinf(mapped), self.dtype.type(np.float32(1e10)), mapped))
         Np = _lib.roundup(N)
         Xd = dev.upload(X)
-        Kd = dev.alloc(Np, Np, self.dtype)
+        Kd = dev.alloc(Np + _lib.G3_RHS_PAD, Np, self.dtype)   # + the right-hand-side block that carries delta
         ad = dev.alloc(1, Np, self.dtype)
         Wd = dev.alloc_inverses(Np, self.dtype)
         c = dict(key=key, X=X.copy(), y=y.copy(), N=N, d=d, Np=Np, Xd=Xd, Kd=Kd, Wd=Wd, ad=ad, mu=mu, det_m=det_m,

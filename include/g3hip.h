@@ -196,14 +196,26 @@ int g3_rows_dot_ss(g3_ctx* ctx, const void* V_dev, int64_t m, int64_t n, int64_t
  *     K = tt_to_cov(prog(X, X))   (prog already contains the Noise term, elliptical.py:26-31,70-71)
  *     L = cholesky_robust(K); a = L^-1 delta          (gaussian.py:208-224)
  * X_dev: N x d (row stride ldx), delta_dev: N (= T^-1(y) - m(X), computed by the host layer).
- * K_dev: workspace / output, Npad x Npad with Npad = roundup(N, 128), ld = ldk; on return its
- * lower triangle holds L.  invd_dev (Npad/128 blocks of 128x128) receives the diagonal-block
+ * K_dev: workspace / output, (Npad + 128) x Npad with Npad = roundup(N, 128), ld = ldk; on return
+ * the lower triangle of its first Npad rows holds L; the 128 trailing rows are the right-hand-side
+ * block that carries delta THROUGH the factorisation (the panel solves and trailing updates that
+ * factor K also perform the forward substitution -- there is no separate trsv pass).  invd_dev (Npad/128 blocks of 128x128) receives the diagonal-block
  * inverses that g3_gp_cross needs.  a_dev (Npad) receives L^-1 delta.
  * out_host[0] = sum log L_ii, [1] = a^T a, [2] = #non-finite in a, [3] = jitter tries,
  * [4] = 1 if the 1e-10*I fallback was taken, [5] = potrf info of the first attempt. */
 int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev, int64_t N,
                  int64_t ldx, int d, const void* delta_dev, g3_dtype dt, void* K_dev, int64_t ldk,
                  void* invd_dev, void* a_dev, double out_host[6]);
+
+/* g3_gp_factor plus the posterior pieces of M test points in ONE sweep: K_dev has
+ * Npad + 128 + Mpad rows (Mpad = roundup(M, 128)); rows [Npad+128, +Mpad) receive
+ * V = K(Xs, X) L^-T, carried through the factorisation like the delta row.
+ * mu[i] = V[i,:] . a, ss[i] = |V[i,:]|^2 (mean = m(Xs) + mu, var = diag K** - ss; elliptical.py:81-97).
+ * prog_cross: kernel of the cross covariance (elliptical.py:78-79). */
+int g3_gp_factor_predict(g3_ctx* ctx, const g3_kernel_prog* prog_host, const g3_kernel_prog* prog_cross,
+                         const void* X_dev, int64_t N, int64_t ldx, int d, const void* delta_dev,
+                         const void* Xs_dev, int64_t M, int64_t ldxs, g3_dtype dt, void* K_dev, int64_t ldk,
+                         void* invd_dev, void* a_dev, void* mu_dev, void* ss_dev, double out_host[6]);
 
 /* Posterior location / variance pieces at M test points given the factor from g3_gp_factor:
  *     V = K(Xs, X) L^-T  (Mpad x Npad with Mpad = roundup(M, 128), in V_dev, ldv);

@@ -21,7 +21,7 @@ def _factor(dev, spec, X, y):
     N, d = X.shape
     Np = _lib.roundup(N)
     Xd, dd = dev.upload(X), dev.upload(y)
-    K, a, W = dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64), dev.alloc_inverses(Np, np.float64)
+    K, a, W = dev.alloc(Np + 128, Np, np.float64), dev.alloc(1, Np, np.float64), dev.alloc_inverses(Np, np.float64)
     st = dev.gp_factor(compile_spec(spec, d), Xd, N, d, dd, K, W, a)
     lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
     return lp, st, (K, W), a, Xd
@@ -59,6 +59,16 @@ def test_config2_n8192_d4_vs_oracle(dev):
     dev.gp_cross(compile_spec(spec_f, d), dev.upload(Xs), M, Xd, N, d, K[0], K[1], a, V, mu, ss)
     np.testing.assert_allclose(dev.download(mu, 1, M)[0], mean_ref, atol=1e-8)
     np.testing.assert_allclose(np.maximum(1.0 - dev.download(ss, 1, M)[0], 0), var_ref, atol=1e-8)
+    # fused sweep: the delta row and the K(Xs, X) rows ride through the factorisation
+    K2 = dev.alloc(Np + 128 + Mp, Np, np.float64)
+    W2, a2 = dev.alloc_inverses(Np, np.float64), dev.alloc(1, Np, np.float64)
+    mu2, ss2 = dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
+    st2 = dev.gp_factor_predict(compile_spec(orc.with_noise(spec_f, 0.1), d), compile_spec(spec_f, d), Xd, N, d,
+                                dev.upload(y), dev.upload(Xs), M, K2, W2, a2, mu2, ss2)
+    lp2 = -0.5 * N * np.log(2 * np.pi) - 0.5 * st2['quad'] - st2['logdet']
+    assert abs(lp2 - lp_ref) <= 1e-8 * abs(lp_ref)
+    np.testing.assert_allclose(dev.download(mu2, 1, M)[0], mean_ref, atol=1e-8)
+    np.testing.assert_allclose(np.maximum(1.0 - dev.download(ss2, 1, M)[0], 0), var_ref, atol=1e-8)
 
 
 def _row(dev, K, i, n):
