@@ -138,11 +138,10 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   };
 
   const int frow = lane & 15, kq = lane >> 4, swz = (frow >> 1) & 7;
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int s) {   // s = 0, 1: the two 8-deep halves of a K tile
     const char* a = sA + buf * BM * ROWB + (wm + frow) * ROWB;
     const char* b = sB + buf * BN * ROWB + (wn + frow) * ROWB;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    {
       const int off = (((s * 4 + kq) ^ swz) << 4);
       chunk_t fa[TM], fb[TN];
 #pragma unroll
@@ -165,8 +164,11 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) load_stage((kt + 1) * BK);
-    compute(buf);
+    compute(buf, 0);
+    // the staged tile goes to LDS between the two halves: its write latency hides under the
+    // second half's MFMAs instead of sitting in front of the barrier
     if (kt + 1 < KT) store_stage(buf ^ 1);
+    compute(buf, 1);
     __syncthreads();
   }
 
