@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libg3hip.so')
 
-G3_MAXD, G3_MAXCOLS, G3_MAXLEAF, G3_MAXPROD, G3_MAXFAC = 32, 60, 8, 16, 4
+G3_MAXD, G3_MAXCOLS, G3_MAXLEAF, G3_MAXPROD, G3_MAXFAC = 32, 40, 8, 16, 4
 G3_F64, G3_F32 = 0, 1
 G3_GRAM_LOWER, G3_GRAM_SCRUB, G3_GRAM_PAD_EYE = 1, 2, 4
 G3_PAD = 128       # matrices are padded to a multiple of the panel block (G3_LB in the library)

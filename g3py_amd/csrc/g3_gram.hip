@@ -134,13 +134,31 @@ struct SeParams {
   T var, noise;
 };
 
+// One workgroup (256 threads) writes a 64-row x 128-column tile; a thread owns two adjacent
+// columns (one 16-byte store per row for fp64: a wave writes 1 KiB of one row per instruction)
+// and every fourth row.
+#define GTN 128
 template <typename T, int D, bool SE_FAST>
 __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
             int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
             T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym) {
-  const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
-  if ((flags & G3_GRAM_LOWER) && j0 > i0) return;
+  int64_t bi = blockIdx.y, bj = blockIdx.x;
+  if (flags & G3_GRAM_LOWER) {
+    // 1-D grid over the tiles on or below the diagonal only: row-block b has b/2 + 1 column
+    // tiles (64-row, 128-column tiles), prefix q(q+1) + r(q+1) for b = 2q + r
+    const int64_t id = blockIdx.x;
+    int64_t q = (int64_t)((sqrt(1.0 + 4.0 * (double)id) - 1.0) * 0.5);
+    while ((q + 1) * (q + 2) <= id) ++q;
+    while (q * (q + 1) > id) --q;
+    int64_t rem = id - q * (q + 1);
+    const int64_t r = rem >= q + 1 ? 1 : 0;
+    if (r) rem -= q + 1;
+    bi = 2 * q + r;
+    bj = rem;
+  }
+  const int64_t i0 = bi * GT, j0 = bj * GTN;
+  if (i0 >= n1pad || j0 >= n2pad) return;
   extern __shared__ __attribute__((aligned(16))) char smem_g[];
   const int dp = d | 1;  // odd row stride: conflict-free column-varying reads
   T* xi_s = reinterpret_cast<T*>(smem_g);
@@ -149,45 +167,62 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
   for (int e = tid; e < GT * d; e += 256) {
     const int r = e / d, c = e - r * d;
     xi_s[r * dp + c] = (i0 + r < n1) ? X1[(i0 + r) * ldx1 + c] : T(0);
+  }
+  for (int e = tid; e < GTN * d; e += 256) {
+    const int r = e / d, c = e - r * d;
     xj_s[r * dp + c] = (j0 + r < n2) ? X2[(j0 + r) * ldx2 + c] : T(0);
   }
   __syncthreads();
-  const int tx = tid & 63, ty = tid >> 6;  // column within tile, row phase
-  const int64_t j = j0 + tx;
-  if (j >= n2pad) return;
-  const T* xj = xj_s + tx * dp;
-  T xjr[D];
+  const int tx = tid & 63, ty = tid >> 6;  // column pair within tile, row phase
+  const int64_t ja = j0 + 2 * tx;
+  if (ja >= n2pad) return;
+  const bool two = (ja + 1 < n2pad);
+  const T* xja = xj_s + (2 * tx) * dp;
+  const T* xjb = xja + dp;
+  T xra[D], xrb[D];
   if (SE_FAST) {
 #pragma unroll
-    for (int c = 0; c < D; ++c) xjr[c] = xj[c];
+    for (int c = 0; c < D; ++c) { xra[c] = xja[c]; xrb[c] = xjb[c]; }
   }
   const bool scr = (flags & G3_GRAM_SCRUB) != 0;
   const bool eye = (flags & G3_GRAM_PAD_EYE) != 0;
+  const bool vec_ok = two && ((ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(K) & (2 * sizeof(T) - 1)) == 0);
 #pragma unroll 4
   for (int rr = ty; rr < GT; rr += 4) {
     const int64_t i = i0 + rr;
     if (i >= n1pad) break;
-    T v;
-    if (i < n1 && j < n2) {
-      const bool dg = sym && (i == j);
-      if (SE_FAST) {
-        const T* xi = xi_s + rr * dp;
-        T dd = T(0);
+    T v[2];
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-          const T dx = xi[c] - xjr[c];
-          dd += (dx * dx) * se.w[c];
+    for (int q = 0; q < 2; ++q) {
+      const int64_t j = ja + q;
+      if (i < n1 && j < n2) {
+        const bool dg = sym && (i == j);
+        if (SE_FAST) {
+          const T* xi = xi_s + rr * dp;
+          T dd = T(0);
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            const T dx = xi[c] - (q ? xrb[c] : xra[c]);
+            dd += (dx * dx) * se.w[c];
+          }
+          v[q] = se.var * exp(-dd);
+          if (dg) v[q] += se.noise;
+        } else {
+          v[q] = prog_eval<T>(prog, xi_s + rr * dp, q ? xjb : xja, dg, sym != 0);
         }
-        v = se.var * exp(-dd);
-        if (dg) v += se.noise;
+        if (scr) v[q] = scrub(v[q]);
       } else {
-        v = prog_eval<T>(prog, xi_s + rr * dp, xj, dg, sym != 0);
+        v[q] = (eye && i == j) ? T(1) : T(0);
       }
-      if (scr) v = scrub(v);
-    } else {
-      v = (eye && i == j) ? T(1) : T(0);
     }
-    K[i * ldk + j] = v;
+    T* p = K + i * ldk + ja;
+    if (vec_ok) {
+      typedef T vec2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<vec2*>(p) = vec2{v[0], v[1]};
+    } else {
+      p[0] = v[0];
+      if (two) p[1] = v[1];
+    }
   }
 }
 
@@ -232,6 +267,15 @@ static int validate_prog(const g3_kernel_prog* p, int d) {
   return 0;
 }
 
+static dim3 gram_grid(int64_t n1pad, int64_t n2pad, unsigned flags) {
+  const int64_t tr = (n1pad + GT - 1) / GT, tc = (n2pad + GTN - 1) / GTN;
+  if (flags & G3_GRAM_LOWER) {   // tiles on or below the diagonal: sum_b (b/2 + 1), b < tr
+    const int64_t q = tr / 2, r = tr % 2;
+    return dim3((unsigned)(q * (q + 1) + r * (q + 1)));
+  }
+  return dim3((unsigned)tc, (unsigned)tr);
+}
+
 // recognise  var*SE(x[:, 0:d]) (+ Noise)  so the common case takes the register fast path
 template <typename T, int D>
 static bool match_se(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
@@ -266,8 +310,8 @@ template <typename T, int D>
 static int launch_gram_fast(g3_ctx* ctx, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
                             const T* X2, int64_t n2, int64_t ldx2, T* K, int64_t ldk, int64_t n1pad,
                             int64_t n2pad, unsigned flags, int sym) {
-  dim3 grid((unsigned)((n2pad + GT - 1) / GT), (unsigned)((n1pad + GT - 1) / GT));
-  const size_t lds = 2 * GT * (D | 1) * sizeof(T);
+  dim3 grid = gram_grid(n1pad, n2pad, flags);
+  const size_t lds = (GT + GTN) * (D | 1) * sizeof(T);
   hipLaunchKernelGGL((gram_kernel<T, D, true>), grid, dim3(256), lds, ctx->stream,
                      (const g3_kernel_prog*)nullptr, se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad,
                      n2pad, flags, sym);
@@ -291,8 +335,8 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   const g3_kernel_prog* dprog;
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
   if (rc) return rc;
-  dim3 grid((unsigned)((n2pad + GT - 1) / GT), (unsigned)((n1pad + GT - 1) / GT));
-  const size_t lds = 2 * GT * (d | 1) * sizeof(T);
+  dim3 grid = gram_grid(n1pad, n2pad, flags);
+  const size_t lds = (GT + GTN) * (d | 1) * sizeof(T);
   SeParams<T, 1> dummy{};
   hipLaunchKernelGGL((gram_kernel<T, 1, false>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
                      ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym);

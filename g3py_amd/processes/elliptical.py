@@ -50,6 +50,9 @@ class EllipticalProcess(StochasticProcess):
         self.f_location.check_hypers(self.name + '_')
         self.f_kernel_noise.check_hypers(self.name + '_')
         self.f_mapping.check_hypers(self.name + '_')
+        self.f_location.check_potential()
+        self.f_kernel_noise.check_potential()
+        self.f_mapping.check_potential()
 
     def default_hypers(self):
         x, y = self.inputs, self.outputs
@@ -70,6 +73,12 @@ class EllipticalProcess(StochasticProcess):
                 values[v.name] = e
             else:
                 values[v.name] = p
+        # optional L1 / L2 potentials enter th_logp like pm.Potential terms (stochastic.py:305)
+        for _, reg, c, sel in self.model.potentials:
+            if reg == 'L1':
+                logjac += c * -float(sum(np.sum(np.abs(values[h.name])) for h in sel))
+            elif reg == 'L2':
+                logjac += c * -float(sum(np.sum(np.asarray(values[h.name]) ** 2) for h in sel))
         return values, logjac
 
     def _x(self, a):
@@ -122,7 +131,7 @@ class EllipticalProcess(StochasticProcess):
         c['stats'], c['which'] = st, which
         return st
 
-    def _cross(self, c, values, space, noise):
+    def _cross(self, c, values, space, noise, kernel=None):
         """V = K(space, X) L^-T, mu = V a, ss = |V_i|^2 (elliptical.py:78-91)"""
         dev = self.device
         S = self._x(space)
@@ -132,7 +141,7 @@ class EllipticalProcess(StochasticProcess):
         V = dev.alloc(Mp, c['Np'], self.dtype)
         mu = dev.alloc(1, Mp, self.dtype)
         ss = dev.alloc(1, Mp, self.dtype)
-        kern = self.f_kernel_noise if noise else self.f_kernel
+        kern = kernel if kernel is not None else (self.f_kernel_noise if noise else self.f_kernel)
         dev.gp_cross(self._prog(kern, values, c['d']), Sd, M, c['Xd'], c['N'], c['d'], c['Kd'], c['Wd'], c['ad'], V, mu, ss)
         return V, dev.download(mu, 1, M)[0], dev.download(ss, 1, M)[0], M, Mp
 
@@ -193,6 +202,17 @@ class EllipticalProcess(StochasticProcess):
         self._solve(c, values, 'post')
         _, mu, _, _, _ = self._cross(c, values, space, noise)
         return loc + mu                                                   # elliptical.py:81-84
+
+    def th_cross_mean(self, space, inputs, outputs, vector, params, prior=False, noise=False, cross_kernel=None):
+        """location of one process given another through a cross kernel (gaussian.py:99-112)"""
+        values, _ = self._values(params)
+        loc = self.f_location(self._x(space), values)
+        if prior:
+            return loc
+        c = self._factor(values, inputs, outputs)
+        self._solve(c, values, 'post')
+        _, mu, _, _, _ = self._cross(c, values, space, False, kernel=cross_kernel)
+        return loc + mu
 
     def th_kernel(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         values, _ = self._values(params)
@@ -269,4 +289,4 @@ class EllipticalProcess(StochasticProcess):
                 ('loglike', 'th_loglike'), ('mapping', 'th_mapping'), ('mapping_inv', 'th_mapping_inv'),
                 ('location', 'th_location'), ('kernel', 'th_kernel'), ('cholesky', 'th_cholesky'),
                 ('kernel_diag', 'th_kernel_diag'), ('kernel_sd', 'th_kernel_sd'),
-                ('cholesky_diag', 'th_cholesky_diag'))
+                ('cholesky_diag', 'th_cholesky_diag'), ('cross_mean', 'th_cross_mean'))

@@ -41,6 +41,7 @@ class Model:
     def __init__(self, name=''):
         self.name = name
         self.vars = []
+        self.potentials = []   # (name, 'L1'|'L2', c, [HyperVar]) -- pm.Potential stand-ins
 
     def __enter__(self):
         _MODEL_STACK.append(self)
@@ -135,8 +136,21 @@ class Hypers:
     def default_hypers_dims(self, x=None, y=None):
         return dict(self.default_hypers(x[:, self.dims], y))
 
+    def set_potential(self, hypers='', reg='L1', c=1):
+        """optional L1 / L2 regulariser on the hypers whose name contains `hypers`
+        (hypers/__init__.py:94-95)"""
+        self.potential = (hypers, reg, c)
+
     def check_potential(self):
-        return None
+        """register the potential with the active model (hypers/__init__.py:97-109); the value
+        is c * (-sum |h|) or c * (-sum h^2) over the NATURAL-space hypers selected by name"""
+        if getattr(self, 'potential', None) is None:
+            return None
+        hypers, reg, c = self.potential
+        sel = [k for k in self.hypers if isinstance(k, HyperVar) and k.name.find(hypers) > 0]
+        pot = (self.name + '_' + hypers + '_' + reg, reg, float(c), sel)
+        modelcontext().potentials.append(pot)
+        return pot
 
     @staticmethod
     def Flat(name, shape=()):

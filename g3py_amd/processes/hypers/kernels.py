@@ -124,6 +124,10 @@ class KernelOperation(Kernel):
     def default_hypers_dims(self, x=None, y=None):
         return self.k.default_hypers_dims(x, y)
 
+    def check_potential(self):
+        super().check_potential()
+        self.k.check_potential()
+
     @property
     def name(self):
         return str(self.element) + " " + self.op + " " + self.k.name
@@ -152,6 +156,11 @@ class KernelComposition(Kernel):
 
     def default_hypers_dims(self, x=None, y=None):
         return {**self.k1.default_hypers_dims(x, y), **self.k2.default_hypers_dims(x, y)}
+
+    def check_potential(self):
+        super().check_potential()
+        self.k1.check_potential()
+        self.k2.check_potential()
 
     @property
     def name(self):

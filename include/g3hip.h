@@ -51,7 +51,7 @@ typedef enum { G3_F64 = 0, G3_F32 = 1 } g3_dtype;
  * hyper-parameters are in NATURAL space (the host applies exp() to `*_log_` values).
  */
 #define G3_MAXD 32     /* max columns one leaf may use            */
-#define G3_MAXCOLS 60  /* max columns d of the N x d input        */
+#define G3_MAXCOLS 40  /* max columns d of the N x d input        */
 #define G3_MAXLEAF 8   /* max distinct leaves in one program      */
 #define G3_MAXPROD 16  /* max product terms                       */
 #define G3_MAXFAC 4    /* max factors in one product term         */

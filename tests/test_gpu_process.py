@@ -160,3 +160,39 @@ def test_fp32_process_close_to_fp64(golden_dir):
     lp = gp.logp(p)
     assert lp.dtype == np.float32 and abs(lp - float(g['logp'])) <= 1e-4 * abs(float(g['logp']))
     np.testing.assert_allclose(gp.mean(p), g['mean'], atol=2e-3)
+
+
+def test_cross_mean_and_wgp_fp32_draws():
+    """th_cross_mean (gaussian.py:99-112) and a float32 warped GP with posterior draws (the shape of
+    BASELINE config 5, at a size the CPU oracle handles)"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(12)
+    N, d, M = 1500, 16, 96
+    X = rng.uniform(0, N ** (1 / d), (N, d))
+    Xs = rng.uniform(0, N ** (1 / d), (M, d))
+    f = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.standard_normal(N)
+    y = f - f.min() + 1.0
+    r = np.ones(d)
+    gp = g3.GaussianProcess(space=Xs, location=g3.Zero(), kernel=g3.SE(X))
+    gp.observed(X, y)
+    p = _params(gp, SE_var=1.0, SE_rate=r, Noise_var=0.1)
+    ref = orc.GP(('SE', 1.0, r, None), 0.1)
+    np.testing.assert_allclose(gp.cross_mean(p), ref.mean(Xs, X, y), atol=1e-8)
+    k2 = g3.OU(X, var=0.7, metric=g3.ARD_L1(X, rate=r))
+    got = gp.cross_mean(p, cross_kernel=k2)
+    K = ref.prior_kernel(X, True)
+    want = orc.kernel_cov(('OU', 0.7, r, None), Xs, X).dot(np.linalg.solve(K, y))
+    np.testing.assert_allclose(got, want, atol=1e-8)
+    # float32 warped GP with draws
+    wgp = g3.WGP(space=Xs, location=g3.Zero(), kernel=g3.SE(X), mapping=g3.BoxCoxLinear(), dtype=np.float32)
+    wgp.observed(X, y)
+    pw = _params(wgp, SE_var=1.0, SE_rate=r, Noise_var=0.1, BoxCoxLinear_shift=1.0, BoxCoxLinear_scale=1.0,
+                 BoxCoxLinear_power=1.2)
+    o = orc.GP(('SE', 1.0, r, None), 0.1, mapping=('BoxCoxLinear', 1.0, 1.0, 1.2))
+    lp = wgp.logp(pw)
+    assert lp.dtype == np.float32 and abs(lp - o.logp(X, y)) <= 1e-4 * abs(o.logp(X, y))
+    np.testing.assert_allclose(wgp.mean(pw), o.mean(Xs, X, y), rtol=2e-3, atol=2e-3)
+    Z = rng.standard_normal((M, 4))
+    draws = wgp.sampler(pw, samples=4, rand=Z)
+    np.testing.assert_allclose(draws, o.sampler(Xs, X, y, Z), rtol=5e-3, atol=5e-3)

@@ -155,3 +155,17 @@ def test_mappings_and_means_match_oracle():
         lin.check_hypers('')
     np.testing.assert_allclose(lin(x, {'L_Constant': 0.5, 'L_Coeff': np.array([1.0, -2.0])}),
                                orc.mean_eval(('Linear', 0.5, np.array([1.0, -2.0]), None), x))
+
+
+def test_potentials_enter_logp_prior():
+    """optional L1 / L2 regularisers (hypers/__init__.py:94-109) are added to th_logp like pm.Potential"""
+    x = np.linspace(0, 1, 6)[:, None]
+    k = g3.SE(x)
+    k.set_potential('var', 'L1', c=2.0)
+    gp = g3.GP(space=x, location=g3.Zero(), kernel=k)
+    assert len(gp.model.potentials) == 1
+    p = gp.params_test
+    p['GP_SE_var_log_'] = np.log(3.0)
+    values, extra = gp._values(p)
+    assert np.isclose(extra, -2.0 * 3.0)
+    assert np.isclose(gp.th_logp(None, None, None, [], p, prior=True), -6.0)
