@@ -14,8 +14,10 @@
 //     ds_read_b128 and feeds its elements to consecutive MFMAs.
 //   * LDS tiles are [row][128 bytes] with the 16-byte chunk index XOR-swizzled by
 //     (row >> 1) & 7, which makes every ds_read_b128 lane group hit 64 distinct banks.
-//   * Global -> register -> LDS staging, double-buffered, one barrier per K tile; the
-//     f64 MFMA is 64 cycles per instruction, so the loop is matrix-pipe bound.
+//   * Global -> LDS by LDS-DMA (global_load_lds_dwordx4, swizzle applied on the source
+//     address), double-buffered, one barrier per K tile; the f64 MFMA is 64 cycles per
+//     instruction, so the loop is matrix-pipe bound (ablation: register staging + ds_write
+//     cost 6-9 % of the MFMA rate).
 #include "g3_internal.h"
 #include <stdlib.h>
 
@@ -105,35 +107,32 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-  // staging assignment: chunk c of row r  <-  idx = tid + i * NT
-  chunk_t ra[CA], rb[CB];
+  // ---- staging: LDS-DMA (global_load_lds_dwordx4).  One wave-instruction moves 64 x 16 B =
+  // 8 rows x 128 B straight from global memory into LDS (no VGPR round trip, no ds_write).
+  // The LDS destination is linear (wave-uniform base + lane * 16), so the XOR swizzle is
+  // applied to the per-lane SOURCE address: physical chunk c of row r receives logical chunk
+  // c ^ ((r >> 1) & 7), which is what the fragment reads below expect.
+  constexpr int NW = NT / 64;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "rows per wave-instruction");
   const T* gA = A + (int64_t)m0 * lda;
   const T* gB = B + (int64_t)n0 * ldb;
-
-  auto load_stage = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
-      ra[i] = *reinterpret_cast<const chunk_t*>(gA + (int64_t)r * lda + k0 + c * EPC);
-    }
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
-      rb[i] = *reinterpret_cast<const chunk_t*>(gB + (int64_t)r * ldb + k0 + c * EPC);
-    }
-  };
-  auto store_stage = [&](int buf) {
+  const int sr = lane >> 3, sc = lane & 7;
+  auto stage = [&](int buf, int k0) {
     char* a = sA + buf * BM * ROWB;
     char* b = sB + buf * BN * ROWB;
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
-      *reinterpret_cast<chunk_t*>(a + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4)) = ra[i];
+    for (int i = 0; i < BM / 8 / NW; ++i) {
+      const int rb = (i * NW + wave) * 8, row = rb + sr;
+      const T* src = gA + (int64_t)row * lda + k0 + ((sc ^ ((row >> 1) & 7)) * EPC);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(a + rb * ROWB), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      int idx = tid + i * NT, r = idx >> 3, c = idx & 7;
-      *reinterpret_cast<chunk_t*>(b + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4)) = rb[i];
+    for (int i = 0; i < BN / 8 / NW; ++i) {
+      const int rb = (i * NW + wave) * 8, row = rb + sr;
+      const T* src = gB + (int64_t)row * ldb + k0 + ((sc ^ ((row >> 1) & 7)) * EPC);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(b + rb * ROWB), 16, 0, 0);
     }
   };
 
@@ -157,18 +156,19 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     }
   };
 
+  // two LDS buffers: the DMA of tile kt+1 is in flight during all 64 MFMAs of tile kt; the
+  // vmcnt(0) + barrier at the end of an iteration both publishes tile kt+1 and guarantees
+  // everyone has finished reading the buffer the next DMA will overwrite
   const int KT = K / BK;
-  load_stage(0);
-  store_stage(0);
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) load_stage((kt + 1) * BK);
+    if (kt + 1 < KT) stage(buf ^ 1, (kt + 1) * BK);
     compute(buf, 0);
-    // the staged tile goes to LDS between the two halves: its write latency hides under the
-    // second half's MFMAs instead of sitting in front of the barrier
-    if (kt + 1 < KT) store_stage(buf ^ 1);
     compute(buf, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
