@@ -253,19 +253,23 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   if (forced == 3) return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
   if (forced == 4 && n % 128 == 0)
     return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  // (the 256 x 128 tile, one block per CU, measured 4-5 % slower than 128 x 128 at two blocks
-  //  per CU on every large shape once the raster keeps operands in L2; kept for experiments)
-  if (n % 128 == 0 && m % 32 == 0 && blocks128 < 128 && (wide || (m / 64) * (n / 64) < 128))
-    // few tiles: thin 32 x 128 tiles spread a small problem over more CUs (one f64 tile of
-    // 128 x 128 keeps a single CU busy for ~2 us per 16-deep K step)
-    return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  if (m % 128 == 0 && n % 128 == 0 && (blocks128 >= 96 || wide))
-    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  if (wide) {  // the caller aliases C with A and needs one tile to span 128 output columns
-    snprintf(ctx->err, sizeof(ctx->err), "in-place panel GEMM needs m, n multiples of 128 (m=%lld n=%lld)",
+  // Tile choice (measured on MI355X, scripts/gemm_bench.py):
+  //  * in-place panel solves (`wide`, C aliases A, n = 128): thin 32 x 128 tiles always -- one
+  //    tile must span the 128 output columns, and 4x more workgroups beat 128 x 128 tiles from
+  //    m = 1024 (13 vs 32 us) to m = 31744 (34 vs 45 us);
+  //  * >= 4096 tiles of 128 x 128: the big tile (two blocks per CU, 65-68 TFLOP/s);
+  //  * everything in between: 64 x 64 tiles -- finer work quanta balance better over the 256 CUs
+  //    (lower SYRK 4096^2 x 1024: 51 vs 40 TFLOP/s; 2048 x 1024 x 1024: 50 vs 27).
+  // (a 256 x 128 tile, one block per CU, was 4-5 % slower than 128 x 128 everywhere.)
+  if (wide) {
+    if (n % 128 == 0 && m % 32 == 0)
+      return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+    snprintf(ctx->err, sizeof(ctx->err), "in-place panel GEMM needs n %% 128 == 0 and m %% 32 == 0 (m=%lld n=%lld)",
              (long long)m, (long long)n);
     return G3_ERR_HIP;
   }
+  if (m % 128 == 0 && n % 128 == 0 && blocks128 >= 4096)
+    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
   return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
 }
 
