@@ -93,7 +93,7 @@ def main():
     ap.add_argument('--queries', dest='m', type=int, default=1024, help='M prediction points')
     ap.add_argument('--cpu-n', type=int, default=8192, help='N of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
-    ap.add_argument('--panel', dest='nb', type=int, default=2048, help='block-column width of the multi-GPU distribution')
+    ap.add_argument('--panel', dest='nb', type=int, default=1024, help='block-column width of the multi-GPU distribution')
     args = ap.parse_args()
 
     import torch

@@ -223,10 +223,13 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
     }
   }
   dim3 grid((unsigned)nv);
-  // algorithmic flops: 2 m n k, or m n k when only the lower triangle is wanted.  Profiling
+  // algorithmic flops: 2 k per output element that is wanted.  Profiling
   // tag: launches of the 128 x 128 tile with >= 1024 tiles are the bulk panel updates
   const int tag = (BM == 128 && BN == 128) ? (nv >= 1024 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
-  const int pr = g3i_prof_begin(ctx, tag, (lower_only ? 1.0 : 2.0) * (double)m * (double)n * (double)k);
+  // lower-only: 2k flops for every element on or below the diagonal (m >= n: m n - n(n-1)/2 of them)
+  const double elems = lower_only ? ((double)m * n - 0.5 * (double)n * (n - 1) - (m < n ? 0.5 * (double)(n - m) * (n - m + 1) : 0.0))
+                                  : (double)m * n;
+  const int pr = g3i_prof_begin(ctx, tag, 2.0 * elems * (double)k);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, ctx->stream, (T*)C, ldc, (const T*)A, lda,
                      (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info, tiles_m, tiles_n);
   g3i_prof_end(ctx, pr);

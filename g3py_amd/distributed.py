@@ -14,9 +14,11 @@ algebra is the same Gram + Cholesky + triangular solves as the single-GPU path
               panel; the owner of the next panel updates and factors it first and its
               broadcast is issued asynchronously while all ranks apply the current panel to
               the rest of their block columns (MFMA SYRK/GEMM).
-  Solves      X L^T = B for B = [K(Xs, X); delta^T] block by block: every rank accumulates
-              the partial products of the blocks it owns, one ALL-REDUCE per block column
-              sums them, the owner finishes the block against its diagonal factor.
+  Solves      the right-hand sides B = [delta^T; K(Xs, X)] are appended as extra ROWS to every
+              panel (block column j of B lives with block column j of K), so the panel solves
+              and trailing updates of the factorisation also compute B L^-T: no separate
+              triangular-solve phase and no extra communication (the broadcast panels simply
+              carry 128 + roundup(M, 128) more rows).
   Scalars     log det, a^T a, posterior mean / variance pieces: one all-reduce of a short vector.
 
 Only broadcast and all_reduce are used, so the same driver runs on RCCL and, for tests, on gloo.
@@ -100,8 +102,8 @@ class HipPanelOps:
         """C[m x n] -= A[m x k] B[n x k]^T on and below C's diagonal"""
         self.dev.gemm_nt(self._w(C_, m, n), self._w(A, m, k), self._w(B, n, k), m, n, k, alpha=-1.0, beta=1.0, lower_only=True)
 
-    def cross_block(self, out, Xs, M, X, N, r0, nb, spec, delta):
-        """out[Mp x nb]: rows < M = tt_to_num(K(Xs, X[r0:r0+nb])), row M = delta[r0:r0+nb], rest 0"""
+    def rhs_block(self, out, Xs, M, X, N, r0, nb, spec, delta):
+        """out[E x nb], E = 128 + Mp: row 0 = delta[r0:r0+nb]; rows 128..128+M = tt_to_num(K(Xs, X[r0:r0+nb]))"""
         d = X.shape[1]
         out.zero_()
         ncols = max(min(nb, N - r0), 0)
@@ -110,28 +112,18 @@ class HipPanelOps:
             xs = self.dev.wrap(Xs.data_ptr(), M, d, Xs.stride(0), self.dtype, keep=Xs)
             xv = X[r0:]
             xw = self.dev.wrap(xv.data_ptr(), ncols, d, X.stride(0), self.dtype, keep=X)
-            self.dev.gram(prog, xs, xw, d, self._w(out), M, ncols, self._lib.G3_GRAM_SCRUB)
-            out[M, :ncols] = delta[r0:r0 + ncols]
+            v = out[128:]
+            self.dev.gram(prog, xs, xw, d, self._w(v), M, ncols, self._lib.G3_GRAM_SCRUB)
+            out[0, :ncols] = delta[r0:r0 + ncols]
 
-    def gemm_acc(self, S, Xk, Ljk, m, n, k, first):
-        """S[m x n] = (0 if first else S) + Xk[m x k] Ljk[n x k]^T"""
-        self.dev.gemm_nt(self._w(S, m, n), self._w(Xk, m, k), self._w(Ljk, n, k), m, n, k, alpha=1.0, beta=0.0 if first else 1.0)
-
-    def solve_block(self, Bj, S, Ljj, Wj, m, nb, have_s):
-        """Bj <- (Bj - S) Ljj^-T"""
-        if have_s:
-            Bj.sub_(S)
-        rc = self.dev.lib.g3_trsm_rlt(self.dev.ctx, Ljj.data_ptr(), nb, Ljj.stride(0), Bj.data_ptr(), m, Bj.stride(0),
-                                      self._lib.dtype_code(self.dtype), Wj.data_ptr())
-        if rc:
-            raise self._lib.G3Error('g3_trsm_rlt failed %d' % rc)
-
-    def block_stats(self, Xj, Ljj, M, nb, nvalid):
-        """(sum log diag L_jj over valid rows, a_j^T a_j, dot[M], ss[M]) with a_j = row M of Xj"""
-        a = Xj[M:M + 1]
+    def block_stats(self, rhs, Ljj, M, nb, nvalid):
+        """(sum log diag L_jj over valid rows, a_j^T a_j, dot[M], ss[M]) with a_j = row 0 of the
+        solved right-hand-side block and V_j = its rows 128..128+M"""
+        a = rhs[0:1]
+        V = rhs[128:]
         st = self.dev.logp_terms(self._w(Ljj, nb, nb), max(nvalid, 1), self._w(a, 1, nb)) if nvalid > 0 else [0.0, 0.0, 0, 0]
         dot, ss = self.alloc(1, M), self.alloc(1, M)
-        self.dev.rows_dot_ss(self._w(Xj, M, nb), M, nb, self._w(a, 1, nb), self._w(dot, 1, M), self._w(ss, 1, M))
+        self.dev.rows_dot_ss(self._w(V, M, nb), M, nb, self._w(a, 1, nb), self._w(dot, 1, M), self._w(ss, 1, M))
         # a beyond nvalid is exactly zero (zero right-hand side in the identity padding)
         quad = float((a[0, :] * a[0, :]).sum().item())
         return st[0], quad, dot[0].double().cpu().numpy(), ss[0].double().cpu().numpy()
@@ -143,46 +135,47 @@ class HipPanelOps:
 class DistributedGP:
     """One evaluation of logp + posterior mean / variance over `world` ranks."""
 
-    def __init__(self, dev, dist, rank, world, N, d, M, nb=2048, torch_device=None, ops=None, dtype=np.float64):
+    def __init__(self, dev, dist, rank, world, N, d, M, nb=1024, torch_device=None, ops=None, dtype=np.float64):
         import torch
         self.dist, self.rank, self.world = dist, rank, world
         self.N, self.d, self.M = N, d, M
         pad = 128
         self.nb = max(pad, (nb // pad) * pad)
         self.Np = (N + pad - 1) // pad * pad
-        self.Mp = (M + 1 + pad - 1) // pad * pad          # rows 0..M-1: K(Xs, .), row M: delta
+        self.Mp = (M + pad - 1) // pad * pad
+        self.E = 128 + self.Mp                          # right-hand-side rows: delta block + K(Xs, .)
+        self.R = self.Np + self.E
         self.blocks = block_ranges(self.Np, self.nb)
         self.ops = ops if ops is not None else HipPanelOps(dev, torch, torch_device, dtype)
         self.torch = torch
         o = self.ops
-        # owned panels, their block inverses, right-hand-side blocks
-        self.panels, self.W, self.B = {}, {}, {}
+        # owned panels: rows r_j..Np of block column j, then the E right-hand-side rows
+        self.panels, self.W = {}, {}
         for j, (r0, nbj) in enumerate(self.blocks):
             if j % world == rank:
-                self.panels[j] = o.alloc(self.Np - r0, nbj)
+                self.panels[j] = o.alloc(self.R - r0, nbj)
                 self.W[j] = o.alloc(nbj, 128)
-                self.B[j] = o.alloc(self.Mp, nbj)
-        self.recv = [o.alloc(self.Np, self.nb), o.alloc(self.Np, self.nb)]   # double-buffered panel landing zone
-        self.S = o.alloc(self.Mp, self.nb)
+        self.recv = [o.alloc(self.R, self.nb), o.alloc(self.R, self.nb)]   # double-buffered panel landing zone
         self.last = {}
+        self._alias = {}
 
     def owner(self, j):
         return j % self.world
 
-    # ---------------------------------------------------------------- factorisation
-    def _build(self, spec, X, jitter):
-        o, dist = self.ops, self.dist
+    # ---------------------------------------------------------------- build
+    def _build(self, spec, spec_cross, X, Xs, delta, jitter):
+        o = self.ops
         lmin = np.inf
         for j, P in self.panels.items():
             r0, nbj = self.blocks[j]
-            o.gram_panel(P, X, self.N, self.Np, r0, nbj, spec)
+            o.gram_panel(P[:self.Np - r0], X, self.N, self.Np, r0, nbj, spec)
+            o.rhs_block(P[self.Np - r0:], Xs, self.M, X, self.N, r0, nbj, spec_cross, delta)
             nv = max(min(nbj, self.N - r0), 0)
             if nv > 0:
                 lmin = min(lmin, o.diag_min(P, nv)[0])
         # tt_to_cov (tensors.py:95-98): min over the WHOLE diagonal
         t = self.torch.tensor([lmin if np.isfinite(lmin) else 1e300], dtype=self.torch.float64)
-        t = self._allreduce(t, 'min')
-        gmin = float(t[0])
+        gmin = float(self._allreduce(t, 'min')[0])
         add = jitter
         if not gmin > 0:
             add += float(np.float32(1e-6)) - gmin
@@ -202,47 +195,38 @@ class DistributedGP:
         dist.all_reduce(dev_t, op=opmap[op])
         return dev_t.cpu()
 
-    def _panel_view(self, k):
+    def _panel(self, k):
         """the (rows x nb_k) tensor holding panel k on this rank (own storage or landing zone)"""
         r0, nbk = self.blocks[k]
         if self.owner(k) == self.rank:
             return self.panels[k]
-        return self.recv[k % 2][:self.Np - r0, :nbk]
+        if k not in self._alias:   # contiguous (rows x nb_k) alias of the landing zone
+            rows = self.R - r0
+            self._alias[k] = self.recv[k % 2].view(-1)[:rows * nbk].view(rows, nbk)
+        return self._alias[k]
 
     def _bcast(self, k, async_op):
         if self.world == 1:
             return None
-        r0, nbk = self.blocks[k]
-        t = self._panel_view(k)
-        if not t.is_contiguous():
-            # landing-zone views of narrower last panels: use a contiguous alias
-            t = self.recv[k % 2].view(-1)[:(self.Np - r0) * nbk].view(self.Np - r0, nbk)
-            self._alias = getattr(self, '_alias', {})
-            self._alias[k] = t
-        return self.dist.broadcast(t, src=self.owner(k), async_op=async_op)
-
-    def _panel(self, k):
-        if self.owner(k) != self.rank and getattr(self, '_alias', {}).get(k) is not None:
-            return self._alias[k]
-        return self._panel_view(k)
+        return self.dist.broadcast(self._panel(k), src=self.owner(k), async_op=async_op)
 
     def _apply(self, k, j):
-        """block column j -= panel k contribution (SYRK/GEMM, lower part only)"""
+        """block column j (and its right-hand-side rows) -= panel k contribution (lower part only)"""
         rk, nbk = self.blocks[k]
         rj, nbj = self.blocks[j]
-        Pk = self._panel(k)
-        rows = Pk[rj - rk:]
-        self.ops.syrk_update(self.panels[j], rows, rows, self.Np - rj, nbj, nbk)
+        rows = self._panel(k)[rj - rk:]
+        self.ops.syrk_update(self.panels[j], rows, rows, self.R - rj, nbj, nbk)
 
-    def factor(self, spec, X, jitter=0.0):
+    # ---------------------------------------------------------------- factorisation + solves in one sweep
+    def factor(self, spec, spec_cross, X, Xs, delta, jitter=0.0):
         """returns the global potrf info (0 = success)"""
         o = self.ops
         self._alias = {}
-        self._build(spec, X, jitter)
+        self._build(spec, spec_cross, X, Xs, delta, jitter)
         nblk = len(self.blocks)
         info = 0
         if self.owner(0) == self.rank:
-            info = max(info, o.potrf_panel(self.panels[0], self.Np, self.blocks[0][1], self.W[0]))
+            info = max(info, o.potrf_panel(self.panels[0], self.R, self.blocks[0][1], self.W[0]))
         work = self._bcast(0, async_op=False)
         for k in range(nblk):
             if work is not None and hasattr(work, 'wait'):
@@ -252,7 +236,7 @@ class DistributedGP:
                 if self.owner(k + 1) == self.rank:      # look-ahead: next panel first
                     self._apply(k, k + 1)
                     r1, nb1 = self.blocks[k + 1]
-                    info = max(info, o.potrf_panel(self.panels[k + 1], self.Np - r1, nb1, self.W[k + 1]))
+                    info = max(info, o.potrf_panel(self.panels[k + 1], self.R - r1, nb1, self.W[k + 1]))
                 work = self._bcast(k + 1, async_op=True)
             for j in self.panels:
                 if j > k + 1:
@@ -260,13 +244,13 @@ class DistributedGP:
         t = self._allreduce(self.torch.tensor([float(info)], dtype=self.torch.float64), 'max')
         return int(t[0])
 
-    def factor_robust(self, spec, X):
+    def factor_robust(self, spec, spec_cross, X, Xs, delta):
         """CholeskyRobust's schedule (tensors.py:197-222) around the distributed factorisation"""
-        info = self.factor(spec, X)
+        info = self.factor(spec, spec_cross, X, Xs, delta)
         tries, fallback = 0, False
         if info != 0:
             # jitter from the diagonal of the (lifted) covariance: rebuild and gather mean / min
-            self._build(spec, X, 0.0)
+            self._build(spec, spec_cross, X, Xs, delta, 0.0)
             s, cnt, mn = 0.0, 0, np.inf
             for j, P in self.panels.items():
                 r0, nbj = self.blocks[j]
@@ -284,7 +268,7 @@ class DistributedGP:
             ok = False
             for _ in range(20):
                 tries += 1
-                if self.factor(spec, X, jitter=lift + dK) == 0:
+                if self.factor(spec, spec_cross, X, Xs, delta, jitter=lift + dK) == 0:
                     ok = True
                     break
                 dK *= c10
@@ -294,50 +278,28 @@ class DistributedGP:
         self.last.update(info=info, tries=tries, fallback=fallback)
         return info
 
-    # ---------------------------------------------------------------- solves and statistics
-    def solve(self, spec_cross, Xs, X, delta):
-        """X_j = (B_j - sum_{k<j} X_k L_jk^T) L_jj^-T for B = [K(Xs, X); delta^T]; returns
-        (logdet, quad, mean_pieces[M], ss[M]) summed over all ranks"""
-        o, M, Mp = self.ops, self.M, self.Mp
-        nblk = len(self.blocks)
-        for j, Bj in self.B.items():
-            r0, nbj = self.blocks[j]
-            o.cross_block(Bj, Xs, M, X, self.N, r0, nbj, spec_cross, delta)
+    def stats(self):
+        """(logdet, quad, mean_pieces[M], ss[M]) summed over all ranks"""
+        o, M = self.ops, self.M
         acc = np.zeros(2 + 2 * M)
-        for j in range(nblk):
+        for j, P in self.panels.items():
             rj, nbj = self.blocks[j]
-            S = self.S[:, :nbj] if nbj == self.nb else self.S.view(-1)[:Mp * nbj].view(Mp, nbj)
-            first = True
-            for k in self.panels:
-                if k < j:
-                    rk, nbk = self.blocks[k]
-                    Ljk = self.panels[k][rj - rk: rj - rk + nbj]
-                    o.gemm_acc(S, self.B[k], Ljk, Mp, nbj, nbk, first)
-                    first = False
-            if j > 0:
-                if first:
-                    S.zero_()
-                if self.world > 1:
-                    self.dist.all_reduce(S)
-            if self.owner(j) == self.rank:
-                o.solve_block(self.B[j], S, self.panels[j], self.W[j], Mp, nbj, j > 0)
-                nv = max(min(nbj, self.N - rj), 0)
-                ld, q, dot, ss = o.block_stats(self.B[j], self.panels[j], M, nbj, nv)
-                acc[0] += ld
-                acc[1] += q
-                acc[2:2 + M] += dot
-                acc[2 + M:] += ss
+            nv = max(min(nbj, self.N - rj), 0)
+            ld, q, dot, ss = o.block_stats(P[self.Np - rj:], P, M, nbj, nv)
+            acc[0] += ld
+            acc[1] += q
+            acc[2:2 + M] += dot
+            acc[2 + M:] += ss
         t = self._allreduce(self.torch.from_numpy(acc), 'sum').numpy()
         return float(t[0]), float(t[1]), t[2:2 + M], t[2 + M:]
 
-    def step(self, spec_noise, spec_f, X, Xs, delta, prior_var=None):
+    def step(self, spec_noise, spec_f, X, Xs, delta):
         """one pass of the hot path; returns logp (mean / variance pieces in self.last)"""
         Xt = X._keep if hasattr(X, '_keep') and X._keep is not None else X
         Xst = Xs._keep if hasattr(Xs, '_keep') and Xs._keep is not None else Xs
         dt = delta._keep if hasattr(delta, '_keep') and delta._keep is not None else delta
-        dvec = dt.reshape(-1)
-        self.factor_robust(spec_noise, Xt)
-        logdet, quad, mean, ss = self.solve(spec_f, Xst, Xt, dvec)
+        self.factor_robust(spec_noise, spec_f, Xt, Xst, dt.reshape(-1))
+        logdet, quad, mean, ss = self.stats()
         self.ops.sync()
         logp = -0.5 * self.N * np.log(2 * np.pi) - 0.5 * quad - logdet
         self.last.update(logdet=logdet, quad=quad, mean=mean, ss=ss, logp=logp)

@@ -31,5 +31,5 @@ for (m, n, k, lower) in shapes:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = (1.0 if lower else 2.0) * m * n * k
+    fl = 2.0 * k * ((m * n - n * (n - 1) / 2) if lower else m * n)
     print('m %6d n %6d k %6d lower %d cfg %s: %8.3f ms  %6.2f TFLOP/s' % (m, n, k, lower, os.environ.get('G3_GEMM_CFG', 'auto'), ms, fl / ms / 1e9))

@@ -67,32 +67,21 @@ class NumpyPanelOps:
         mask = np.tril(np.ones((m, n), bool))
         c[:m, :n] -= np.where(mask, upd, 0.0)
 
-    def cross_block(self, out, Xs, M, X, N, r0, nb, spec, delta):
+    def rhs_block(self, out, Xs, M, X, N, r0, nb, spec, delta):
         from oracle import g3_oracle as orc
         o = out.numpy()
         o[:] = 0
         cols = max(min(nb, N - r0), 0)
         if cols > 0:
-            o[:M, :cols] = orc.tt_to_num(orc.kernel_cov(spec, Xs.numpy(), X.numpy()[r0:r0 + cols]))
-            o[M, :cols] = delta.numpy()[r0:r0 + cols]
+            o[128:128 + M, :cols] = orc.tt_to_num(orc.kernel_cov(spec, Xs.numpy(), X.numpy()[r0:r0 + cols]))
+            o[0, :cols] = delta.numpy()[r0:r0 + cols]
 
-    def gemm_acc(self, S, Xk, Ljk, m, n, k, first):
-        s = S.numpy()
-        v = Xk.numpy()[:m, :k] @ Ljk.numpy()[:n, :k].T
-        s[:m, :n] = v if first else s[:m, :n] + v
-
-    def solve_block(self, Bj, S, Ljj, Wj, m, nb, have_s):
-        b = Bj.numpy()
-        if have_s:
-            b[:m, :nb] -= S.numpy()[:m, :nb]
-        L = np.tril(Ljj.numpy()[:nb, :nb])
-        b[:m, :nb] = scipy.linalg.solve_triangular(L, b[:m, :nb].T, lower=True).T
-
-    def block_stats(self, Xj, Ljj, M, nb, nvalid):
-        x = Xj.numpy()
-        a = x[M, :nb]
+    def block_stats(self, rhs, Ljj, M, nb, nvalid):
+        x = rhs.numpy()
+        a = x[0, :nb]
+        V = x[128:128 + M, :nb]
         ld = float(np.sum(np.log(np.diag(Ljj.numpy()[:nvalid, :nvalid])))) if nvalid > 0 else 0.0
-        return ld, float(a @ a), x[:M, :nb] @ a, (x[:M, :nb] ** 2).sum(1)
+        return ld, float(a @ a), V @ a, (V ** 2).sum(1)
 
     def sync(self):
         pass
