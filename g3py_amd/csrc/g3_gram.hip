@@ -7,14 +7,26 @@
 // evaluates the whole kernel expression for its pairs and writes K exactly once, row-wise
 // coalesced (HBM-write bound).  tt_to_num (tensors.py:90-92) is fused into the store.
 #include "g3_internal.h"
+#include <stdlib.h>
 
 #define GT 64           // output tile edge
 #define G3_PI 3.14159265358979323846
 
+// Periodic leaves depend on the pair only through cos / sin of theta_i - theta_j with
+// theta = scale * freq_k * x_k.  When `ti`, `tj` are given they hold, per point,
+// [cos(theta_k), sin(theta_k)] pairs prepared once per tile, and the pair value costs two
+// FMAs per dimension instead of one fp64 cos/sin (the angle-difference identities are exact;
+// the only deviation from the direct formula is the rounding of theta itself).
+// (SINC divides sin(theta_i - theta_j) by dx: the absolute rounding of theta would be amplified
+//  for close points, so SINC keeps the direct formula.)
+__host__ __device__ __forceinline__ bool leaf_has_trig(int kind) {
+  return kind == G3_K_COS || kind == G3_K_SIN || kind == G3_K_SM;
+}
+
 template <typename T>
 __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* xj, bool diag_sym,
-                                       bool sym) {
-  // xi, xj: LDS rows (all d columns of the two points)
+                                       bool sym, const T* ti, const T* tj) {
+  // xi, xj: LDS rows (all d columns of the two points); ti, tj: trig rows of this leaf or null
   const int nd = lf.ndims;
   const T var = (T)lf.var;
   switch (lf.kind) {
@@ -62,6 +74,10 @@ __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* 
     }
     case G3_K_COS: {
       T p = T(1);
+      if (ti) {
+        for (int k = 0; k < nd; ++k) p *= ti[2 * k] * tj[2 * k] + ti[2 * k + 1] * tj[2 * k + 1];
+        return var * p;
+      }
       for (int k = 0; k < nd; ++k) {
         const int c = lf.dims[k];
         p *= cos(T(2 * G3_PI) * (xi[c] - xj[c]) * (T)lf.freq[k]);
@@ -70,6 +86,11 @@ __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* 
     }
     case G3_K_SIN: {
       T s = T(0);
+      if (ti) {   // sin^2(pi f dx) = (1 - cos(2 pi f dx)) / 2
+        for (int k = 0; k < nd; ++k)
+          s += (T(0.5) * (T(1) - (ti[2 * k] * tj[2 * k] + ti[2 * k + 1] * tj[2 * k + 1]))) * (T)lf.rate[k];
+        return var * exp(T(2) * s);
+      }
       for (int k = 0; k < nd; ++k) {
         const int c = lf.dims[k];
         const T v = sin(T(G3_PI) * (xi[c] - xj[c]) * (T)lf.freq[k]);
@@ -83,7 +104,9 @@ __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* 
         const int c = lf.dims[k];
         const T dx = xi[c] - xj[c];
         const T f = (T)lf.freq[k];
-        const T v = sin(T(2 * G3_PI * G3_PI) * dx * f) / (T(2 * G3_PI * G3_PI) * f * dx);
+        const T sn = ti ? (ti[2 * k + 1] * tj[2 * k] - ti[2 * k] * tj[2 * k + 1])   // sin(theta_i - theta_j)
+                        : sin(T(2 * G3_PI * G3_PI) * dx * f);
+        const T v = sn / (T(2 * G3_PI * G3_PI) * f * dx);
         p *= (dx != T(0)) ? v : T(1);
       }
       return var * p;
@@ -95,7 +118,7 @@ __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* 
         const T dx = xi[c] - xj[c];
         const T r = (T)lf.rate[k];
         s += (dx * dx) * (r * r);
-        p *= cos(T(2 * G3_PI) * dx * (T)lf.freq[k]);
+        p *= ti ? (ti[2 * k] * tj[2 * k] + ti[2 * k + 1] * tj[2 * k + 1]) : cos(T(2 * G3_PI) * dx * (T)lf.freq[k]);
       }
       return var * (exp(T(-2 * G3_PI * G3_PI) * s) * p);
     }
@@ -106,16 +129,30 @@ __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* 
 
 template <typename T>
 __device__ __forceinline__ T prog_eval(const g3_kernel_prog* __restrict__ prog, const T* xi,
-                                       const T* xj, bool diag_sym, bool sym) {
+                                       const T* xj, bool diag_sym, bool sym, const T* trig_i = nullptr,
+                                       const T* trig_j = nullptr, const int* toff = nullptr) {
   T acc = (T)prog->shift;
   const int np = prog->nprod;
   for (int p = 0; p < np; ++p) {
     T v = (T)prog->prod[p].coef;
     const int nf = prog->prod[p].nfac;
-    for (int f = 0; f < nf; ++f) v *= leaf_eval<T>(prog->leaf[prog->prod[p].fac[f]], xi, xj, diag_sym, sym);
+    for (int f = 0; f < nf; ++f) {
+      const int l = prog->prod[p].fac[f];
+      const bool tr = trig_i != nullptr && toff[l] >= 0;
+      v *= leaf_eval<T>(prog->leaf[l], xi, xj, diag_sym, sym, tr ? trig_i + 2 * toff[l] : (const T*)nullptr,
+                        tr ? trig_j + 2 * toff[l] : (const T*)nullptr);
+    }
     acc += v;
   }
   return acc;
+}
+
+// number of (leaf, dimension) pairs that need a cos / sin table entry
+static __host__ __device__ inline int prog_trig_pairs(const g3_kernel_prog* p) {
+  int tt = 0;
+  for (int l = 0; l < p->nleaf; ++l)
+    if (leaf_has_trig(p->leaf[l].kind)) tt += p->leaf[l].ndims;
+  return tt;
 }
 
 template <typename T>
@@ -142,7 +179,7 @@ template <typename T, int D, bool SE_FAST>
 __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
             int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
-            T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym) {
+            T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym, int ntrig) {
   int64_t bi = blockIdx.y, bj = blockIdx.x;
   if (flags & G3_GRAM_LOWER) {
     // 1-D grid over the tiles on or below the diagonal only: row-block b has b/2 + 1 column
@@ -171,6 +208,35 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
   for (int e = tid; e < GTN * d; e += 256) {
     const int r = e / d, c = e - r * d;
     xj_s[r * dp + c] = (j0 + r < n2) ? X2[(j0 + r) * ldx2 + c] : T(0);
+  }
+  // cos / sin tables of the periodic leaves for the 64 + 128 points of this tile
+  T* trig_s = xj_s + GTN * dp;
+  const int tstride = 2 * ntrig + 1;   // odd stride: conflict-free column-varying reads
+  __shared__ int toff_s[G3_MAXLEAF];
+  if constexpr (!SE_FAST) if (ntrig > 0) {
+    if (tid == 0) {
+      int o = 0;
+      for (int l = 0; l < prog->nleaf; ++l) {
+        const bool h = leaf_has_trig(prog->leaf[l].kind);
+        toff_s[l] = h ? o : -1;
+        if (h) o += prog->leaf[l].ndims;
+      }
+      for (int l = prog->nleaf; l < G3_MAXLEAF; ++l) toff_s[l] = -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < (GT + GTN) * ntrig; e += 256) {
+      const int pnt = e / ntrig, t = e - pnt * ntrig;
+      int l = 0;
+      while (l + 1 < prog->nleaf && !(toff_s[l] >= 0 && t >= toff_s[l] && t < toff_s[l] + prog->leaf[l].ndims)) ++l;
+      const g3_leaf& lf = prog->leaf[l];
+      const int k = t - toff_s[l];
+      const T x = (pnt < GT ? xi_s[pnt * dp + lf.dims[k]] : xj_s[(pnt - GT) * dp + lf.dims[k]]);
+      const T scale = (lf.kind == G3_K_SINC) ? T(2 * G3_PI * G3_PI) : T(2 * G3_PI);
+      const T th = scale * (T)lf.freq[k] * x;
+      const T sn = sin(th), cs = cos(th);
+      trig_s[pnt * tstride + 2 * t] = cs;
+      trig_s[pnt * tstride + 2 * t + 1] = sn;
+    }
   }
   __syncthreads();
   const int tx = tid & 63, ty = tid >> 6;  // column pair within tile, row phase
@@ -208,7 +274,11 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
           v[q] = se.var * exp(-dd);
           if (dg) v[q] += se.noise;
         } else {
-          v[q] = prog_eval<T>(prog, xi_s + rr * dp, q ? xjb : xja, dg, sym != 0);
+          if (ntrig > 0)
+            v[q] = prog_eval<T>(prog, xi_s + rr * dp, q ? xjb : xja, dg, sym != 0, trig_s + rr * tstride,
+                                trig_s + (GT + 2 * tx + q) * tstride, toff_s);
+          else
+            v[q] = prog_eval<T>(prog, xi_s + rr * dp, q ? xjb : xja, dg, sym != 0);
         }
         if (scr) v[q] = scrub(v[q]);
       } else {
@@ -314,7 +384,7 @@ static int launch_gram_fast(g3_ctx* ctx, const SeParams<T, D>& se, const T* X1, 
   const size_t lds = (GT + GTN) * (D | 1) * sizeof(T);
   hipLaunchKernelGGL((gram_kernel<T, D, true>), grid, dim3(256), lds, ctx->stream,
                      (const g3_kernel_prog*)nullptr, se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad,
-                     n2pad, flags, sym);
+                     n2pad, flags, sym, 0);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -336,10 +406,19 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
   if (rc) return rc;
   dim3 grid = gram_grid(n1pad, n2pad, flags);
-  const size_t lds = (GT + GTN) * (d | 1) * sizeof(T);
+  // periodic leaves: per-tile cos / sin tables unless there are too many (LDS) or the caller
+  // asked for the direct formulas (G3_GRAM_DIRECT_TRIG=1)
+  int ntrig = prog_trig_pairs(prog);
+  static int direct = -1;
+  if (direct < 0) {
+    const char* e = getenv("G3_GRAM_DIRECT_TRIG");
+    direct = (e && atoi(e)) ? 1 : 0;
+  }
+  if (ntrig > 16 || direct) ntrig = 0;
+  const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
   SeParams<T, 1> dummy{};
   hipLaunchKernelGGL((gram_kernel<T, 1, false>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
-                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym);
+                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
