@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, AMD public spec; see DESIGN.md
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = FP32 vector peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -91,6 +92,9 @@ def main():
     ap.add_argument('--points', dest='n', type=int, default=32768, help='N observations')
     ap.add_argument('--dims', dest='d', type=int, default=4, help='input columns d')
     ap.add_argument('--queries', dest='m', type=int, default=1024, help='M prediction points')
+    ap.add_argument('--kernel', default='se', choices=['se', 'mat52cos'],
+                    help='se: BASELINE configs 2/4; mat52cos: MAT52 + periodic COS sum kernel (config 3)')
+    ap.add_argument('--f32', action='store_true', help='float32 arithmetic (config 5 runs in fp32)')
     ap.add_argument('--cpu-n', type=int, default=8192, help='N of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
     ap.add_argument('--panel', dest='nb', type=int, default=1024, help='block-column width of the multi-GPU distribution')
@@ -125,8 +129,13 @@ def main():
     N, d, M, seed = args.n, args.d, args.m, 1004
     X, y, Xs = synth(N, d, M, seed)
     delta = y.copy()                      # Zero mean, identity mapping: delta = y
-    spec_f = ('SE', 1.0, np.ones(d), None)
+    if args.kernel == 'se':
+        spec_f = ('SE', 1.0, np.ones(d), None)
+    else:
+        spec_f = ('sum', ('MAT52', 1.0, np.ones(d), None), ('COS', 0.5, np.full(d, 0.125), None))
     spec_n = ('sum', spec_f, ('NOISE', 0.1))
+    npdt = np.float32 if args.f32 else np.float64
+    tdt = torch.float32 if args.f32 else torch.float64
     dev = g3.Device(local_rank)
     # the critical-path stream gets high priority; the library's side stream (bulk updates) is low
     hp = torch.cuda.Stream(device=tdev0, priority=-1) if os.environ.get('G3_BENCH_HIPRIO', '1') == '1' else None
@@ -137,21 +146,21 @@ def main():
     tdev = torch.device('cuda', local_rank)
 
     def tens(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(tdev)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=npdt)).to(tdev)
 
     def wrap(t, rows, cols):
-        return dev.wrap(t.data_ptr(), rows, cols, t.stride(0) if t.dim() == 2 else cols, np.float64, keep=t)
+        return dev.wrap(t.data_ptr(), rows, cols, t.stride(0) if t.dim() == 2 else cols, npdt, keep=t)
 
     Xt, Xst, dt_ = tens(X), tens(Xs), tens(delta[None, :])
     Xd, Xsd, dd = wrap(Xt, N, d), wrap(Xst, M, d), wrap(dt_, 1, N)
 
     if world == 1:
-        Kt = torch.empty((Np + 128 + Mp, Np), dtype=torch.float64, device=tdev)   # covariance + right-hand-side rows
-        at = torch.empty((1, Np), dtype=torch.float64, device=tdev)
-        Vt = torch.empty((Mp, Np), dtype=torch.float64, device=tdev)
-        mut = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
-        sst = torch.empty((1, Mp), dtype=torch.float64, device=tdev)
-        Wt_ = torch.empty((Np, 128), dtype=torch.float64, device=tdev)
+        Kt = torch.empty((Np + 128 + Mp, Np), dtype=tdt, device=tdev)   # covariance + right-hand-side rows
+        at = torch.empty((1, Np), dtype=tdt, device=tdev)
+        Vt = torch.empty((Mp, Np), dtype=tdt, device=tdev)
+        mut = torch.empty((1, Mp), dtype=tdt, device=tdev)
+        sst = torch.empty((1, Mp), dtype=tdt, device=tdev)
+        Wt_ = torch.empty((Np, 128), dtype=tdt, device=tdev)
         Wd = wrap(Wt_, Np, 128)
         Kd, ad, Vd, mud, ssd = wrap(Kt, Np + 128 + Mp, Np), wrap(at, 1, Np), wrap(Vt, Mp, Np), wrap(mut, 1, Mp), wrap(sst, 1, Mp)
         prog_n, prog_f = compile_spec(spec_n, d), compile_spec(spec_f, d)
@@ -166,7 +175,7 @@ def main():
         parallelism = '1gpu'
     else:
         from g3py_amd.distributed import DistributedGP
-        dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, torch_device=tdev)
+        dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, torch_device=tdev, dtype=npdt)
         result = {}
 
         def step():
@@ -190,7 +199,7 @@ def main():
     prof = dev.prof_collect()
     dev.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        t = torch.tensor([elapsed], dtype=tdt, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -198,11 +207,11 @@ def main():
         sec = elapsed / args.steps
         flops = step_flops(N, M)
         out = {
-            'metric': 'GP logp+predict end-to-end (Gram+Cholesky+solves), N=%d fp64: algorithmic TFLOP/s' % N,
+            'metric': 'GP logp+predict end-to-end (Gram+Cholesky+solves), N=%d %s: algorithmic TFLOP/s' % (N, 'fp32' if args.f32 else 'fp64'),
             'value': flops / sec / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'SE-kernel GaussianProcess fp64, N=%d d=%d, M=%d test points: Gram + blocked '
+            'vs_baseline': None, 'dtype': 'f32' if args.f32 else 'f64', 'data': 'synthetic',
+            'config': {'workload': args.kernel.upper() + '-kernel GaussianProcess, N=%d d=%d, M=%d test points: Gram + blocked '
                                    'Cholesky + L^-1 y (logp) + cross-Gram + %d-rhs trsm + posterior mean/variance'
                                    % (N, d, M, M), 'N': N, 'd': d, 'M': M, 'parallelism': parallelism},
             'e2e_sec': sec, 'logp': float(result['logp']),
@@ -218,9 +227,10 @@ def main():
         g = prof['gemm_bulk']
         if g['count']:
             ach = g['work'] / (g['ms'] * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / FP64_MATRIX_PEAK_TFLOPS, 'traffic': _traffic(),
-                               'kernel': 'gemm_nt_kernel<double,128,128,64,64>, launches with >= 1024 tiles '
+            peak = FP32_MATRIX_PEAK_TFLOPS if args.f32 else FP64_MATRIX_PEAK_TFLOPS
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': ach / peak, 'traffic': _traffic() if (not args.f32 and N == 32768) else None,
+                               'kernel': 'gemm_nt_kernel<%s,128,128,64,64>, launches with >= 1024 tiles ' % ('float' if args.f32 else 'double') +
                                          '(bulk panel updates of the blocked Cholesky and of the trsm)',
                                'launches_per_step': g['count'] / args.steps,
                                'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],

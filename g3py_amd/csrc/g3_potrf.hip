@@ -413,7 +413,9 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
   int64_t NB = ctx->nb_lookahead;
   if (NB <= 0) {
     const char* e = getenv("G3_NB");
-    NB = e ? atoll(e) : 1024;
+    // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
+    // kernels that dominates small problems, wide panels give the bulk updates more K
+    NB = e ? atoll(e) : (n <= 8192 ? 256 : (n <= 20480 ? 512 : 1024));
   }
   NB = g3_roundup(NB < LB ? LB : NB, LB);
   if (n >= 3 * NB) {

@@ -11,15 +11,17 @@ shapes = [(16384, 16384, 2048, 1), (16384, 16384, 16384, 1), (8192, 8192, 2048, 
 if len(sys.argv) > 4:
     a = list(map(int, sys.argv[1:]))
     shapes = [tuple(a[i:i + 4]) for i in range(0, len(a), 4)]
+DT = np.float32 if os.environ.get('G3_BENCH_F32') else np.float64
+TDT = torch.float32 if DT == np.float32 else torch.float64
 dev = g3.Device(0)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 dev.set_stream(st.cuda_stream)
 for (m, n, k, lower) in shapes:
-    A = torch.rand((max(m, n), k), dtype=torch.float64, device='cuda') - 0.5
-    C = torch.rand((m, n), dtype=torch.float64, device='cuda')
-    Ad = dev.wrap(A.data_ptr(), max(m, n), k, k, np.float64)
-    Cd = dev.wrap(C.data_ptr(), m, n, n, np.float64)
+    A = torch.rand((max(m, n), k), dtype=TDT, device='cuda') - 0.5
+    C = torch.rand((m, n), dtype=TDT, device='cuda')
+    Ad = dev.wrap(A.data_ptr(), max(m, n), k, k, DT)
+    Cd = dev.wrap(C.data_ptr(), m, n, n, DT)
     for _ in range(2):
         dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=1.0, lower_only=bool(lower))
     torch.cuda.synchronize()
@@ -32,4 +34,4 @@ for (m, n, k, lower) in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * k * ((m * n - n * (n - 1) / 2) if lower else m * n)
-    print('m %6d n %6d k %6d lower %d cfg %s: %8.3f ms  %6.2f TFLOP/s' % (m, n, k, lower, os.environ.get('G3_GEMM_CFG', 'auto'), ms, fl / ms / 1e9))
+    print(np.dtype(DT).name, 'm %6d n %6d k %6d lower %d cfg %s: %8.3f ms  %6.2f TFLOP/s' % (m, n, k, lower, os.environ.get('G3_GEMM_CFG', 'auto'), ms, fl / ms / 1e9))
