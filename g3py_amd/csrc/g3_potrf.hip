@@ -38,17 +38,26 @@ __device__ __forceinline__ float fast_rcp(float p) {
   return y;
 }
 
-// ---- 64 x 64 elimination sweep (device function, 512 threads as a 16 x 32 grid, each owning
-// a 4 x 2 register micro-tile of A and of W).  FACTOR: A <- chol(A) and W <- inv(L);
-// otherwise A already holds L and only W is formed.  Per elimination step only column j of A
-// and row j of W travel through LDS (double buffered: one barrier per step).  W is written at
-// stride ldw and, if Wt != nullptr, transposed at stride ldwt.
+// ---- 64 x 64 elimination sweep (device function, 512 threads).  Thread (ti, tk) = (tid & 15,
+// tid >> 4) owns the 4 x 2 micro-tile rows 4ti.., columns 2tk.. of A and of W in registers.
+// FACTOR: A <- chol(A) and W <- inv(L); otherwise A already holds L and only W is formed.
+// TWO columns are eliminated per barrier: the 16 lanes that own column pair (j, j+1) finish
+// both columns among themselves with wave shuffles (pivot, scale, update of column j+1, second
+// pivot) and publish the two final L columns plus three scalars through LDS; after one barrier
+// every thread applies the rank-2 update to its A tile and, from the raw rows j, j+1 of W
+// published at the same time, to its W tile.  Only the owning wave runs the two rsqrt chains.
 constexpr int LEAF_THREADS = 512;
+template <typename T>
+struct LeafLds {
+  T col[2][2][G3_LEAF];   // [buffer][column j / j+1][row]
+  T row[2][2][G3_LEAF];   // [buffer][W row j / j+1][column]
+  T scal[2][4];           // rp_j, rp_j+1, l_{j+1,j}
+};
+
 template <typename T, bool FACTOR>
 __device__ __forceinline__ void leaf64_sweep(T* A, int64_t ld, T* W, int64_t ldw, T* Wt, int64_t ldwt,
-                                             int* info, int64_t row_base, T (*colbuf)[G3_LEAF],
-                                             T (*rowbuf)[G3_LEAF]) {
-  const int tid = threadIdx.x, ti = tid >> 5, tk = tid & 31;   // rows 4*ti.., cols 2*tk..
+                                             int* info, int64_t row_base, LeafLds<T>& S) {
+  const int tid = threadIdx.x, ti = tid & 15, tk = tid >> 4, lane = tid & 63;
   T a[4][2], w[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -58,74 +67,107 @@ __device__ __forceinline__ void leaf64_sweep(T* A, int64_t ld, T* W, int64_t ldw
       a[r][c] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
       w[r][c] = (row == col) ? T(1) : T(0);
     }
-  for (int jj = 0; jj < 16; ++jj) {
+  for (int jq = 0; jq < 16; ++jq) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int j = 4 * jj + s;
-      const int buf = s & 1;
-      const int ctk = 2 * jj + (s >> 1), cc = s & 1;   // owner column group / column in tile
-      if (tk == ctk) {
+    for (int h = 0; h < 2; ++h) {
+      const int jp = 2 * jq + h, j = 2 * jp, buf = h;
+      constexpr int dummy = 0; (void)dummy;
+      const int r0 = 2 * h, r1 = 2 * h + 1;          // rows j, j+1 inside the micro-tile of ti == jq
+      if (tk == jp) {                                // the 16 lanes that own columns j and j+1
+        const int src = (lane & ~15) | jq;           // the lane that holds rows j, j+1
+        T p0 = __shfl(a[r0][0], src, 64);
+        T rp0, d0;
+        if (FACTOR) {
+          if (!(p0 > T(0))) {                        // also catches NaN
+            if (ti == jq) atomicCAS(info, 0, (int)(row_base + j + 1));
+            p0 = T(1);
+          }
+          rp0 = fast_rsqrt(p0);
+          d0 = p0 * rp0;
+          d0 = fma(T(0.5) * rp0, fma(-d0, d0, p0), d0);
+        } else {
+          d0 = p0;
+          rp0 = fast_rcp(p0);
+        }
+        T l0[4], c1[4], l1[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) colbuf[buf][4 * ti + r] = a[r][cc];
+        for (int r = 0; r < 4; ++r) l0[r] = FACTOR ? a[r][0] * rp0 : a[r][0];
+        const T l10 = __shfl(l0[r1], src, 64);       // L[j+1][j]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c1[r] = FACTOR ? fma(-l0[r], l10, a[r][1]) : a[r][1];
+        T p1 = __shfl(c1[r1], src, 64);
+        T rp1, d1;
+        if (FACTOR) {
+          if (!(p1 > T(0))) {
+            if (ti == jq) atomicCAS(info, 0, (int)(row_base + j + 2));
+            p1 = T(1);
+          }
+          rp1 = fast_rsqrt(p1);
+          d1 = p1 * rp1;
+          d1 = fma(T(0.5) * rp1, fma(-d1, d1, p1), d1);
+        } else {
+          d1 = p1;
+          rp1 = fast_rcp(p1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          l1[r] = FACTOR ? c1[r] * rp1 : c1[r];
+          S.col[buf][0][4 * ti + r] = l0[r];
+          S.col[buf][1][4 * ti + r] = l1[r];
+        }
+        if (FACTOR) {                                // columns j, j+1 are final in the owners' registers
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * ti + r;
+            if (row > j) a[r][0] = l0[r];
+            else if (row == j) a[r][0] = d0;
+            if (row > j + 1) a[r][1] = l1[r];
+            else if (row == j + 1) a[r][1] = d1;
+          }
+        }
+        if (ti == jq) {
+          S.scal[buf][0] = rp0;
+          S.scal[buf][1] = rp1;
+          S.scal[buf][2] = l10;
+        }
       }
-      if (ti == jj) {
+      if (ti == jq) {                                // raw rows j, j+1 of W
 #pragma unroll
-        for (int c = 0; c < 2; ++c) rowbuf[buf][2 * tk + c] = w[s][c];
+        for (int c = 0; c < 2; ++c) {
+          S.row[buf][0][2 * tk + c] = w[r0][c];
+          S.row[buf][1][2 * tk + c] = w[r1][c];
+        }
       }
       __syncthreads();
-      T p = colbuf[buf][j];
-      T rp, dg;
-      if (FACTOR) {
-        if (!(p > T(0))) {  // also catches NaN
-          if (tid == 0) atomicCAS(info, 0, (int)(row_base + j + 1));
-          p = T(1);
-        }
-        // 1/sqrt(p) from the hardware estimate + two Newton steps (full precision, no fp64
-        // divide / sqrt sequences on the critical path); sqrt(p) = p * rp with one correction
-        rp = fast_rsqrt(p);
-        dg = p * rp;
-        dg = fma(T(0.5) * rp, fma(-dg, dg, p), dg);
-      } else {
-        dg = p;
-        rp = fast_rcp(p);
-      }
-      T li[4], lk[2], wj[2];
+      const T rp0 = S.scal[buf][0], rp1 = S.scal[buf][1], l10 = S.scal[buf][2];
+      T lim0[4], lim1[4], lcm0[2], lcm1[2], wj0[2], wj1[2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        li[r] = colbuf[buf][4 * ti + r];
-        if (FACTOR) li[r] *= rp;
+        const bool below = (4 * ti + r) > j + 1;
+        lim0[r] = below ? S.col[buf][0][4 * ti + r] : T(0);
+        lim1[r] = below ? S.col[buf][1][4 * ti + r] : T(0);
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        lk[c] = colbuf[buf][2 * tk + c];
-        if (FACTOR) lk[c] *= rp;
-        wj[c] = rowbuf[buf][2 * tk + c] * rp;
+        const bool right = (2 * tk + c) > j + 1;
+        lcm0[c] = right ? S.col[buf][0][2 * tk + c] : T(0);
+        lcm1[c] = right ? S.col[buf][1][2 * tk + c] : T(0);
+        wj0[c] = S.row[buf][0][2 * tk + c] * rp0;
+        wj1[c] = fma(-l10, wj0[c], S.row[buf][1][2 * tk + c]) * rp1;
       }
-      // masked operands instead of per-element predicates: rows <= j and columns <= j of the
-      // trailing update contribute exactly zero
-      T lim[4], lkm[2];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lim[r] = ((4 * ti + r) > j) ? li[r] : T(0);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) lkm[c] = ((2 * tk + c) > j) ? lk[c] : T(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          if (FACTOR) a[r][c] = fma(-lim[r], lkm[c], a[r][c]);
-          w[r][c] = fma(-lim[r], wj[c], w[r][c]);
+          if (FACTOR) a[r][c] = fma(-lim1[r], lcm1[c], fma(-lim0[r], lcm0[c], a[r][c]));
+          w[r][c] = fma(-lim1[r], wj1[c], fma(-lim0[r], wj0[c], w[r][c]));
         }
-      if (FACTOR && tk == ctk) {
+      if (ti == jq) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * ti + r;
-          if (row > j) a[r][cc] = li[r];
-          else if (row == j) a[r][cc] = dg;
+        for (int c = 0; c < 2; ++c) {
+          w[r0][c] = wj0[c];
+          w[r1][c] = wj1[c];
         }
-      }
-      if (ti == jj) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) w[s][c] = wj[c];
       }
     }
   }
@@ -199,25 +241,220 @@ diag128_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_
   W += (int64_t)blockIdx.x * w_stride;
   scr += (int64_t)blockIdx.x * (2 * 64 * 64);
   row_base += (int64_t)blockIdx.x * G3_LB;
-  __shared__ T colbuf[2][G3_LEAF];
-  __shared__ T rowbuf[2][G3_LEAF];
+  __shared__ LeafLds<T> lds;
   T* W11t = scr;
   T* Tt = scr + 64 * 64;
   T* A21 = A + 64 * ld;
   T* A22 = A21 + 64;
   T* W22 = W + 64 * ldw + 64;
-  leaf64_sweep<T, FACTOR>(A, ld, W, ldw, W11t, 64, info, row_base, colbuf, rowbuf);
+  leaf64_sweep<T, FACTOR>(A, ld, W, ldw, W11t, 64, info, row_base, lds);
   __syncthreads();
   if (FACTOR) {
     tile_gemm64<T>(A21, ld, A21, ld, W, ldw, T(1), T(0), false);        // L21 = A21 W11^T (in place)
     tile_gemm64<T>(A22, ld, A21, ld, A21, ld, T(-1), T(1), true);       // A22 -= L21 L21^T
   }
-  leaf64_sweep<T, FACTOR>(A22, ld, W22, ldw, (T*)nullptr, 0, info, row_base + 64, colbuf, rowbuf);
+  leaf64_sweep<T, FACTOR>(A22, ld, W22, ldw, (T*)nullptr, 0, info, row_base + 64, lds);
   __syncthreads();
   tile_gemm64<T>(Tt, 64, W11t, 64, A21, ld, T(1), T(0), false);         // Tt = (L21 W11)^T
   tile_gemm64<T>(W + 64 * ldw, ldw, W22, ldw, Tt, 64, T(-1), T(0), false);   // W21 = -W22 (L21 W11)
   // the upper-right 64 x 64 block of W must read as zero
   for (int e = threadIdx.x; e < 64 * 64; e += LEAF_THREADS) W[(int64_t)(e >> 6) * ldw + 64 + (e & 63)] = T(0);
+}
+
+// =======================================================================================
+// MFMA-blocked diagonal kernel: one workgroup (8 waves) factors a 128 x 128 block and forms its
+// inverse with BOTH matrices resident in MFMA accumulators.  The block is an 8 x 8 grid of
+// 16 x 16 tiles; wave w owns block row w (tiles (w, 0..w)) of A and of W.  Per block step k:
+//   wave k      : diagonal tile -> LDS -> one row per lane; 16 x 16 Cholesky and triangular
+//                 inverse with scalar broadcasts (v_readlane) -- the only sequential part;
+//                 W(k, :) <- W_dd W(k, :) by MFMA; publishes W_dd and its W row through LDS
+//   waves i > k : L(i,k) = A(i,k) W_dd^T (MFMA), published through LDS;
+//                 A(i,j) -= L(i,k) L(j,k)^T for k < j <= i and W(i,j) -= L(i,k) W(k,j) for j <= k
+// Three barriers per block step (24 per block) instead of one per column (128), and all O(n^3)
+// work on the matrix pipe.  FACTOR = false: A already holds L, only W is formed.
+constexpr int TS = 17;   // LDS tile row stride in elements (16 + 1: conflict-free fragment reads)
+template <typename T>
+struct DiagLds {
+  T D[16 * TS];        // diagonal tile, then L_dd
+  T Wd[16 * TS];       // W_dd = inv(L_dd)
+  T P[8][16 * TS];     // panel tiles L(i,k), i = block row (also scratch for the raw A(i,k))
+  T Wr[8][16 * TS];    // row k of W: tiles W(k, j)
+};
+
+__device__ __forceinline__ double readlane_t(double v, int l) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+  return u.d;
+}
+__device__ __forceinline__ float readlane_t(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <typename T>
+struct TileOps {
+  using M = MfmaT<T>;
+  using acc_t = typename M::acc_t;
+  // accumulator (C/D layout) <-> LDS tile
+  static __device__ __forceinline__ void store(T* t, const acc_t& a, int lane) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[M::row(lane, r) * TS + (lane & 15)] = a[r];
+  }
+  static __device__ __forceinline__ acc_t load(const T* t, int lane) {
+    acc_t a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = t[M::row(lane, r) * TS + (lane & 15)];
+    return a;
+  }
+  // acc += sign * X * Y^T   (X, Y LDS tiles): A[i][k] = X[i][k], B[k][j] = Y[j][k]
+  static __device__ __forceinline__ acc_t mul_nt(const T* X, const T* Y, acc_t acc, T sign, int lane) {
+    const int o = (lane & 15) * TS + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = M::mfma(sign * X[o + 4 * s], Y[o + 4 * s], acc);
+    return acc;
+  }
+  // acc += sign * X * Y     (X, Y LDS tiles): A[i][k] = X[i][k], B[k][j] = Y[k][j]
+  static __device__ __forceinline__ acc_t mul_nn(const T* X, const T* Y, acc_t acc, T sign, int lane) {
+    const int oa = (lane & 15) * TS + (lane >> 4);
+    const int ob = (lane >> 4) * TS + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = M::mfma(sign * X[oa + 4 * s], Y[ob + 4 * s * TS], acc);
+    return acc;
+  }
+};
+
+// 16 x 16 Cholesky + triangular inverse by ONE wave: lane i < 16 holds row i of the tile.
+// In: D (LDS, lower triangle valid).  Out: D <- L_dd (upper zero), Wd <- inv(L_dd).
+template <typename T, bool FACTOR>
+__device__ __forceinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t base) {
+  const int i = lane & 15;
+  T row[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) row[c] = D[i * TS + c];
+  T rp[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    T p = readlane_t(row[j], j);
+    if (FACTOR) {
+      if (!(p > T(0))) {   // also catches NaN
+        if (lane == 0) atomicCAS(info, 0, (int)(base + j + 1));
+        p = T(1);
+      }
+      rp[j] = fast_rsqrt(p);
+      T dg = p * rp[j];
+      dg = fma(T(0.5) * rp[j], fma(-dg, dg, p), dg);
+      const T lj = (i > j) ? row[j] * rp[j] : ((i == j) ? dg : T(0));
+      row[j] = lj;
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) row[c] = fma(-lj, readlane_t(lj, c), row[c]);
+    } else {
+      rp[j] = fast_rcp(p);
+      if (i < j) row[j] = T(0);
+    }
+  }
+  // inverse: lane c holds column c of W; W[i][c] = (delta_ic - sum_{k<i} L[i][k] W[k][c]) / L[i][i]
+  T w[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    T acc = (r == i) ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < r; ++k) acc = fma(-readlane_t(row[k], r), w[k], acc);
+    w[r] = acc * rp[r];
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) D[i * TS + c] = row[c];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Wd[r * TS + i] = (r >= i) ? w[r] : T(0);
+  }
+}
+
+template <typename T, bool FACTOR>
+__global__ void __launch_bounds__(512)
+diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, int* info,
+                int64_t row_base) {
+  using TO = TileOps<T>;
+  using acc_t = typename TO::acc_t;
+  using M = MfmaT<T>;
+  if (FACTOR && *info != 0) return;
+  A += (int64_t)blockIdx.x * a_stride;
+  W += (int64_t)blockIdx.x * w_stride;
+  row_base += (int64_t)blockIdx.x * G3_LB;
+  __shared__ DiagLds<T> S;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   // wave w owns block row w
+  acc_t aA[8], aW[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    aW[j] = acc_t{0, 0, 0, 0};
+    aA[j] = acc_t{0, 0, 0, 0};
+    if (j <= w) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + M::row(lane, r), col = 16 * j + (lane & 15);
+        aA[j][r] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
+        aW[j][r] = (row == col) ? T(1) : T(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    __syncthreads();                       // previous step's LDS readers are done
+    if (w == k) {
+      TO::store(S.D, aA[k], lane);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes landed (wave-local hand-off)
+      __builtin_amdgcn_wave_barrier();
+      diag16<T, FACTOR>(S.D, S.Wd, lane, info, row_base + 16 * k);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (FACTOR) aA[k] = TO::load(S.D, lane);
+      // W(k, j) <- W_dd W(k, j) for j < k ; W(k, k) = W_dd
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < k) {
+          TO::store(S.Wr[j], aW[j], lane);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          aW[j] = TO::mul_nn(S.Wd, S.Wr[j], acc_t{0, 0, 0, 0}, T(1), lane);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          TO::store(S.Wr[j], aW[j], lane);
+        }
+      }
+      aW[k] = TO::load(S.Wd, lane);
+      TO::store(S.Wr[k], aW[k], lane);
+    }
+    __syncthreads();                       // W_dd and row k of W are published
+    if (w > k) {
+      TO::store(S.P[w], aA[k], lane);
+      if (FACTOR) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        aA[k] = TO::mul_nt(S.P[w], S.Wd, acc_t{0, 0, 0, 0}, T(1), lane);   // L(w,k) = A(w,k) W_dd^T
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        TO::store(S.P[w], aA[k], lane);
+      }
+    }
+    __syncthreads();                       // the panel L(:, k) is published
+    if (w > k) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (FACTOR && j > k && j <= w) aA[j] = TO::mul_nt(S.P[w], S.P[j], aA[j], T(-1), lane);
+        if (j <= k) aW[j] = TO::mul_nn(S.P[w], S.Wr[j], aW[j], T(-1), lane);
+      }
+    }
+  }
+  // write back: L (lower part only, strict upper never written) and W (full 128 x 128, upper zero)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * w + M::row(lane, r), col = 16 * j + (lane & 15);
+      if (FACTOR && j <= w && row >= col) A[(int64_t)row * ld + col] = aA[j][r];
+      W[(int64_t)row * ldw + col] = (j <= w && row >= col) ? aW[j][r] : T(0);
+    }
+  }
 }
 
 constexpr int64_t LB = G3_LB;
@@ -235,8 +472,14 @@ static int64_t split_point(int64_t n, int64_t unit) {
 template <typename T>
 static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_dtype dt) {
   const int pr = g3i_prof_begin(ctx, G3_TAG_LEAF, 128.0 * 128.0 * 128.0 / 3.0);
-  hipLaunchKernelGGL((diag128_kernel<T, true>), dim3(1), dim3(LEAF_THREADS), 0, ctx->stream, A, ld, (int64_t)0, W,
-                     LB, (int64_t)0, (T*)ctx->wscr, ctx->d_info, row_base);
+  static int old_kernel = -1;
+  if (old_kernel < 0) old_kernel = getenv("G3_DIAG_OLD") ? 1 : 0;
+  if (old_kernel)
+    hipLaunchKernelGGL((diag128_kernel<T, true>), dim3(1), dim3(LEAF_THREADS), 0, ctx->stream, A, ld, (int64_t)0, W,
+                       LB, (int64_t)0, (T*)ctx->wscr, ctx->d_info, row_base);
+  else
+    hipLaunchKernelGGL((diag128m_kernel<T, true>), dim3(1), dim3(512), 0, ctx->stream, A, ld, (int64_t)0, W, LB,
+                       (int64_t)0, ctx->d_info, row_base);
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -445,13 +688,13 @@ int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtyp
   }
   const unsigned nb = (unsigned)(n / LB);
   if (dt == G3_F64)
-    hipLaunchKernelGGL((diag128_kernel<double, false>), dim3(nb), dim3(LEAF_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL((diag128m_kernel<double, false>), dim3(nb), dim3(512), 0, ctx->stream,
                        (double*)const_cast<void*>(L), ldl, LB * (ldl + 1), (double*)invd, LB, LB * LB,
-                       (double*)ctx->wscr, ctx->d_info, (int64_t)0);
+                       ctx->d_info, (int64_t)0);
   else
-    hipLaunchKernelGGL((diag128_kernel<float, false>), dim3(nb), dim3(LEAF_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL((diag128m_kernel<float, false>), dim3(nb), dim3(512), 0, ctx->stream,
                        (float*)const_cast<void*>(L), ldl, LB * (ldl + 1), (float*)invd, LB, LB * LB,
-                       (float*)ctx->wscr, ctx->d_info, (int64_t)0);
+                       ctx->d_info, (int64_t)0);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
