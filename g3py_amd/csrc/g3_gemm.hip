@@ -25,7 +25,6 @@
 
 constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
 constexpr int GROUP_M = 4; // row-blocks per raster group
-constexpr int NCH = 8;     // 16-byte chunks per row
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
@@ -39,8 +38,6 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   constexpr int NWN = BN / WN;
   constexpr int NT = (BM / WM) * NWN * 64;
   constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int CA = BM * NCH / NT, CB = BN * NCH / NT;
-  static_assert(BM * NCH % NT == 0 && BN * NCH % NT == 0, "tile/threads mismatch");
 
   // ---- tile assignment: XCD-aware, grouped raster over the ACTIVE tiles only.
   // Workgroups are dealt round-robin over the 8 XCDs, so ids {x, x+8, ...} share an L2;

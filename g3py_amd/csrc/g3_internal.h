@@ -7,7 +7,6 @@
 
 #include "g3hip.h"
 
-#define G3_LEAF 64  // diagonal block factored (and inverted) by one workgroup
 #define G3_LB 128   // diagonal block factored + inverted by ONE fused kernel; matrices are padded to it
 
 struct g3_ctx {
@@ -30,8 +29,6 @@ struct g3_ctx {
   // block inverses of the last factorisation
   void* invd;
   size_t invd_bytes;
-  void* wscr;              // scratch of the fused diagonal kernel (2 x 64 x 64 per block)
-  size_t wscr_bytes;
   // padded workspace for g3_potrf_robust / g3_trsm on ragged sizes
   void* work;
   size_t work_bytes;

@@ -7,9 +7,10 @@
 // Structure (all row-major, lower triangle):
 //   potrf(A[n x n])      = potrf(A11); A21 <- A21 L11^-T; A22 -= A21 A21^T; potrf(A22)
 //   trsm_rlt(B, L[n x n]) = trsm(B1, L11); B2 -= B1 L21^T; trsm(B2, L22)
-// Leaves are 64 x 64: ONE workgroup factors the diagonal block and, in the same sweep,
-// forms its inverse W = L^-1 (forward elimination on [A | I]); every panel solve is then a
-// GEMM against W^T, so all O(N^3) work runs in the MFMA GEMM of g3_gemm.hip.
+// Leaves are 128 x 128: ONE workgroup factors the diagonal block and forms its inverse
+// W = L^-1 with both matrices resident in MFMA accumulators; every panel solve is then a GEMM
+// against W^T, so all O(N^3) work runs on the matrix pipe (g3_gemm.hip).  Large matrices use a
+// flat right-looking sweep over panels with one-panel look-ahead on two streams.
 #include "g3_internal.h"
 #include "g3_mfma.h"
 #include <stdlib.h>
@@ -36,229 +37,6 @@ __device__ __forceinline__ float fast_rcp(float p) {
   float y = __builtin_amdgcn_rcpf(p);
   y = y * fmaf(-p, y, 2.0f);
   return y;
-}
-
-// ---- 64 x 64 elimination sweep (device function, 512 threads).  Thread (ti, tk) = (tid & 15,
-// tid >> 4) owns the 4 x 2 micro-tile rows 4ti.., columns 2tk.. of A and of W in registers.
-// FACTOR: A <- chol(A) and W <- inv(L); otherwise A already holds L and only W is formed.
-// TWO columns are eliminated per barrier: the 16 lanes that own column pair (j, j+1) finish
-// both columns among themselves with wave shuffles (pivot, scale, update of column j+1, second
-// pivot) and publish the two final L columns plus three scalars through LDS; after one barrier
-// every thread applies the rank-2 update to its A tile and, from the raw rows j, j+1 of W
-// published at the same time, to its W tile.  Only the owning wave runs the two rsqrt chains.
-constexpr int LEAF_THREADS = 512;
-template <typename T>
-struct LeafLds {
-  T col[2][2][G3_LEAF];   // [buffer][column j / j+1][row]
-  T row[2][2][G3_LEAF];   // [buffer][W row j / j+1][column]
-  T scal[2][4];           // rp_j, rp_j+1, l_{j+1,j}
-};
-
-template <typename T, bool FACTOR>
-__device__ __forceinline__ void leaf64_sweep(T* A, int64_t ld, T* W, int64_t ldw, T* Wt, int64_t ldwt,
-                                             int* info, int64_t row_base, LeafLds<T>& S) {
-  const int tid = threadIdx.x, ti = tid & 15, tk = tid >> 4, lane = tid & 63;
-  T a[4][2], w[4][2];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int row = 4 * ti + r, col = 2 * tk + c;
-      a[r][c] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
-      w[r][c] = (row == col) ? T(1) : T(0);
-    }
-  for (int jq = 0; jq < 16; ++jq) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int jp = 2 * jq + h, j = 2 * jp, buf = h;
-      constexpr int dummy = 0; (void)dummy;
-      const int r0 = 2 * h, r1 = 2 * h + 1;          // rows j, j+1 inside the micro-tile of ti == jq
-      if (tk == jp) {                                // the 16 lanes that own columns j and j+1
-        const int src = (lane & ~15) | jq;           // the lane that holds rows j, j+1
-        T p0 = __shfl(a[r0][0], src, 64);
-        T rp0, d0;
-        if (FACTOR) {
-          if (!(p0 > T(0))) {                        // also catches NaN
-            if (ti == jq) atomicCAS(info, 0, (int)(row_base + j + 1));
-            p0 = T(1);
-          }
-          rp0 = fast_rsqrt(p0);
-          d0 = p0 * rp0;
-          d0 = fma(T(0.5) * rp0, fma(-d0, d0, p0), d0);
-        } else {
-          d0 = p0;
-          rp0 = fast_rcp(p0);
-        }
-        T l0[4], c1[4], l1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) l0[r] = FACTOR ? a[r][0] * rp0 : a[r][0];
-        const T l10 = __shfl(l0[r1], src, 64);       // L[j+1][j]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c1[r] = FACTOR ? fma(-l0[r], l10, a[r][1]) : a[r][1];
-        T p1 = __shfl(c1[r1], src, 64);
-        T rp1, d1;
-        if (FACTOR) {
-          if (!(p1 > T(0))) {
-            if (ti == jq) atomicCAS(info, 0, (int)(row_base + j + 2));
-            p1 = T(1);
-          }
-          rp1 = fast_rsqrt(p1);
-          d1 = p1 * rp1;
-          d1 = fma(T(0.5) * rp1, fma(-d1, d1, p1), d1);
-        } else {
-          d1 = p1;
-          rp1 = fast_rcp(p1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          l1[r] = FACTOR ? c1[r] * rp1 : c1[r];
-          S.col[buf][0][4 * ti + r] = l0[r];
-          S.col[buf][1][4 * ti + r] = l1[r];
-        }
-        if (FACTOR) {                                // columns j, j+1 are final in the owners' registers
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 4 * ti + r;
-            if (row > j) a[r][0] = l0[r];
-            else if (row == j) a[r][0] = d0;
-            if (row > j + 1) a[r][1] = l1[r];
-            else if (row == j + 1) a[r][1] = d1;
-          }
-        }
-        if (ti == jq) {
-          S.scal[buf][0] = rp0;
-          S.scal[buf][1] = rp1;
-          S.scal[buf][2] = l10;
-        }
-      }
-      if (ti == jq) {                                // raw rows j, j+1 of W
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          S.row[buf][0][2 * tk + c] = w[r0][c];
-          S.row[buf][1][2 * tk + c] = w[r1][c];
-        }
-      }
-      __syncthreads();
-      const T rp0 = S.scal[buf][0], rp1 = S.scal[buf][1], l10 = S.scal[buf][2];
-      T lim0[4], lim1[4], lcm0[2], lcm1[2], wj0[2], wj1[2];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool below = (4 * ti + r) > j + 1;
-        lim0[r] = below ? S.col[buf][0][4 * ti + r] : T(0);
-        lim1[r] = below ? S.col[buf][1][4 * ti + r] : T(0);
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bool right = (2 * tk + c) > j + 1;
-        lcm0[c] = right ? S.col[buf][0][2 * tk + c] : T(0);
-        lcm1[c] = right ? S.col[buf][1][2 * tk + c] : T(0);
-        wj0[c] = S.row[buf][0][2 * tk + c] * rp0;
-        wj1[c] = fma(-l10, wj0[c], S.row[buf][1][2 * tk + c]) * rp1;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          if (FACTOR) a[r][c] = fma(-lim1[r], lcm1[c], fma(-lim0[r], lcm0[c], a[r][c]));
-          w[r][c] = fma(-lim1[r], wj1[c], fma(-lim0[r], wj0[c], w[r][c]));
-        }
-      if (ti == jq) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          w[r0][c] = wj0[c];
-          w[r1][c] = wj1[c];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int row = 4 * ti + r, col = 2 * tk + c;
-      const T wv = (row >= col) ? w[r][c] : T(0);
-      if (FACTOR && row >= col) A[(int64_t)row * ld + col] = a[r][c];   // strict upper: never written
-      W[(int64_t)row * ldw + col] = wv;
-      if (Wt) Wt[(int64_t)col * ldwt + row] = wv;
-    }
-}
-
-// C[64 x 64] = alpha * A[64 x 64] * B[64 x 64]^T + beta * C by the 8 waves of the workgroup,
-// operands straight from global memory / L2 (one scalar per lane per MFMA, no LDS staging:
-// the whole product is 32 KB per operand).  Wave w owns output tiles 2w and 2w+1 of the
-// 4 x 4 grid of 16 x 16 tiles.  C may alias A: every wave finishes its loads before the
-// barrier that precedes the stores.
-template <typename T>
-__device__ __forceinline__ void tile_gemm64(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
-                                            T alpha, T beta, bool lower_only) {
-  using M = MfmaT<T>;
-  using acc_t = typename M::acc_t;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, kq = lane >> 4;
-  acc_t acc[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int tile = 2 * wave + t, tr = tile >> 2, tc = tile & 3;
-    acc[t] = acc_t{0, 0, 0, 0};
-    if (lower_only && tc > tr) continue;
-    const T* a = A + (int64_t)(16 * tr + fr) * lda + kq;
-    const T* b = B + (int64_t)(16 * tc + fr) * ldb + kq;
-#pragma unroll
-    for (int k = 0; k < 64; k += 4) acc[t] = M::mfma(a[k], b[k], acc[t]);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int tile = 2 * wave + t, tr = tile >> 2, tc = tile & 3;
-    if (lower_only && tc > tr) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * tr + M::row(lane, r), col = 16 * tc + fr;
-      if (lower_only && col > row) continue;
-      T* p = C + (int64_t)row * ldc + col;
-      T v = alpha * acc[t][r];
-      if (beta != T(0)) v += beta * (*p);
-      *p = v;
-    }
-  }
-  __syncthreads();
-}
-
-// ---- fused diagonal block: one workgroup factors a 128 x 128 block and forms its inverse
-//   L11 = chol(A11), W11 = inv(L11)          (64-wide sweep)
-//   L21 = A21 W11^T ; A22 -= L21 L21^T        (MFMA tile products)
-//   L22 = chol(A22), W22 = inv(L22)           (64-wide sweep)
-//   W21 = -W22 (L21 W11)                      (two MFMA tile products)
-// W (128 x 128, stride ldw) receives [[W11, 0], [W21, W22]]; scr holds W11^T and (L21 W11)^T.
-// FACTOR = false: A already holds L, only W is formed.  One block per 128-block (batched via
-// blockIdx.x with the given strides).
-template <typename T, bool FACTOR>
-__global__ void __launch_bounds__(LEAF_THREADS)
-diag128_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, T* scr,
-               int* info, int64_t row_base) {
-  if (FACTOR && *info != 0) return;
-  A += (int64_t)blockIdx.x * a_stride;
-  W += (int64_t)blockIdx.x * w_stride;
-  scr += (int64_t)blockIdx.x * (2 * 64 * 64);
-  row_base += (int64_t)blockIdx.x * G3_LB;
-  __shared__ LeafLds<T> lds;
-  T* W11t = scr;
-  T* Tt = scr + 64 * 64;
-  T* A21 = A + 64 * ld;
-  T* A22 = A21 + 64;
-  T* W22 = W + 64 * ldw + 64;
-  leaf64_sweep<T, FACTOR>(A, ld, W, ldw, W11t, 64, info, row_base, lds);
-  __syncthreads();
-  if (FACTOR) {
-    tile_gemm64<T>(A21, ld, A21, ld, W, ldw, T(1), T(0), false);        // L21 = A21 W11^T (in place)
-    tile_gemm64<T>(A22, ld, A21, ld, A21, ld, T(-1), T(1), true);       // A22 -= L21 L21^T
-  }
-  leaf64_sweep<T, FACTOR>(A22, ld, W22, ldw, (T*)nullptr, 0, info, row_base + 64, lds);
-  __syncthreads();
-  tile_gemm64<T>(Tt, 64, W11t, 64, A21, ld, T(1), T(0), false);         // Tt = (L21 W11)^T
-  tile_gemm64<T>(W + 64 * ldw, ldw, W22, ldw, Tt, 64, T(-1), T(0), false);   // W21 = -W22 (L21 W11)
-  // the upper-right 64 x 64 block of W must read as zero
-  for (int e = threadIdx.x; e < 64 * 64; e += LEAF_THREADS) W[(int64_t)(e >> 6) * ldw + 64 + (e & 63)] = T(0);
 }
 
 // =======================================================================================
@@ -327,7 +105,7 @@ struct TileOps {
 // 16 x 16 Cholesky + triangular inverse by ONE wave: lane i < 16 holds row i of the tile.
 // In: D (LDS, lower triangle valid).  Out: D <- L_dd (upper zero), Wd <- inv(L_dd).
 template <typename T, bool FACTOR>
-__device__ __forceinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t base) {
+__device__ __noinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t base) {
   const int i = lane & 15;
   T row[16];
 #pragma unroll
@@ -472,14 +250,8 @@ static int64_t split_point(int64_t n, int64_t unit) {
 template <typename T>
 static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_dtype dt) {
   const int pr = g3i_prof_begin(ctx, G3_TAG_LEAF, 128.0 * 128.0 * 128.0 / 3.0);
-  static int old_kernel = -1;
-  if (old_kernel < 0) old_kernel = getenv("G3_DIAG_OLD") ? 1 : 0;
-  if (old_kernel)
-    hipLaunchKernelGGL((diag128_kernel<T, true>), dim3(1), dim3(LEAF_THREADS), 0, ctx->stream, A, ld, (int64_t)0, W,
-                       LB, (int64_t)0, (T*)ctx->wscr, ctx->d_info, row_base);
-  else
-    hipLaunchKernelGGL((diag128m_kernel<T, true>), dim3(1), dim3(512), 0, ctx->stream, A, ld, (int64_t)0, W, LB,
-                       (int64_t)0, ctx->d_info, row_base);
+  hipLaunchKernelGGL((diag128m_kernel<T, true>), dim3(1), dim3(512), 0, ctx->stream, A, ld, (int64_t)0, W, LB,
+                     (int64_t)0, ctx->d_info, row_base);
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -521,25 +293,7 @@ int g3i_reset_info(g3_ctx* ctx) {
   return G3_OK;
 }
 
-// scratch of the fused diagonal kernel: W11^T and (L21 W11)^T, one pair per block so the batched
-// inverse-only launch (g3i_trtri_blocks) can run all blocks at once
-static int ensure_scratch(g3_ctx* ctx, int64_t n) {
-  const size_t wneed = (size_t)(n / LB > 0 ? n / LB : 1) * 2 * 64 * 64 * sizeof(double);
-  if (ctx->wscr_bytes >= wneed) return G3_OK;
-  if (ctx->wscr) {
-    G3_HIP(hipStreamSynchronize(ctx->stream));
-    G3_HIP(hipFree(ctx->wscr));
-    ctx->wscr = nullptr;
-    ctx->wscr_bytes = 0;
-  }
-  G3_HIP(hipMalloc(&ctx->wscr, wneed));
-  ctx->wscr_bytes = wneed;
-  return G3_OK;
-}
-
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt) {
-  int rc = ensure_scratch(ctx, n);
-  if (rc) return rc;
   size_t need = (size_t)(n / LB) * LB * LB * g3_esize(dt);
   if (ctx->invd_bytes >= need) return G3_OK;
   if (ctx->invd) {
@@ -649,10 +403,7 @@ int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* in
 int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd, int64_t E) {
   G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (n == 0) return G3_OK;
-  {
-    int rc0 = ensure_scratch(ctx, LB);   // the factorisation runs one diagonal block at a time
-    if (rc0) return rc0;
-  }
+
   int64_t NB = ctx->nb_lookahead;
   if (NB <= 0) {
     const char* e = getenv("G3_NB");
@@ -682,10 +433,7 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
 
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd) {
   if (n == 0) return G3_OK;
-  {
-    int rc0 = ensure_scratch(ctx, n);
-    if (rc0) return rc0;
-  }
+
   const unsigned nb = (unsigned)(n / LB);
   if (dt == G3_F64)
     hipLaunchKernelGGL((diag128m_kernel<double, false>), dim3(nb), dim3(512), 0, ctx->stream,
