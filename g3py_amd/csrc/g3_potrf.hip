@@ -53,10 +53,11 @@ __device__ __forceinline__ float fast_rcp(float p) {
 constexpr int TS = 17;   // LDS tile row stride in elements (16 + 1: conflict-free fragment reads)
 template <typename T>
 struct DiagLds {
-  T D[16 * TS];        // diagonal tile, then L_dd
-  T Wd[16 * TS];       // W_dd = inv(L_dd)
-  T P[8][16 * TS];     // panel tiles L(i,k), i = block row (also scratch for the raw A(i,k))
-  T Wr[8][16 * TS];    // row k of W: tiles W(k, j)
+  T D[2][16 * TS];        // [step parity] diagonal tile, then L_dd
+  T Wd[2][16 * TS];       // [step parity] W_dd = inv(L_dd)
+  T P[8][16 * TS];        // panel tiles L(i,k), i = block row (also scratch for the raw A(i,k))
+  T Tt[8][16 * TS];       // T_i = L(i,k) W_dd, private to wave i
+  T Wr[2][8][16 * TS];    // [step parity] row k of W BEFORE its scaling by W_dd: tiles W(k, j), j < k
 };
 
 __device__ __forceinline__ double readlane_t(double v, int l) {
@@ -175,52 +176,45 @@ diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w
       }
     }
   }
+  // Per block step: [wave k: 16 x 16 factor + inverse] B1 [waves i > k: panel tile and
+  // T_i = L(i,k) W_dd] B2 [trailing updates; wave k scales its own W row meanwhile].  Buffers
+  // written by wave k+1 for the NEXT step have the other parity, so no third barrier is needed and
+  // wave k+1 (the lightest in the trailing phase) starts its diagonal tile while the others update.
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    __syncthreads();                       // previous step's LDS readers are done
+    const int par = k & 1;
     if (w == k) {
-      TO::store(S.D, aA[k], lane);
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes landed (wave-local hand-off)
-      __builtin_amdgcn_wave_barrier();
-      diag16<T, FACTOR>(S.D, S.Wd, lane, info, row_base + 16 * k);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      if (FACTOR) aA[k] = TO::load(S.D, lane);
-      // W(k, j) <- W_dd W(k, j) for j < k ; W(k, k) = W_dd
+      TO::store(S.D[par], aA[k], lane);
+      diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
+      if (FACTOR) aA[k] = TO::load(S.D[par], lane);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < k) {
-          TO::store(S.Wr[j], aW[j], lane);
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-          aW[j] = TO::mul_nn(S.Wd, S.Wr[j], acc_t{0, 0, 0, 0}, T(1), lane);
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-          TO::store(S.Wr[j], aW[j], lane);
-        }
-      }
-      aW[k] = TO::load(S.Wd, lane);
-      TO::store(S.Wr[k], aW[k], lane);
+      for (int j = 0; j < 8; ++j)
+        if (j < k) TO::store(S.Wr[par][j], aW[j], lane);     // old W(k, j): consumers multiply by T_i
     }
-    __syncthreads();                       // W_dd and row k of W are published
+    __syncthreads();                       // W_dd and the old row k of W are published
     if (w > k) {
       TO::store(S.P[w], aA[k], lane);
       if (FACTOR) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        aA[k] = TO::mul_nt(S.P[w], S.Wd, acc_t{0, 0, 0, 0}, T(1), lane);   // L(w,k) = A(w,k) W_dd^T
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        aA[k] = TO::mul_nt(S.P[w], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);   // L(w,k) = A(w,k) W_dd^T
         TO::store(S.P[w], aA[k], lane);
       }
+      // T_w = L(w,k) W_dd: W(w,j) -= T_w W_old(k,j) for j < k, and W(w,k) -= T_w (W_old(k,k) = I)
+      const acc_t t = TO::mul_nn(S.P[w], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);
+      aW[k] -= t;
+      TO::store(S.Tt[w], t, lane);
     }
     __syncthreads();                       // the panel L(:, k) is published
     if (w > k) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (FACTOR && j > k && j <= w) aA[j] = TO::mul_nt(S.P[w], S.P[j], aA[j], T(-1), lane);
-        if (j <= k) aW[j] = TO::mul_nn(S.P[w], S.Wr[j], aW[j], T(-1), lane);
+        if (j < k) aW[j] = TO::mul_nn(S.Tt[w], S.Wr[par][j], aW[j], T(-1), lane);
       }
+    } else if (w == k) {                   // off the critical path: W(k, :) <- W_dd W(k, :)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < k) aW[j] = TO::mul_nn(S.Wd[par], S.Wr[par][j], acc_t{0, 0, 0, 0}, T(1), lane);
+      aW[k] = TO::load(S.Wd[par], lane);
     }
   }
   // write back: L (lower part only, strict upper never written) and W (full 128 x 128, upper zero)
