@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _built_library():
+    """build libg3hip.so in-tree when the snapshot does not carry it (hipcc cross-compiles without a GPU)"""
+    from g3py_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
