@@ -36,6 +36,12 @@ class KernelProg(C.Structure):
                 ('leaf', Leaf * G3_MAXLEAF), ('prod', Prod * G3_MAXPROD)]
 
 
+class GradMap(C.Structure):
+    """g3_grad_map: output slot of each leaf parameter (-1 = not wanted)"""
+    _fields_ = [('nslots', C.c_int32), ('var', C.c_int32 * G3_MAXLEAF), ('alpha', C.c_int32 * G3_MAXLEAF),
+                ('rate', C.c_int32 * G3_MAXLEAF), ('freq', C.c_int32 * G3_MAXLEAF)]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _SIGS = {
@@ -73,6 +79,12 @@ _SIGS = {
                               _I64, C.c_int, _P, _I64, _P, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _P], C.c_int),
+    'g3_grad_layout': ([C.POINTER(KernelProg), C.POINTER(GradMap)], C.c_int),
+    'g3_potri': ([_P, _P, _I64, _I64, _P, C.c_int, _P, _I64, _P, _I64], C.c_int),
+    'g3_gram_grad': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
+                      _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_dlogp': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
+                     C.c_int, _P, _I64, _P, _I64, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_prof_enable': ([_P, C.c_int], C.c_int),
     'g3_prof_reset': ([_P], C.c_int),
     'g3_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),

@@ -1,0 +1,555 @@
+// Gradient of the GP log marginal likelihood with respect to the kernel hyper-parameters.
+//
+// Reference: StochasticProcess.th_dlogp = gradient(th_logp) (g3py/processes/stochastic.py:308-309,
+// g3py/libs/tensors.py:11-22) -- Theano differentiates logp_cho (gaussian.py:208-224) through
+// CholeskyRobust.grad (tensors.py:224-260, Murray 2016).  In closed form that chain is
+//     d logp / d theta = 1/2 * sum_ij G_ij * dK_ij/dtheta ,   G = alpha alpha^T - K^-1 ,  alpha = K^-1 delta
+// with K the matrix that was actually factored (jitter included, treated as a constant, exactly
+// as grad() re-uses the jittered factor).  Here:
+//   g3i_potri        Y = L^-T by a right-looking sweep with one-panel look-ahead (the same
+//                    two-stream schedule as the factorisation), K^-1 = Y Y^T accumulated panel by
+//                    panel as SYRKs on the bulk stream -- 2 N^3 / 3 flops, all in the MFMA GEMM;
+//   gram_grad_kernel one pass over the lower triangle of K^-1 (HBM-read bound) that re-evaluates
+//                    the kernel expression per pair and accumulates G_ij * d k_ij / d theta for
+//                    every parameter of every leaf; deterministic two-stage reduction.
+#include "g3_internal.h"
+#include <stdlib.h>
+
+#define GG_T 64            // pair tile edge
+#define GG_THREADS 256
+#define GG_PI 3.14159265358979323846
+
+// ------------------------------------------------------------------------------------------
+// K^-1 from the factor
+// ------------------------------------------------------------------------------------------
+static int ensure_events(g3_ctx* ctx, int need) {
+  if (ctx->la_nev >= need) return G3_OK;
+  if (ctx->la_ev) {
+    for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
+    free(ctx->la_ev);
+    ctx->la_ev = nullptr;
+    ctx->la_nev = 0;
+  }
+  ctx->la_ev = (hipEvent_t*)calloc((size_t)need, sizeof(hipEvent_t));
+  if (!ctx->la_ev) return G3_ERR_NOMEM;
+  for (int i = 0; i < need; ++i) G3_HIP(hipEventCreateWithFlags(&ctx->la_ev[i], hipEventDisableTiming));
+  ctx->la_nev = need;
+  return G3_OK;
+}
+
+// Y (n x n, upper triangular on return) = L^-T and C (lower triangle) = K^-1 = Y Y^T.
+// Right-looking over NB-wide panels of columns: panel k of Y is final after the solve against
+// L_kk; it then updates the columns to its right (rows 0..r1 only: Y is upper triangular, so
+// no flop is spent on structural zeros) and adds its outer product to C.
+int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* invd, g3_dtype dt, void* Y,
+              int64_t ldy, void* C, int64_t ldc) {
+  if (n == 0) return G3_OK;
+  const size_t es = g3_esize(dt);
+  int64_t NB = ctx->nb_lookahead;
+  if (NB <= 0) {
+    const char* e = getenv("G3_NB");
+    NB = e ? atoll(e) : (n <= 8192 ? 256 : (n <= 20480 ? 512 : 1024));
+  }
+  NB = g3_roundup(NB < G3_LB ? G3_LB : NB, G3_LB);
+  const int nblk = (int)((n + NB - 1) / NB);
+  int rc = ensure_events(ctx, 2 * nblk + 2);
+  if (rc) return rc;
+  hipEvent_t* evP = ctx->la_ev;
+  hipEvent_t* evB = ctx->la_ev + nblk;
+  hipStream_t sA = ctx->stream, sB = ctx->side_stream;
+  const bool two = nblk >= 3;   // small problems: everything on the caller's stream
+  if (!two) sB = sA;
+
+  G3_HIP(hipMemset2DAsync(Y, (size_t)ldy * es, 0, (size_t)n * es, (size_t)n, sA));
+  G3_HIP(hipMemset2DAsync(C, (size_t)ldc * es, 0, (size_t)n * es, (size_t)n, sA));
+  rc = g3_diag_add(ctx, Y, n, ldy, dt, 1.0);
+  if (rc) return rc;
+  if (two) {
+    G3_HIP(hipEventRecord(evB[nblk], sA));
+    G3_HIP(hipStreamWaitEvent(sB, evB[nblk], 0));
+  }
+  auto r = [&](int k) { return (int64_t)k * NB < n ? (int64_t)k * NB : n; };
+  auto Lp = [&](int64_t i, int64_t j) { return (const char*)L + ((size_t)i * ldl + j) * es; };
+  auto Yp = [&](int64_t j) { return (char*)Y + (size_t)j * es; };   // row 0, column j
+  const char* Wb = (const char*)invd;
+  auto panel = [&](int k) -> int {   // Y[0:r(k+1), panel k] <- . L_kk^-T
+    return g3i_trsm_rlt(ctx, Lp(r(k), r(k)), r(k + 1) - r(k), ldl, Yp(r(k)), r(k + 1), ldy, dt,
+                        Wb + (size_t)(r(k) / G3_LB) * G3_LB * G3_LB * es);
+  };
+  auto update = [&](int k, int64_t c0, int64_t c1) -> int {   // columns [c0, c1) of Y with panel k
+    return g3i_gemm_nt(ctx, Yp(c0), ldy, Yp(r(k)), ldy, Lp(c0, r(k)), ldl, r(k + 1), c1 - c0, r(k + 1) - r(k),
+                       -1.0, 1.0, dt, 0);
+  };
+  auto syrk = [&](int k) -> int {
+    return g3i_gemm_nt(ctx, C, ldc, Yp(r(k)), ldy, Yp(r(k)), ldy, r(k + 1), r(k + 1), r(k + 1) - r(k), 1.0, 1.0,
+                       dt, 1);
+  };
+  rc = panel(0);
+  if (rc) return rc;
+  if (two) G3_HIP(hipEventRecord(evP[0], sA));
+  for (int k = 0; k + 1 < nblk; ++k) {
+    const int64_t r2 = r(k + 2), r3 = r(k + 3);
+    // bulk stream: columns beyond the next panel, then this panel's share of K^-1
+    if (two) G3_HIP(hipStreamWaitEvent(sB, evP[k], 0));
+    ctx->stream = sB;
+    if (r2 < n) {
+      rc = update(k, r2, r3);
+      if (!rc && two && hipEventRecord(evB[k], sB) != hipSuccess) rc = G3_ERR_HIP;
+      if (!rc && r3 < n) rc = update(k, r3, n);
+    } else if (two && hipEventRecord(evB[k], sB) != hipSuccess) {
+      rc = G3_ERR_HIP;
+    }
+    if (!rc) rc = syrk(k);
+    ctx->stream = sA;
+    if (rc) return rc;
+    // critical path: next panel
+    if (two && k >= 1) G3_HIP(hipStreamWaitEvent(sA, evB[k - 1], 0));
+    rc = update(k, r(k + 1), r2);
+    if (rc) return rc;
+    rc = panel(k + 1);
+    if (rc) return rc;
+    if (two) G3_HIP(hipEventRecord(evP[k + 1], sA));
+  }
+  if (two) G3_HIP(hipStreamWaitEvent(sB, evP[nblk - 1], 0));
+  ctx->stream = sB;
+  rc = syrk(nblk - 1);
+  ctx->stream = sA;
+  if (rc) return rc;
+  if (two) {
+    G3_HIP(hipEventRecord(evB[nblk], sB));
+    G3_HIP(hipStreamWaitEvent(sA, evB[nblk], 0));
+  }
+  return G3_OK;
+}
+
+extern "C" int g3_potri(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, const void* invd_dev, g3_dtype dt,
+                        void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc) {
+  if (!ctx) return -1;
+  if (!L_dev) return -2;
+  if (n < 0 || n % G3_LB) return -3;
+  const int64_t al = 16 / (int64_t)g3_esize(dt);
+  if (ldl < n || ldl % al) return -4;
+  if (!Y_dev) return -7;
+  if (ldy < n || ldy % al) return -8;
+  if (!Kinv_dev) return -9;
+  if (ldc < n || ldc % al) return -10;
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  if (!invd_dev) {
+    rc = g3i_ensure_invd(ctx, n, dt);
+    if (rc) return rc;
+    rc = g3i_trtri_blocks(ctx, L_dev, n, ldl, dt, ctx->invd);
+    if (rc) return rc;
+    invd_dev = ctx->invd;
+  }
+  return g3i_potri(ctx, L_dev, n, ldl, invd_dev, dt, Y_dev, ldy, Kinv_dev, ldc);
+}
+
+// ------------------------------------------------------------------------------------------
+// sum_ij G_ij dK_ij / dtheta
+// ------------------------------------------------------------------------------------------
+extern "C" int g3_grad_layout(const g3_kernel_prog* prog, g3_grad_map* map) {
+  if (!prog) return -1;
+  if (!map) return -2;
+  if (prog->nleaf < 0 || prog->nleaf > G3_MAXLEAF) return -1;
+  int s = 0;
+  for (int l = 0; l < G3_MAXLEAF; ++l) map->var[l] = map->alpha[l] = map->rate[l] = map->freq[l] = -1;
+  for (int l = 0; l < prog->nleaf; ++l) {
+    const g3_leaf& lf = prog->leaf[l];
+    const int nd = lf.ndims;
+    map->var[l] = s++;
+    switch (lf.kind) {
+      case G3_K_SE: case G3_K_OU: case G3_K_MAT32: case G3_K_MAT52:
+        map->rate[l] = s; s += nd; break;
+      case G3_K_RQ:
+        map->alpha[l] = s++; map->rate[l] = s; s += nd; break;
+      case G3_K_COS: case G3_K_SINC:
+        map->freq[l] = s; s += nd; break;
+      case G3_K_SIN: case G3_K_SM:
+        map->freq[l] = s; s += nd; map->rate[l] = s; s += nd; break;
+      default: break;
+    }
+  }
+  map->nslots = s;
+  return G3_OK;
+}
+
+// thread-private accumulators in LDS: slot-major so that a wave touches 64 consecutive doubles
+struct SlotAcc {
+  double* acc;     // [window][GG_THREADS]
+  int lo, width, tid;
+  __device__ __forceinline__ void operator()(int slot, double v) const {
+    const unsigned s = (unsigned)(slot - lo);
+    if (s < (unsigned)width) acc[s * GG_THREADS + tid] += v;
+  }
+};
+
+// unit-variance value of a leaf for the pair and, through `add`, w * d(var * k)/d(param) for
+// every parameter of the leaf (w = G_ij * dK/d(leaf value)).  Formulas follow the leaf
+// definitions in g3_gram.hip (kernels.py:388-487, metrics.py:89-102).
+template <typename Acc>
+__device__ __forceinline__ void leaf_grad(const g3_leaf& lf, int l, const g3_grad_map& map, const double* xi,
+                                          const double* xj, bool diag, double w, const Acc& add) {
+  const int nd = lf.ndims;
+  const double var = lf.var;
+  const double wv = w * var;
+  switch (lf.kind) {
+    case G3_K_NOISE:
+    case G3_K_WN:
+      if (diag) add(map.var[l], w);
+      return;
+    case G3_K_SE:
+    case G3_K_MAT32:
+    case G3_K_MAT52:
+    case G3_K_RQ: {
+      double D = 0.0;
+      for (int k = 0; k < nd; ++k) {
+        const double dx = xi[lf.dims[k]] - xj[lf.dims[k]];
+        D += (dx * dx) * (0.5 * lf.rate[k] * lf.rate[k]);
+      }
+      double kv, dkdD;
+      if (lf.kind == G3_K_SE) {
+        kv = exp(-D); dkdD = -kv;
+      } else if (lf.kind == G3_K_MAT32) {
+        const double s = sqrt(3.0 * D), e = exp(-s);
+        kv = (1.0 + s) * e; dkdD = -1.5 * e;
+      } else if (lf.kind == G3_K_MAT52) {
+        const double s = sqrt(5.0 * D), e = exp(-s);
+        kv = (1.0 + s + 5.0 * D / 3.0) * e; dkdD = -(5.0 / 6.0) * (1.0 + s) * e;
+      } else {
+        const double al = lf.alpha, b = 1.0 + D / al;
+        kv = pow(b, -al); dkdD = -kv / b;
+        add(map.alpha[l], wv * kv * (-log(b) + D / (al + D)));
+      }
+      add(map.var[l], w * kv);
+      const double c = wv * dkdD;
+      for (int k = 0; k < nd; ++k) {
+        const double dx = xi[lf.dims[k]] - xj[lf.dims[k]];
+        add(map.rate[l] + k, c * lf.rate[k] * (dx * dx));
+      }
+      return;
+    }
+    case G3_K_OU: {
+      double D = 0.0;
+      for (int k = 0; k < nd; ++k) D += fabs(xi[lf.dims[k]] - xj[lf.dims[k]]) * lf.rate[k];
+      const double kv = exp(-D);
+      add(map.var[l], w * kv);
+      for (int k = 0; k < nd; ++k) add(map.rate[l] + k, -wv * kv * fabs(xi[lf.dims[k]] - xj[lf.dims[k]]));
+      return;
+    }
+    case G3_K_SIN: {
+      double s = 0.0;
+      for (int k = 0; k < nd; ++k) {
+        const double v = sin(GG_PI * (xi[lf.dims[k]] - xj[lf.dims[k]]) * lf.freq[k]);
+        s += (v * v) * lf.rate[k];
+      }
+      const double kv = exp(2.0 * s);
+      add(map.var[l], w * kv);
+      for (int k = 0; k < nd; ++k) {
+        const double dx = xi[lf.dims[k]] - xj[lf.dims[k]];
+        const double v = sin(GG_PI * dx * lf.freq[k]);
+        add(map.rate[l] + k, wv * kv * 2.0 * (v * v));
+        add(map.freq[l] + k, wv * kv * (2.0 * GG_PI) * lf.rate[k] * dx * sin(2.0 * GG_PI * dx * lf.freq[k]));
+      }
+      return;
+    }
+    case G3_K_COS:
+    case G3_K_SINC:
+    case G3_K_SM: {
+      // value = env * prod_k f_k ; d/dfreq_m = env * f'_m * prod_{k != m} f_k
+      const bool sinc = lf.kind == G3_K_SINC;
+      const double cs = sinc ? 2.0 * GG_PI * GG_PI : 2.0 * GG_PI;
+      double p = 1.0, s = 0.0;
+      for (int k = 0; k < nd; ++k) {
+        const double dx = xi[lf.dims[k]] - xj[lf.dims[k]];
+        const double th = cs * dx * lf.freq[k];
+        p *= sinc ? (dx != 0.0 ? sin(th) / th : 1.0) : cos(th);
+        s += (dx * dx) * (lf.rate[k] * lf.rate[k]);
+      }
+      const double env = lf.kind == G3_K_SM ? exp(-2.0 * GG_PI * GG_PI * s) : 1.0;
+      const double kv = env * p;
+      add(map.var[l], w * kv);
+      for (int m = 0; m < nd; ++m) {
+        const double dx = xi[lf.dims[m]] - xj[lf.dims[m]];
+        const double th = cs * dx * lf.freq[m];
+        double fm, dfm;
+        if (sinc) {
+          fm = dx != 0.0 ? sin(th) / th : 1.0;
+          dfm = dx != 0.0 ? (cos(th) - fm) / lf.freq[m] : 0.0;
+        } else {
+          fm = cos(th);
+          dfm = -cs * dx * sin(th);
+        }
+        double others;
+        if (fm != 0.0) {
+          others = p / fm;
+        } else {
+          others = 1.0;
+          for (int k = 0; k < nd; ++k) {
+            if (k == m) continue;
+            const double dk = xi[lf.dims[k]] - xj[lf.dims[k]];
+            const double tk = cs * dk * lf.freq[k];
+            others *= sinc ? (dk != 0.0 ? sin(tk) / tk : 1.0) : cos(tk);
+          }
+        }
+        add(map.freq[l] + m, wv * env * dfm * others);
+        if (lf.kind == G3_K_SM) add(map.rate[l] + m, wv * kv * (-4.0 * GG_PI * GG_PI) * (dx * dx) * lf.rate[m]);
+      }
+      return;
+    }
+    default:
+      return;
+  }
+}
+
+// value of a leaf (variance included) for the pair, in fp64
+__device__ __forceinline__ double leaf_value(const g3_leaf& lf, const double* xi, const double* xj, bool diag) {
+  const int nd = lf.ndims;
+  switch (lf.kind) {
+    case G3_K_NOISE:
+    case G3_K_WN:
+      return diag ? lf.var : 0.0;
+    case G3_K_SE: case G3_K_MAT32: case G3_K_MAT52: case G3_K_RQ: {
+      double D = 0.0;
+      for (int k = 0; k < nd; ++k) {
+        const double dx = xi[lf.dims[k]] - xj[lf.dims[k]];
+        D += (dx * dx) * (0.5 * lf.rate[k] * lf.rate[k]);
+      }
+      if (lf.kind == G3_K_SE) return lf.var * exp(-D);
+      if (lf.kind == G3_K_MAT32) { const double s = sqrt(3.0 * D); return lf.var * ((1.0 + s) * exp(-s)); }
+      if (lf.kind == G3_K_MAT52) { const double s = sqrt(5.0 * D); return lf.var * ((1.0 + s + 5.0 * D / 3.0) * exp(-s)); }
+      return lf.var * pow(1.0 + D / lf.alpha, -lf.alpha);
+    }
+    case G3_K_OU: {
+      double D = 0.0;
+      for (int k = 0; k < nd; ++k) D += fabs(xi[lf.dims[k]] - xj[lf.dims[k]]) * lf.rate[k];
+      return lf.var * exp(-D);
+    }
+    case G3_K_SIN: {
+      double s = 0.0;
+      for (int k = 0; k < nd; ++k) {
+        const double v = sin(GG_PI * (xi[lf.dims[k]] - xj[lf.dims[k]]) * lf.freq[k]);
+        s += (v * v) * lf.rate[k];
+      }
+      return lf.var * exp(2.0 * s);
+    }
+    case G3_K_COS: case G3_K_SINC: case G3_K_SM: {
+      const bool sinc = lf.kind == G3_K_SINC;
+      const double cs = sinc ? 2.0 * GG_PI * GG_PI : 2.0 * GG_PI;
+      double p = 1.0, s = 0.0;
+      for (int k = 0; k < nd; ++k) {
+        const double dx = xi[lf.dims[k]] - xj[lf.dims[k]];
+        const double th = cs * dx * lf.freq[k];
+        p *= sinc ? (dx != 0.0 ? sin(th) / th : 1.0) : cos(th);
+        s += (dx * dx) * (lf.rate[k] * lf.rate[k]);
+      }
+      return lf.var * (lf.kind == G3_K_SM ? exp(-2.0 * GG_PI * GG_PI * s) * p : p);
+    }
+    default:
+      return 0.0;
+  }
+}
+
+// One workgroup walks 64 x 64 tiles of the lower triangle (grid-stride).  Thread t owns column
+// t & 63 and rows (t >> 6) + 4 r of the tile; G rows are read 512 B at a time per wave.
+template <typename T>
+__global__ void __launch_bounds__(GG_THREADS)
+gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const T* __restrict__ X, int64_t N,
+                 int64_t ldx, int d, const T* __restrict__ G, int64_t ldg, const T* __restrict__ alpha,
+                 double* __restrict__ partial, int lo, int width) {
+  extern __shared__ __attribute__((aligned(16))) char smem_gg[];
+  const int dp = d | 1;
+  double* xi_s = (double*)smem_gg;             // GG_T x dp
+  double* xj_s = xi_s + GG_T * dp;             // GG_T x dp
+  double* ai_s = xj_s + GG_T * dp;             // GG_T
+  double* aj_s = ai_s + GG_T;                  // GG_T
+  double* lv_s = aj_s + GG_T;                  // G3_MAXLEAF x GG_THREADS
+  double* acc_s = lv_s + G3_MAXLEAF * GG_THREADS;   // width x GG_THREADS
+  const int tid = threadIdx.x;
+  for (int s = 0; s < width; ++s) acc_s[s * GG_THREADS + tid] = 0.0;
+  const SlotAcc add{acc_s, lo, width, tid};
+  const int nleaf = prog->nleaf, nprod = prog->nprod;
+  const int64_t nt = (N + GG_T - 1) / GG_T;
+  const int64_t ntiles = nt * (nt + 1) / 2;
+  for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    int64_t bi = (int64_t)((sqrt(1.0 + 8.0 * (double)id) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
+    while (bi * (bi + 1) / 2 > id) --bi;
+    const int64_t bj = id - bi * (bi + 1) / 2;
+    const int64_t i0 = bi * GG_T, j0 = bj * GG_T;
+    __syncthreads();
+    for (int e = tid; e < GG_T * d; e += GG_THREADS) {
+      const int r = e / d, c = e - r * d;
+      xi_s[r * dp + c] = i0 + r < N ? (double)X[(i0 + r) * ldx + c] : 0.0;
+      xj_s[r * dp + c] = j0 + r < N ? (double)X[(j0 + r) * ldx + c] : 0.0;
+    }
+    if (tid < GG_T) ai_s[tid] = i0 + tid < N ? (double)alpha[i0 + tid] : 0.0;
+    else if (tid < 2 * GG_T) aj_s[tid - GG_T] = j0 + tid - GG_T < N ? (double)alpha[j0 + tid - GG_T] : 0.0;
+    __syncthreads();
+    const int c = tid & (GG_T - 1);
+    const int64_t j = j0 + c;
+    const double* xj = xj_s + c * dp;
+    for (int rr = tid >> 6; rr < GG_T; rr += GG_THREADS / GG_T) {
+      const int64_t i = i0 + rr;
+      if (i >= N || j > i) continue;
+      const bool diag = i == j;
+      const double* xi = xi_s + rr * dp;
+      // G_ij with the symmetric pair (j, i) folded in
+      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj_s[c] - (double)G[i * ldg + j]);
+      for (int l = 0; l < nleaf; ++l) lv_s[l * GG_THREADS + tid] = leaf_value(prog->leaf[l], xi, xj, diag);
+      for (int l = 0; l < nleaf; ++l) {
+        // dK/d(leaf l) = sum over the products that contain it of coef * the other factors
+        double q = 0.0;
+        for (int p = 0; p < nprod; ++p) {
+          const g3_prod& pr = prog->prod[p];
+          bool has = false;
+          double v = pr.coef;
+          for (int f = 0; f < pr.nfac; ++f) {
+            if (pr.fac[f] == l && !has) has = true;
+            else v *= lv_s[pr.fac[f] * GG_THREADS + tid];
+          }
+          if (has) q += v;
+        }
+        if (q != 0.0) leaf_grad(prog->leaf[l], l, map, xi, xj, diag, g * q, add);
+      }
+    }
+  }
+  __syncthreads();
+  // block reduction: wave w sums slots w, w + 4, ...
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int s = wv; s < width; s += GG_THREADS / 64) {
+    double v = 0.0;
+    for (int q = 0; q < GG_THREADS / 64; ++q) v += acc_s[s * GG_THREADS + q * 64 + lane];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) partial[(size_t)blockIdx.x * width + s] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+grad_reduce_kernel(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int s = blockIdx.x;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) v += partial[(size_t)b * width + s];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[s] = red[0];
+}
+
+int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N,
+                  int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host) {
+  const int nslots = map->nslots;
+  if (nslots == 0 || N == 0) {
+    for (int s = 0; s < nslots; ++s) out_host[s] = 0.0;
+    return G3_OK;
+  }
+  const g3_kernel_prog* dprog = nullptr;
+  int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
+  if (rc) return rc;
+  const int dp = d | 1;
+  const size_t fixed = ((size_t)2 * GG_T * dp + 2 * GG_T + (size_t)G3_MAXLEAF * GG_THREADS) * sizeof(double);
+  const size_t lds_max = 160 * 1024;
+  int window = (int)((lds_max - fixed) / (GG_THREADS * sizeof(double)));
+  if (window > 32) window = 32;      // keeps two workgroups per CU for the usual d
+  if (window > nslots) window = nslots;
+  if (window < 1) return G3_ERR_NOMEM;
+  const int64_t nt = (N + GG_T - 1) / GG_T;
+  const int64_t ntiles = nt * (nt + 1) / 2;
+  const int nblocks = (int)(ntiles < 2048 ? ntiles : 2048);
+  const size_t pbytes = (size_t)nblocks * window * sizeof(double);
+  const size_t obytes = (size_t)g3_roundup(nslots, 32) * sizeof(double);
+  rc = g3i_ensure_work(ctx, pbytes + obytes);
+  if (rc) return rc;
+  double* partial = (double*)ctx->work;
+  double* dout = (double*)((char*)ctx->work + pbytes);
+  const size_t lds = fixed + (size_t)window * GG_THREADS * sizeof(double);
+  if (dt == G3_F64)
+    G3_HIP(hipFuncSetAttribute((const void*)gram_grad_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else
+    G3_HIP(hipFuncSetAttribute((const void*)gram_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * (N + 1) / 2 * g3_esize(dt));
+  for (int lo = 0; lo < nslots; lo += window) {
+    const int width = nslots - lo < window ? nslots - lo : window;
+    if (dt == G3_F64)
+      hipLaunchKernelGGL((gram_grad_kernel<double>), dim3(nblocks), dim3(GG_THREADS), lds, ctx->stream, dprog, *map,
+                         (const double*)X, N, ldx, d, (const double*)G, ldg, (const double*)alpha, partial, lo, width);
+    else
+      hipLaunchKernelGGL((gram_grad_kernel<float>), dim3(nblocks), dim3(GG_THREADS), lds, ctx->stream, dprog, *map,
+                         (const float*)X, N, ldx, d, (const float*)G, ldg, (const float*)alpha, partial, lo, width);
+    G3_LAUNCH_CHECK();
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(width), dim3(256), 0, ctx->stream, partial, nblocks, width, dout + lo);
+    G3_LAUNCH_CHECK();
+  }
+  g3i_prof_end(ctx, rec);
+  G3_HIP(hipMemcpyAsync(out_host, dout, (size_t)nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  return G3_OK;
+}
+
+static int check_map(const g3_kernel_prog* prog, const g3_grad_map* map) {
+  if (map->nslots < 0 || map->nslots > G3_GRAD_MAXSLOTS) return 1;
+  for (int l = 0; l < prog->nleaf; ++l) {
+    const int nd = prog->leaf[l].ndims;
+    const int32_t v[4] = {map->var[l], map->alpha[l], map->rate[l], map->freq[l]};
+    const int w[4] = {1, 1, nd, nd};
+    for (int q = 0; q < 4; ++q)
+      if (v[q] < -1 || (v[q] >= 0 && v[q] + w[q] > map->nslots)) return 1;
+  }
+  return 0;
+}
+
+extern "C" int g3_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev,
+                            int64_t N, int64_t ldx, int d, g3_dtype dt, const void* G_dev, int64_t ldg,
+                            const void* alpha_dev, double* out_host) {
+  if (!ctx) return -1;
+  if (!prog || prog->nleaf < 0 || prog->nleaf > G3_MAXLEAF || prog->nprod < 0 || prog->nprod > G3_MAXPROD) return -2;
+  if (!map || check_map(prog, map)) return -3;
+  if (!X_dev && N > 0) return -4;
+  if (N < 0) return -5;
+  if (d < 1 || d > G3_MAXCOLS) return -7;
+  if (ldx < d) return -6;
+  if (!G_dev && N > 0) return -9;
+  if (ldg < N) return -10;
+  if (!alpha_dev && N > 0) return -11;
+  if (!out_host) return -12;
+  return g3i_gram_grad(ctx, prog, map, X_dev, N, ldx, d, dt, G_dev, ldg, alpha_dev, out_host);
+}
+
+// Fused: K^-1 and alpha from a factor produced by g3_gp_factor, then the hyper-parameter sums.
+extern "C" int g3_gp_dlogp(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev,
+                           int64_t N, int64_t ldx, int d, const void* L_dev, int64_t ldl, const void* invd_dev,
+                           const void* a_dev, g3_dtype dt, void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc,
+                           void* alpha_dev, double* out_host) {
+  if (!ctx) return -1;
+  if (!prog || prog->nleaf < 0 || prog->nleaf > G3_MAXLEAF || prog->nprod < 0 || prog->nprod > G3_MAXPROD) return -2;
+  if (!map || check_map(prog, map)) return -3;
+  if (!X_dev) return -4;
+  if (N <= 0) return -5;
+  if (d < 1 || d > G3_MAXCOLS) return -7;
+  if (ldx < d) return -6;
+  const int64_t Np = g3_roundup(N, G3_LB), al = 16 / (int64_t)g3_esize(dt);
+  if (!L_dev) return -8;
+  if (ldl < Np || ldl % al) return -9;
+  if (!invd_dev) return -10;
+  if (!a_dev) return -11;
+  if (!Y_dev) return -13;
+  if (ldy < Np || ldy % al) return -14;
+  if (!Kinv_dev) return -15;
+  if (ldc < Np || ldc % al) return -16;
+  if (!alpha_dev) return -17;
+  if (!out_host) return -18;
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  int rec = g3i_prof_begin(ctx, G3_TAG_POTRF, 2.0 * (double)N * N * N / 3.0);
+  rc = g3i_potri(ctx, L_dev, Np, ldl, invd_dev, dt, Y_dev, ldy, Kinv_dev, ldc);
+  g3i_prof_end(ctx, rec);
+  if (rc) return rc;
+  // alpha = L^-T a = Y a  (row i of Y dotted with a)
+  rc = g3_rows_dot_ss(ctx, Y_dev, Np, Np, ldy, a_dev, dt, alpha_dev, nullptr);
+  if (rc) return rc;
+  return g3i_gram_grad(ctx, prog, map, X_dev, N, ldx, d, dt, Kinv_dev, ldc, alpha_dev, out_host);
+}

@@ -89,3 +89,5 @@ int g3i_reset_info(g3_ctx* ctx);
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt);
 int g3i_ensure_work(g3_ctx* ctx, size_t bytes);
 int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr);
+int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* invd, g3_dtype dt, void* Y,
+              int64_t ldy, void* C, int64_t ldc);

@@ -218,6 +218,32 @@ class Device:
                                   mu.ptr if mu is not None else None, ss.ptr if ss is not None else None)
         _check(self, rc, 'g3_gp_cross')
 
+    # ---- gradient of logp
+    def grad_layout(self, prog):
+        m = _lib.GradMap()
+        _check(self, self.lib.g3_grad_layout(C.byref(prog), C.byref(m)), 'g3_grad_layout')
+        return m
+
+    def potri(self, L, n, W, Y, Kinv):
+        rc = self.lib.g3_potri(self.ctx, L.ptr, n, L.ld, W.ptr if W is not None else None,
+                               _lib.dtype_code(L.dtype), Y.ptr, Y.ld, Kinv.ptr, Kinv.ld)
+        _check(self, rc, 'g3_potri')
+
+    def gram_grad(self, prog, gmap, X, N, d, Kinv, alpha):
+        out = (C.c_double * max(gmap.nslots, 1))()
+        rc = self.lib.g3_gram_grad(self.ctx, C.byref(prog), C.byref(gmap), X.ptr, N, X.ld, d,
+                                   _lib.dtype_code(Kinv.dtype), Kinv.ptr, Kinv.ld, alpha.ptr, out)
+        _check(self, rc, 'g3_gram_grad')
+        return np.array(out[:gmap.nslots])
+
+    def gp_dlogp(self, prog, gmap, X, N, d, L, W, a, Y, Kinv, alpha):
+        """after gp_factor: K^-1, alpha = K^-1 delta and 1/2 sum G_ij dK_ij/dparam per slot"""
+        out = (C.c_double * max(gmap.nslots, 1))()
+        rc = self.lib.g3_gp_dlogp(self.ctx, C.byref(prog), C.byref(gmap), X.ptr, N, X.ld, d, L.ptr, L.ld, W.ptr,
+                                  a.ptr, _lib.dtype_code(L.dtype), Y.ptr, Y.ld, Kinv.ptr, Kinv.ld, alpha.ptr, out)
+        _check(self, rc, 'g3_gp_dlogp')
+        return np.array(out[:gmap.nslots])
+
 
 # --------------------------------------------------------------------------- kernel programs
 def _expand(spec, leaves):
@@ -246,6 +272,13 @@ def _expand(spec, leaves):
         return float(spec[1]) + c, t
     leaves.append(spec)
     return 0.0, [(1.0, (len(leaves) - 1,))]
+
+
+def spec_leaves(spec):
+    """the leaves of a spec tree in the order compile_spec numbers them"""
+    leaves = []
+    _expand(spec, leaves)
+    return leaves
 
 
 def compile_spec(spec, d):

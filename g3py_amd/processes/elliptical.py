@@ -129,6 +129,7 @@ class EllipticalProcess(StochasticProcess):
         st = dev.gp_factor(prog, c['Xd'], c['N'], c['d'], dvec, c['Kd'], c['Wd'], c['ad'])
         st['delta_finite'] = bool(finite)
         c['stats'], c['which'] = st, which
+        c['grad'] = None            # K^-1 / alpha pieces of th_dlogp belong to this factorisation
         return st
 
     def _cross(self, c, values, space, noise, kernel=None):

@@ -26,6 +26,18 @@ def logp_cho_diag(value, mu, sd, mapping, values, dtype):
     return r
 
 
+class _Ref:
+    """placeholder a kernel's spec() carries where a free hyper-parameter's value would go"""
+
+    def __init__(self, name):
+        self.name = name
+
+
+class _Refs(dict):
+    def __getitem__(self, name):
+        return _Ref(name)
+
+
 class GaussianProcess(EllipticalProcess):
     def __init__(self, *args, **kwargs):
         if 'name' not in kwargs:
@@ -57,6 +69,83 @@ class GaussianProcess(EllipticalProcess):
         if prior:
             return t(logjac)
         return t(logjac + self.th_loglike(space, inputs, outputs, vector, params))
+
+    # ---- gradient of logp (stochastic.py:308-309; tensors.py:11-22, 224-260)
+    def th_dlogp(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        """tt_to_num(gradient(th_logp, free variables)): flat vector over the model's variables in
+        creation order, in TRANSFORMED space (d/d log h = h * d/dh for the FlatExp hypers).
+        The reference differentiates the Theano graph; the same chain rule in closed form is
+            d loglike = 1/2 sum_ij (alpha alpha^T - K^-1)_ij dK_ij  +  alpha . dm  -  alpha . dT^-1(y)  +  d logdet
+        with K the (possibly jittered) matrix that was factored -- CholeskyRobust.grad re-uses the
+        jittered factor the same way -- and zero when logp takes its constant -1e30 branch.
+        K^-1 and the kernel-parameter sums are computed on the device (g3_gp_dlogp)."""
+        values, _ = self._values(params)
+        nat = {v.name: np.zeros(v.shape, dtype=np.float64) for v in self.model.vars}
+        for _, reg, c, sel in self.model.potentials:                # hypers/__init__.py:97-109
+            for h in sel:
+                hv = np.asarray(values[h.name], dtype=np.float64)
+                nat[h.name] = nat[h.name] + (-c * np.sign(hv) if reg == 'L1' else -2.0 * c * hv)
+        if not prior:
+            ll = self.th_loglike(space, inputs, outputs, vector, params)
+            if np.isfinite(ll) and ll != self.dtype.type(SENTINEL):
+                self._dloglike(values, inputs, outputs, nat)
+        flat = []
+        for v in self.model.vars:
+            g = np.asarray(nat[v.name], dtype=np.float64).reshape(v.shape)
+            if v.positive:
+                g = g * np.asarray(values[v.name], dtype=np.float64)
+            flat.append(g.reshape(-1))
+        flat = np.concatenate(flat) if flat else np.zeros(0)
+        flat = np.where(np.isnan(flat), 0.0, np.where(np.isinf(flat), float(np.float32(1e10)), flat))   # tt_to_num
+        return flat.astype(self.dtype)
+
+    def _dloglike(self, values, inputs, outputs, nat):
+        """adds d loglike / d (natural-space hyper) into `nat`"""
+        from ..device import spec_leaves
+        dev = self.device
+        c = self._factor(values, inputs, outputs)
+        self._solve(c, values, 'logp')
+        N, d, Np = c['N'], c['d'], c['Np']
+        if c.get('grad') is None:
+            prog = self._prog(self.f_kernel_noise, values, d)
+            gmap = dev.grad_layout(prog)
+            Y = dev.alloc(Np, Np, self.dtype)
+            Kinv = dev.alloc(Np, Np, self.dtype)
+            alpha = dev.alloc(1, Np, self.dtype)
+            slots = dev.gp_dlogp(prog, gmap, c['Xd'], N, d, c['Kd'], c['Wd'], c['ad'], Y, Kinv, alpha)
+            c['grad'] = dict(prog=prog, gmap=gmap, slots=slots, alpha=dev.download(alpha, 1, N)[0].astype(np.float64))
+            del Y, Kinv                                   # 2 N^2 of HBM: released as soon as the sums exist
+        g = c['grad']
+        prog, gmap, slots, alpha = g['prog'], g['gmap'], g['slots'], g['alpha']
+        # kernel hypers: leaf parameter slots -> the HyperVars that fed them
+        by_name = {v.name: v for v in self.model.vars}
+        refs = spec_leaves(self.f_kernel_noise.spec(_Refs(), d))
+        fields = {'SE': dict(rate=2), 'OU': dict(rate=2), 'MAT32': dict(rate=2), 'MAT52': dict(rate=2),
+                  'RQ': dict(rate=2, alpha=3), 'COS': dict(freq=2), 'SINC': dict(freq=2),
+                  'SIN': dict(freq=2, rate=3), 'SM': dict(freq=2, rate=3), 'NOISE': {}, 'WN': {}}
+        for l, lf in enumerate(refs):
+            nd = prog.leaf[l].ndims
+            for pname, idx in dict(var=1, **fields[lf[0]]).items():
+                ref = lf[idx]
+                if not isinstance(ref, _Ref) or ref.name not in by_name:
+                    continue
+                slot = getattr(gmap, pname)[l]
+                if pname in ('var', 'alpha'):
+                    nat[ref.name] = nat[ref.name] + slots[slot]
+                else:
+                    gk = slots[slot:slot + nd]
+                    nat[ref.name] = nat[ref.name] + (gk if by_name[ref.name].shape else gk.sum())
+        # location and warping hypers: O(N) host arithmetic on alpha = K^-1 delta
+        X = self._x(inputs)
+        y = np.asarray(outputs, dtype=self.dtype).reshape(-1)
+        for h, J in self.f_location.grad(X, values):
+            if getattr(h, 'name', None) in by_name:
+                gj = alpha.dot(np.asarray(J, dtype=np.float64))
+                nat[h.name] = nat[h.name] + (gj.reshape(by_name[h.name].shape) if by_name[h.name].shape else gj.sum())
+        with np.errstate(all='ignore'):
+            for h, dinv, dlogdet in self.f_mapping.grad(y, values):
+                if getattr(h, 'name', None) in by_name:
+                    nat[h.name] = nat[h.name] + (-alpha.dot(np.asarray(dinv, dtype=np.float64)) + float(dlogdet))
 
     def th_logpredictive(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         loc, sd, values = self._loc_sd(space, inputs, outputs, params, prior, noise, sd_noise=True)
@@ -92,6 +181,9 @@ class GaussianProcess(EllipticalProcess):
         dev.gemm_nt(out, Zt, Ld, Sp, Mp, Mp)                      # (L Z)^T
         g = loc[:, None] + dev.download(out, S, M).T
         return np.array([self.mapping(params, space, inputs, outputs=k.T) for k in g.T]).T
+
+
+    _methods = EllipticalProcess._methods + (('dlogp', 'th_dlogp'),)
 
 
 class WarpedGaussianProcess(GaussianProcess):

@@ -16,6 +16,11 @@ class Mapping(Hypers):
     def logdet_dinv(self, y, values=None):
         raise NotImplementedError
 
+    def grad(self, y, values=None):
+        """[(hyper, d inv(y) / d hyper (length N), d logdet_dinv(y) / d hyper)] in natural space:
+        the pieces th_dlogp needs from the warping (mappings.py:88-215, 309-333 differentiated)"""
+        return []
+
 
 class Identity(Mapping):
     def __init__(self, y=None, name=None):
@@ -62,6 +67,11 @@ class LinearMapping(Mapping):
         shift, scale = self._p(values, y.dtype.type)
         return -y.dtype.type(y.shape[0]) * np.log(scale)
 
+    def grad(self, y, values=None):
+        t = y.dtype.type
+        shift, scale = self._p(values, t)
+        return [(self.shift, np.ones_like(y), t(0)), (self.scale, -y / scale ** 2, -t(y.shape[0]) / scale)]
+
 
 class LogShifted(Mapping):
     def __init__(self, y=None, name=None, shift=None):
@@ -86,6 +96,12 @@ class LogShifted(Mapping):
     def logdet_dinv(self, y, values=None):
         with np.errstate(all='ignore'):
             return -np.sum(np.log(y - y.dtype.type(value_of(self.shift, values))))
+
+    def grad(self, y, values=None):
+        t = y.dtype.type
+        z = y - t(value_of(self.shift, values))
+        with np.errstate(all='ignore'):
+            return [(self.shift, np.where(z > t(np.float32(1e-32)), -1 / z, t(0)), np.sum(1 / z))]
 
 
 class BoxCoxLinear(Mapping):
@@ -133,6 +149,23 @@ class BoxCoxLinear(Mapping):
         with np.errstate(all='ignore'):
             return (power - t(1)) * np.sum(np.log(np.abs(scale * (y + shift)))) + t(y.shape[0]) * np.log(scale)
 
+    def grad(self, y, values=None):
+        t = y.dtype.type
+        shift, scale, power = self._p(values, t)
+        n = t(y.shape[0])
+        sh = scale * (y + shift)
+        with np.errstate(all='ignore'):
+            a = np.abs(sh)
+            if power < np.float32(1e-5):
+                d_shift, d_scale, d_power = scale / sh, (y + shift) / sh, np.zeros_like(y)
+            else:
+                sp = np.sign(sh) * a ** power
+                d_shift, d_scale = a ** (power - 1) * scale, a ** (power - 1) * (y + shift)
+                d_power = (sp * np.log(a) * power - (sp - 1)) / power ** 2
+            return [(self.shift, d_shift, (power - 1) * np.sum(1 / (y + shift))),
+                    (self.scale, d_scale, power * n / scale),
+                    (self.power, d_power, np.sum(np.log(a)))]
+
 
 class ArcsinhLinear(Mapping):
     def __init__(self, y=None, name=None, shift=None, scale=None):
@@ -165,3 +198,8 @@ class ArcsinhLinear(Mapping):
         t = y.dtype.type
         shift, scale = self._p(values, t)
         return t(y.shape[0]) * np.log(scale) - t(0.5) * np.sum(np.log1p(y ** 2))
+
+    def grad(self, y, values=None):
+        t = y.dtype.type
+        shift, scale = self._p(values, t)
+        return [(self.shift, np.ones_like(y), t(0)), (self.scale, np.arcsinh(y), t(y.shape[0]) / scale)]

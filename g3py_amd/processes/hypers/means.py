@@ -14,6 +14,15 @@ class Mean(Hypers):
         x = np.asarray(x)
         return self.eval(x[:, self.dims] if self.dims is not None else x, values or {})
 
+    def jac(self, x, values):
+        """[(hyper, d m(x) / d hyper as an N x size array)] for the free hypers -- what Theano's
+        reverse mode propagates through means.py:117-159 for th_dlogp"""
+        return []
+
+    def grad(self, x, values=None):
+        x = np.asarray(x)
+        return self.jac(x[:, self.dims] if self.dims is not None else x, values or {})
+
 Location = Mean
 
 
@@ -39,6 +48,9 @@ class Bias(Mean):
     def eval(self, x, values):
         return x.dtype.type(value_of(self.bias, values)) * np.ones(x.shape[0], dtype=x.dtype)
 
+    def jac(self, x, values):
+        return [(self.bias, np.ones((x.shape[0], 1), dtype=x.dtype))]
+
 
 class Linear(Mean):
     def __init__(self, x=None, name=None, constant=None, coeff=None):
@@ -60,3 +72,6 @@ class Linear(Mean):
     def eval(self, x, values):
         coeff = np.broadcast_to(np.asarray(value_of(self.coeff, values), dtype=x.dtype), (x.shape[1],))
         return x.dtype.type(value_of(self.constant, values)) + np.dot(x, coeff)
+
+    def jac(self, x, values):
+        return [(self.constant, np.ones((x.shape[0], 1), dtype=x.dtype)), (self.coeff, x)]

@@ -227,6 +227,51 @@ int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_de
                 int64_t ldl, const void* invd_dev, const void* a_dev, g3_dtype dt, void* V_dev, int64_t ldv,
                 void* mu_dev, void* ss_dev);
 
+/* ---- gradient of logp w.r.t. the kernel hyper-parameters ----
+ * Reference: StochasticProcess.th_dlogp = gradient(th_logp) (g3py/processes/stochastic.py:308-309;
+ * g3py/libs/tensors.py:11-22), i.e. Theano's reverse mode through logp_cho (gaussian.py:208-224)
+ * and CholeskyRobust.grad (tensors.py:224-260).  Closed form used here:
+ *     d logp / d theta = 1/2 sum_ij G_ij dK_ij/dtheta,   G = alpha alpha^T - K^-1,  alpha = K^-1 delta
+ * with K the matrix that was factored (grad() re-uses the possibly jittered factor the same way).
+ *
+ * g3_grad_map tells the device where each parameter of each leaf of a g3_kernel_prog goes in
+ * the output vector: slot index, or -1 to skip; `rate` / `freq` name the first of `ndims`
+ * consecutive slots.  g3_grad_layout fills the standard map (every parameter of every leaf, in
+ * leaf order: var, [alpha], [freq...], [rate...] as the leaf kind has them). */
+#define G3_GRAD_MAXSLOTS (G3_MAXLEAF * (2 + 2 * G3_MAXD))
+typedef struct g3_grad_map {
+  int32_t nslots;
+  int32_t var[G3_MAXLEAF];
+  int32_t alpha[G3_MAXLEAF];
+  int32_t rate[G3_MAXLEAF];
+  int32_t freq[G3_MAXLEAF];
+} g3_grad_map;
+int g3_grad_layout(const g3_kernel_prog* prog, g3_grad_map* map);
+
+/* From a lower Cholesky factor L (n x n, n a multiple of 128, identity padded) and the inverses
+ * of its 128 x 128 diagonal blocks (invd_dev, NULL = computed into the context's scratch):
+ * Y_dev <- L^-T (upper triangular, row-major) and the lower triangle of Kinv_dev <- (L L^T)^-1
+ * = Y Y^T.  2 n^3 / 3 flops in the MFMA GEMM (LAPACK dpotri's work), look-ahead on two streams. */
+int g3_potri(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, const void* invd_dev, g3_dtype dt,
+             void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc);
+
+/* out_host[slot] = 1/2 sum_{i,j < N} (alpha_i alpha_j - Kinv_ij) * d prog(x_i, x_j) / d param(slot)
+ * over the FULL symmetric index range (only the lower triangle of Kinv_dev is read).  Parameters
+ * are the natural-space `var`, `alpha`, `rate[k]`, `freq[k]` fields of the leaves; NOISE / WN
+ * leaves contribute on the diagonal (square case, kernels.py:360-385).  One pass over Kinv
+ * (HBM-read bound); partial sums are combined in a fixed order (bitwise reproducible). */
+int g3_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev,
+                 int64_t N, int64_t ldx, int d, g3_dtype dt, const void* Kinv_dev, int64_t ldc,
+                 const void* alpha_dev, double* out_host);
+
+/* Fused: after g3_gp_factor (L_dev = its K_dev, invd_dev, a_dev = L^-1 delta, roundup(N,128) long):
+ * g3_potri, alpha_dev <- L^-T a (roundup(N,128) entries), then g3_gram_grad.  Y_dev and Kinv_dev
+ * are roundup(N,128)-square workspaces / outputs. */
+int g3_gp_dlogp(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev,
+                int64_t N, int64_t ldx, int d, const void* L_dev, int64_t ldl, const void* invd_dev,
+                const void* a_dev, g3_dtype dt, void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc,
+                void* alpha_dev, double* out_host);
+
 /* ---- profiling (bench.py's live roofline measurement) -------------------------------------
  * When enabled, HIP-event pairs are recorded ON THE CONTEXT'S STREAM around every launch of
  * the MFMA GEMM (one tag per tile configuration) and around the phases of g3_gp_factor /

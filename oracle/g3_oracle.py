@@ -181,6 +181,95 @@ def with_noise(spec_f, noise_var):
     return ('sum', spec_f, ('NOISE', noise_var))
 
 
+def kernel_cov_grads(spec, x, dtype=np.float64, _leaf=None):
+    """Kernel.cov(x) (square) and its derivative with respect to every natural-space parameter of
+    every leaf of the spec tree.  The reference gets these by Theano reverse mode through the
+    formulas of kernels.py:96-110,192-244,360-487 / metrics.py:89-102; this is the same chain
+    rule written out.  Returns (K, grads) with grads a list of (leaf, pname, k, dK):
+    leaf = index of the leaf in left-to-right order, pname in {'var','rate','freq','alpha'},
+    k = position inside the rate / freq vector (None for scalars)."""
+    x = np.asarray(x, dtype=dtype)
+    if x.ndim == 1:
+        x = x[:, None]
+    if _leaf is None:
+        _leaf = [0]
+    op = spec[0]
+    if op in ('sum', 'prod'):
+        K1, g1 = kernel_cov_grads(spec[1], x, dtype, _leaf)
+        K2, g2 = kernel_cov_grads(spec[2], x, dtype, _leaf)
+        if op == 'sum':
+            return K1 + K2, g1 + g2
+        return K1 * K2, [(l, p, k, dK * K2) for l, p, k, dK in g1] + [(l, p, k, dK * K1) for l, p, k, dK in g2]
+    if op == 'scale':
+        K, g = kernel_cov_grads(spec[2], x, dtype, _leaf)
+        return spec[1] * K, [(l, p, k, spec[1] * dK) for l, p, k, dK in g]
+    if op == 'shift':
+        K, g = kernel_cov_grads(spec[2], x, dtype, _leaf)
+        return spec[1] + K, g
+    leaf = _leaf[0]
+    _leaf[0] += 1
+    var = spec[1]
+    unit = (op,) + (1.0,) + tuple(spec[2:])
+    k0 = kernel_cov(unit, x, None, dtype)            # unit-variance leaf
+    grads = [(leaf, 'var', None, k0)]
+    if op in ('NOISE', 'WN'):
+        return var * k0, grads
+    dims = spec[-1]
+    diff = _diff(x, x, dims)                         # n x n x nd
+    nd = diff.shape[2]
+    if op in ('SE', 'MAT32', 'MAT52', 'RQ'):
+        rate = np.broadcast_to(np.asarray(spec[2], dtype=dtype), (nd,))
+        D = np.dot(diff ** 2, 0.5 * rate ** 2)
+        if op == 'SE':
+            dkdD = -np.exp(-D)
+        elif op == 'MAT32':
+            dkdD = -1.5 * np.exp(-np.sqrt(3 * D))
+        elif op == 'MAT52':
+            s5 = np.sqrt(5 * D)
+            dkdD = -(5.0 / 6.0) * (1 + s5) * np.exp(-s5)
+        else:
+            al = spec[3]
+            b = 1 + D / al
+            dkdD = -np.power(b, -al - 1)
+            grads.append((leaf, 'alpha', None, var * k0 * (-np.log(b) + D / (al + D))))
+        for k in range(nd):
+            grads.append((leaf, 'rate', k, var * dkdD * rate[k] * diff[:, :, k] ** 2))
+    elif op == 'OU':
+        for k in range(nd):
+            grads.append((leaf, 'rate', k, -var * k0 * np.abs(diff[:, :, k])))
+    elif op == 'SIN':
+        f = np.broadcast_to(np.asarray(spec[2], dtype=dtype), (nd,))
+        r = np.broadcast_to(np.asarray(spec[3], dtype=dtype), (nd,))
+        for k in range(nd):
+            grads.append((leaf, 'freq', k, var * k0 * 2 * pi * r[k] * diff[:, :, k] * np.sin(2 * pi * diff[:, :, k] * f[k])))
+        for k in range(nd):
+            grads.append((leaf, 'rate', k, var * k0 * 2 * np.sin(pi * diff[:, :, k] * f[k]) ** 2))
+    elif op in ('COS', 'SINC', 'SM'):
+        f = np.broadcast_to(np.asarray(spec[2], dtype=dtype), (nd,))
+        cs = 2 * pi2 if op == 'SINC' else 2 * pi
+        th = cs * diff * f
+        with np.errstate(divide='ignore', invalid='ignore'):
+            if op == 'SINC':
+                fac = np.where(diff != 0, np.sin(th) / th, 1.0)
+                dfac = np.where(diff != 0, (np.cos(th) - fac) / f, 0.0)
+            else:
+                fac = np.cos(th)
+                dfac = -cs * diff * np.sin(th)
+        env = 1.0
+        if op == 'SM':
+            r = np.broadcast_to(np.asarray(spec[3], dtype=dtype), (nd,))
+            env = np.exp(-2 * pi2 * np.dot(diff ** 2, r ** 2))
+        for k in range(nd):
+            others = np.prod(np.delete(fac, k, axis=2), axis=2)
+            grads.append((leaf, 'freq', k, var * env * dfac[:, :, k] * others))
+        if op == 'SM':
+            for k in range(nd):
+                grads.append((leaf, 'rate', k, var * k0 * (-4 * pi2) * diff[:, :, k] ** 2 * r[k]))
+    else:
+        raise ValueError('unknown kernel spec ' + str(op))
+    return var * k0, grads
+
+
 # --------------------------------------------------------------------------- means
 def mean_eval(spec, x, dtype=np.float64):
     """Zero / Bias / Linear -- g3py/processes/hypers/means.py:117-159."""
@@ -196,6 +285,19 @@ def mean_eval(spec, x, dtype=np.float64):
         xs = x if len(spec) < 4 or spec[3] is None else x[:, spec[3]]
         return np.dtype(dtype).type(spec[1]) + np.dot(xs, np.asarray(spec[2], dtype=dtype))
     raise ValueError('unknown mean spec ' + str(op))
+
+
+def mean_grads(spec, x, dtype=np.float64):
+    """d m(x) / d(parameter): list of (pname, k, column) -- means.py:117-159 differentiated."""
+    x = np.asarray(x, dtype=dtype)
+    if x.ndim == 1:
+        x = x[:, None]
+    if spec[0] == 'Zero':
+        return []
+    if spec[0] == 'Bias':
+        return [('bias', None, np.ones(x.shape[0], dtype=dtype))]
+    xs = x if len(spec) < 4 or spec[3] is None else x[:, spec[3]]
+    return [('constant', None, np.ones(x.shape[0], dtype=dtype))] + [('coeff', k, xs[:, k]) for k in range(xs.shape[1])]
 
 
 # --------------------------------------------------------------------------- mappings
@@ -263,6 +365,57 @@ class Mapping:
         raise ValueError(s[0])
 
 
+    def dinv(self, y):
+        """d inv(y) / d(parameter), in the order of the spec (mappings.py:95-96,122-123,145-146,
+        209-211,329-330 differentiated): list of (pname, array)"""
+        s, t = self.spec, self.t
+        y = np.asarray(y)
+        one = np.ones_like(y)
+        if s[0] == 'Identity':
+            return []
+        if s[0] == 'LinearMapping':
+            return [('shift', one), ('scale', -y / t(s[2]) ** 2)]
+        if s[0] == 'LogShifted':
+            z = y - t(s[1])
+            with np.errstate(all='ignore'):
+                return [('shift', np.where(z > t(np.float32(1e-32)), -one / z, 0 * one))]
+        if s[0] == 'BoxCoxLinear':
+            shift, scale, power = t(s[1]), t(s[2]), t(s[3])
+            sh = scale * (y + shift)
+            with np.errstate(all='ignore'):
+                if power < np.float32(1e-5):
+                    return [('shift', scale / sh), ('scale', (y + shift) / sh), ('power', 0 * one)]
+                a = np.abs(sh)
+                sp_ = np.sign(sh) * a ** power
+                dsh = a ** (power - 1)
+                return [('shift', dsh * scale), ('scale', dsh * (y + shift)),
+                        ('power', (sp_ * np.log(a) * power - (sp_ - 1)) / power ** 2)]
+        if s[0] == 'ArcsinhLinear':
+            return [('shift', one), ('scale', np.arcsinh(y))]
+        raise ValueError(s[0])
+
+    def dlogdet_dinv(self, y):
+        """d logdet_dinv(y) / d(parameter): list of (pname, scalar)"""
+        s, t = self.spec, self.t
+        y = np.asarray(y)
+        n = t(y.shape[0])
+        if s[0] == 'Identity':
+            return []
+        if s[0] == 'LinearMapping':
+            return [('shift', t(0)), ('scale', -n / t(s[2]))]
+        if s[0] == 'LogShifted':
+            with np.errstate(all='ignore'):
+                return [('shift', np.sum(1 / (y - t(s[1]))))]
+        if s[0] == 'BoxCoxLinear':
+            shift, scale, power = t(s[1]), t(s[2]), t(s[3])
+            with np.errstate(all='ignore'):
+                return [('shift', (power - 1) * np.sum(1 / (y + shift))), ('scale', power * n / scale),
+                        ('power', np.sum(np.log(np.abs(scale * (y + shift)))))]
+        if s[0] == 'ArcsinhLinear':
+            return [('shift', t(0)), ('scale', n / t(s[2]))]
+        raise ValueError(s[0])
+
+
 # --------------------------------------------------------------------------- Cholesky
 def cholesky_robust(K, maxtries=20, return_info=False):
     """CholeskyRobust._cholesky + .perform -- g3py/libs/tensors.py:197-222.
@@ -299,6 +452,18 @@ def cholesky_robust(K, maxtries=20, return_info=False):
     if return_info:
         return z, tries, fallback
     return z
+
+
+def cholesky_grad(L, Lbar):
+    """CholeskyRobust.grad -- g3py/libs/tensors.py:224-260 (Murray 2016, reverse mode):
+    given Lbar = d f / d L returns d f / d K for the lower-triangular convention used there:
+    s = L^-T Phi(L^T Lbar) L^-1 with Phi = tril with halved diagonal, result tril(s + s^T) - diag(s)."""
+    P = np.tril(L.T.dot(Lbar))
+    P[np.diag_indices_from(P)] *= 0.5                                   # tril_and_halve_diagonal :245-247
+    # conjugate_solve_triangular(outer=L, inner=P) = L^-T P L^-1  :249-252
+    s = sp.linalg.solve_triangular(L, sp.linalg.solve_triangular(L, P.T, lower=True, trans='T').T,
+                                   lower=True, trans='T')
+    return np.tril(s + s.T) - np.diag(np.diag(s))                       # :258
 
 
 # --------------------------------------------------------------------------- logp
@@ -460,6 +625,37 @@ class GP:
         if prior:
             return self.t(lp)
         return self.t(lp) + self.loglike(inputs, outputs)
+
+
+    def dlogp_natural(self, inputs, outputs):
+        """Gradient of `logp` (observed term; the Flat priors and the log-transform Jacobian are
+        constants) with respect to the NATURAL-space parameters, as the reference's
+        th_dlogp = gradient(th_logp) (stochastic.py:308-309, tensors.py:11-22) computes it by
+        reverse mode: logp_cho (gaussian.py:208-232) -> Lbar, delta_bar; CholeskyRobust.grad
+        (tensors.py:224-260) -> Kbar; then the kernel / mean / mapping formulas.  The jittered
+        factor is re-used as the Cholesky of K exactly as grad() does (`chol_x = self(x)`).
+        Returns dict(kernel=[(leaf, pname, k, value)], mean=[(pname, k, value)],
+        mapping=[(pname, value)]); all zeros when logp takes the -1e30 branch (a constant)."""
+        x = self._x(inputs)
+        y = np.asarray(outputs, dtype=self.dtype)
+        K, kg = kernel_cov_grads(self.kn, x, self.dtype)
+        mg = mean_grads(self.mean_spec, x, self.dtype)
+        di, dl = self.map.dinv(y), self.map.dlogdet_dinv(y)
+        zero = dict(kernel=[(l, p, k, 0.0) for l, p, k, _ in kg], mean=[(p, k, 0.0) for p, k, _ in mg],
+                    mapping=[(p, 0.0) for p, _ in di])
+        cho = cholesky_robust(tt_to_cov(K))
+        delta_ = self.mapping_outputs(y) - self.prior_location(x)
+        if not np.isfinite(self.loglike(inputs, outputs)) or self.loglike(inputs, outputs) == self.t(np.float32(-1e30)):
+            return zero
+        a = sp.linalg.solve_triangular(cho, delta_, lower=True)
+        alpha = sp.linalg.solve_triangular(cho, a, lower=True, trans='T')
+        # logp = -1/2 a^T a - sum log L_ii + ...:  Lbar = tril(alpha a^T) - diag(1/L_ii); delta_bar = -alpha
+        Lbar = np.tril(np.outer(alpha, a)) - np.diag(1.0 / np.diag(cho))
+        Kbar = cholesky_grad(cho, Lbar)
+        out = dict(kernel=[(l, p, k, float(np.sum(Kbar * dK))) for l, p, k, dK in kg],
+                   mean=[(p, k, float(alpha.dot(col))) for p, k, col in mg],
+                   mapping=[(p, float(-alpha.dot(dcol) + dscalar)) for (p, dcol), (_, dscalar) in zip(di, dl)])
+        return out
 
 
 # --------------------------------------------------------------------------- CPU baseline

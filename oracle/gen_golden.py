@@ -78,9 +78,22 @@ def gen_gpmm():
         mean = gpmm.MeanPredFromCho(Kyx, L, y)
         varp = gpmm.VarPredFromCho(Kyx, L, Kyy)
         cov = gpmm.CovPredFromCho(Kyx, L, Kyy)
+        # gradient of logp = -NLL w.r.t. (log noise, log var, log rate_k): 5-point central
+        # differences of gpmm's OWN NLL(params, Kernel, X, Fx) (:128-130) -- pins dlogp for SE / OU.
+        # gpmm's parameters are (log noise, H = log var, W_k) with W_k = log(rate_k^2 / 2) (SE) or
+        # log rate_k (OU), so d/dlog rate_k = 2 d/dW_k (SE) or d/dW_k (OU).
+        p0 = Kf.params().astype(float)
+        h = 1e-3
+        dl = np.zeros(len(p0))
+        for i in range(len(p0)):
+            e = np.zeros(len(p0)); e[i] = h
+            f = [gpmm.NLL(p0 + c * e, Kf, X, y) for c in (-2, -1, 1, 2)]
+            dl[i] = -(f[0] - 8 * f[1] + 8 * f[2] - f[3]) / (12 * h)
+        Kf.setParameters(p0)
+        dl[2:] *= 2.0 if kind == 'SE' else 1.0
         np.savez_compressed(os.path.join(OUT, 'gpmm_%s.npz' % name), kind=kind, X=X, y=y, Xs=Xs,
                             var=var, rate=rate, noise=noise, K=K, L=np.tril(L), logp=-nll,
-                            mean=mean, variance=varp, covariance=cov)
+                            mean=mean, variance=varp, covariance=cov, dlogp_log=dl)
         print('gpmm', name, 'logp', -nll)
 
 
@@ -161,6 +174,10 @@ def gen_oracle():
         res[name + '_prior_mean'] = gp.mean(Xs, prior=True)
         res[name + '_prior_var_n1'] = gp.variance(Xs, prior=True, noise=True)
         res[name + '_logpred'] = gp.logpredictive(gp.median(Xs, X, yy), Xs, X, yy)
+        dg = gp.dlogp_natural(X, yy)     # natural-space gradient, oracle ordering (see GP.dlogp_natural)
+        res[name + '_dlogp_kernel'] = np.array([v for _, _, _, v in dg['kernel']])
+        res[name + '_dlogp_mean'] = np.array([v for _, _, v in dg['mean']])
+        res[name + '_dlogp_mapping'] = np.array([v for _, v in dg['mapping']])
     np.savez_compressed(os.path.join(OUT, 'oracle_process.npz'), **res)
 
     # jitter-path cases for CholeskyRobust (tensors.py:197-222)

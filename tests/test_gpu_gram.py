@@ -116,3 +116,81 @@ def test_gram_diag(dev):
     out = dev.alloc(1, 77, np.float64)
     dev.gram_diag(compile_spec(spec, 3), dev.upload(X), 3, out)
     np.testing.assert_allclose(dev.download(out)[0], np.diag(orc.kernel_cov(spec, X)), rtol=1e-13)
+
+
+# ------------------------------------------------------------------ kernel-parameter gradient sums
+def _grad_zoo(d):
+    r = np.linspace(0.6, 1.4, d)
+    f = np.linspace(0.11, 0.23, d)
+    return {
+        'SE+noise': ('sum', ('SE', 1.3, r, None), ('NOISE', 0.1)),
+        'OU': ('OU', 0.9, r, None),
+        'MAT32': ('MAT32', 1.1, r, None),
+        'MAT52+COS': ('sum', ('MAT52', 1.0, r, None), ('COS', 0.5, f, None)),
+        'RQ': ('RQ', 1.2, r, 1.7, None),
+        'SIN': ('SIN', 0.5, f, 0.25 * r, None),
+        'SINC': ('SINC', 1.4, f, None),
+        'SM+WN': ('sum', ('SM', 0.9, f, 0.3 * r, None), ('WN', 0.4, None)),
+        'SE*COS': ('prod', ('SE', 1.0, r, None), ('COS', 1.0, f, None)),
+        '(SE+OU)*(MAT32+0.5)': ('prod', ('sum', ('SE', 1.0, r, None), ('OU', 0.5, r, None)),
+                                ('shift', 0.5, ('MAT32', 0.7, r, None))),
+        '2*SE[dims]+0.1': ('shift', 0.1, ('scale', 2.0, ('SE', 1.0, r[:2], np.array([0, d - 1])))),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(_grad_zoo(3)))
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_gram_grad_matches_oracle(dev, name, dtype):
+    """g3_gram_grad: out[slot] = 1/2 sum_ij (alpha_i alpha_j - G_ij) dK_ij/dparam against the
+    oracle's dK/dparam tensors, for every leaf parameter of every kernel family"""
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    N, d = 150, 3
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 4, (N, d))
+    X[7] = X[3]                                   # a coincident pair (WN / SINC special cases)
+    spec = _grad_zoo(d)[name]
+    A = rng.standard_normal((N, N))
+    G = (A + A.T) / 2
+    alpha = rng.standard_normal(N)
+    K, grads = orc.kernel_cov_grads(spec, X)
+    Gfull = np.outer(alpha, alpha) - G
+    prog = compile_spec(spec, d)
+    gmap = dev.grad_layout(prog)
+    Xd, Gd, ad = dev.upload(X.astype(dtype)), dev.upload(np.tril(G).astype(dtype)), dev.upload(alpha.astype(dtype))
+    out = dev.gram_grad(prog, gmap, Xd, N, d, Gd, ad)
+    assert len(out) == len(grads)
+    tol = 1e-10 if dtype == np.float64 else 2e-4
+    for (leaf, pname, k, dK) in grads:
+        slot = getattr(gmap, pname)[leaf] + (0 if k is None else k)
+        want = 0.5 * np.sum(Gfull * dK)
+        scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
+        assert abs(out[slot] - want) < tol * scale, (name, leaf, pname, k, out[slot], want)
+
+
+@pytest.mark.gpu
+def test_gram_grad_many_slots_and_ragged(dev):
+    """more parameters than one accumulation window (32 slots) and N not a multiple of the tile"""
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    N, d = 203, 12
+    rng = np.random.default_rng(9)
+    X = rng.uniform(0, 2, (N, d))
+    r, f = np.linspace(0.3, 0.6, d), np.linspace(0.05, 0.1, d)
+    spec = ('sum', ('prod', ('SE', 1.0, r, None), ('SM', 0.7, f, 0.2 * r, None)), ('sum', ('RQ', 0.5, r, 2.0, None), ('NOISE', 0.2)))
+    A = rng.standard_normal((N, N))
+    G = (A + A.T) / 2
+    alpha = rng.standard_normal(N)
+    K, grads = orc.kernel_cov_grads(spec, X)
+    prog = compile_spec(spec, d)
+    gmap = dev.grad_layout(prog)
+    assert gmap.nslots == len(grads) > 32
+    out = dev.gram_grad(prog, gmap, dev.upload(X), N, d, dev.upload(np.tril(G)), dev.upload(alpha))
+    Gfull = np.outer(alpha, alpha) - G
+    for (leaf, pname, k, dK) in grads:
+        slot = getattr(gmap, pname)[leaf] + (0 if k is None else k)
+        want, scale = 0.5 * np.sum(Gfull * dK), 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
+        assert abs(out[slot] - want) < 1e-10 * scale
+    out2 = dev.gram_grad(prog, gmap, dev.upload(X), N, d, dev.upload(np.tril(G)), dev.upload(alpha))
+    assert np.array_equal(out, out2)              # fixed-order reduction: bitwise reproducible

@@ -151,3 +151,25 @@ def test_reference_named_tensor_helpers():
     np.testing.assert_allclose(out[0][0], L)
     assert g3.cholesky_robust.infer_shape(None, [(100, 100)]) == [(100, 100)]
     np.testing.assert_array_equal(g3.tt_to_num(np.array([np.nan, np.inf, 1.0])), [0, np.float32(1e10), 1.0])
+
+
+# ------------------------------------------------------------------ K^-1 from the factor (dlogp path)
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,dtype', [(128, np.float64), (384, np.float64), (1024, np.float64), (2048, np.float32)])
+def test_potri_matches_lapack(dev, n, dtype):
+    """g3_potri: Y = L^-T and lower(K^-1) = Y Y^T (LAPACK dpotri's result); n >= 768 takes the
+    two-stream look-ahead schedule"""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    K = A.dot(A.T) / n + np.eye(n)
+    L = np.linalg.cholesky(K)
+    Ld = dev.upload(L.astype(dtype))
+    Y = dev.alloc(n, n, dtype)
+    Ki = dev.alloc(n, n, dtype)
+    dev.potri(Ld, n, None, Y, Ki)
+    Yh, Kih = dev.download(Y), dev.download(Ki)
+    tol = 1e-10 if dtype == np.float64 else 2e-4
+    Linv = np.linalg.inv(L)
+    assert np.max(np.abs(Yh - Linv.T)) < tol * np.max(np.abs(Linv))
+    Kinv = np.linalg.inv(K)
+    assert np.max(np.abs(np.tril(Kih) - np.tril(Kinv))) < tol * np.max(np.abs(Kinv))

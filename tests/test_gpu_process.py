@@ -196,3 +196,116 @@ def test_cross_mean_and_wgp_fp32_draws():
     Z = rng.standard_normal((M, 4))
     draws = wgp.sampler(pw, samples=4, rand=Z)
     np.testing.assert_allclose(draws, o.sampler(Xs, X, y, Z), rtol=5e-3, atol=5e-3)
+
+
+# ------------------------------------------------------------------ dlogp (stochastic.py:308-309)
+@pytest.mark.parametrize('name', ['se_d1', 'se_d3', 'se_d4', 'ou_d2'])
+def test_dlogp_matches_reference_gpmm(golden_dir, name):
+    """gradient in transformed (log) space against finite differences of the reference
+    prototype's own NLL (fixture made by oracle/gen_golden.py from sandbox/gpmm.py:128-130)"""
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'gpmm_%s.npz' % name))
+    X, y, Xs = g['X'], g['y'], g['Xs']
+    kern = g3.SE(X) if str(g['kind']) == 'SE' else g3.OU(X)
+    gp = g3.GaussianProcess(space=Xs, location=g3.Zero(), kernel=kern)
+    gp.observed(X, y)
+    kn = kern.name
+    p = _params(gp, **{kn + '_var': float(g['var']), kn + '_rate': g['rate'], 'Noise_var': float(g['noise'])})
+    got = gp.dlogp(p)
+    assert [v.key for v in gp.model.vars] == ['GP_%s_var_log_' % kn, 'GP_%s_rate_log_' % kn, 'GP_Noise_var_log_']
+    d = len(g['rate'])
+    want = np.concatenate([g['dlogp_log'][1:2], g['dlogp_log'][2:2 + d], g['dlogp_log'][0:1]])
+    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-7)
+    np.testing.assert_array_equal(gp.dlogp(gp.active.dict_to_array(p), array=True), got)
+    assert 'posterior_dlogp' in gp.compiles and 'array_posterior_dlogp' in gp.compiles
+
+
+def _oracle_grad(gp, g, name, nat):
+    """the oracle's natural-space gradient pieces -> the product's flat transformed-space vector"""
+    leaves = [k.split('_')[0] for k in nat if k.split('_')[0] not in
+              ('Noise', 'Bias', 'Linear', 'BoxCoxLinear', 'ArcsinhLinear', 'LogShifted', 'LinearMapping')]
+    leaves = list(dict.fromkeys(leaves)) + ['Noise']
+    kern, mean, mapp = list(g[name + '_dlogp_kernel']), list(g[name + '_dlogp_mean']), list(g[name + '_dlogp_mapping'])
+    by_key = {}
+    order = {'SE': ['var', 'rate'], 'OU': ['var', 'rate'], 'MAT52': ['var', 'rate'], 'RQ': ['var', 'alpha', 'rate'],
+             'COS': ['var', 'freq'], 'Noise': ['var']}
+    d = gp.inputs.shape[1]
+    for lf in leaves:
+        for pn in order[lf]:
+            n = d if pn in ('rate', 'freq') else 1
+            by_key[lf + '_' + pn] = np.array([kern.pop(0) for _ in range(n)])
+    for k in nat:
+        if k.startswith(('Bias_', 'Linear_')):
+            n = d if k == 'Linear_Coeff' else 1
+            by_key[k] = np.array([mean.pop(0) for _ in range(n)])
+        elif k.split('_')[0] in ('BoxCoxLinear', 'ArcsinhLinear', 'LogShifted', 'LinearMapping'):
+            by_key[k] = np.array([mapp.pop(0)])
+    assert not kern and not mean and not mapp
+    out = []
+    for v in gp.model.vars:
+        k = v.name[len(gp.name) + 1:]
+        val = np.atleast_1d(np.asarray(nat[k], dtype=float)) * np.ones(max(v.size, 1))
+        out.append(by_key[k] * (val if v.positive else 1.0))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize('name', sorted(PROCS))
+def test_dlogp_matches_oracle_fixture(golden_dir, name):
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs, y = g['X'], g['Xs'], g[name + '_y']
+    cls, kw, nat = PROCS[name](g3, X)
+    gp = cls(space=Xs, **kw)
+    gp.observed(X, y)
+    p = _params(gp, **nat)
+    got = gp.dlogp(p)
+    want = _oracle_grad(gp, g, name, nat)
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(want).max()))
+    # directional finite difference of the device logp itself
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal(len(got))
+    a = gp.active.dict_to_array(p)
+    h = 1e-5
+    fd = (float(gp.logp(a + h * v, array=True)) - float(gp.logp(a - h * v, array=True))) / (2 * h)
+    assert abs(fd - got.dot(v)) <= 1e-5 * max(1.0, abs(fd))
+
+
+def test_dlogp_edge_branches():
+    """prior=True, the -1e30 sentinel, the -inf Jacobian, an L2 potential and the jitter path"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(2)
+    X = rng.uniform(0, 3, (60, 2))
+    y = np.sin(X.sum(1))
+    k = g3.SE(X)
+    k.set_potential('rate', 'L2', 0.5)
+    gp = g3.GaussianProcess(space=X, location=g3.Bias(), kernel=k)
+    gp.observed(X, y)
+    p = _params(gp, SE_var=1.2, SE_rate=[0.8, 1.1], Noise_var=0.1, Bias_Bias=0.1)
+    names = [v.key for v in gp.model.vars]
+    rate = np.array([0.8, 1.1])
+    pot = np.zeros(len(gp.dlogp(p)))
+    i0 = gp.active.dict_to_array({n: (np.arange(len(np.atleast_1d(p[n]))) + 100 * j) for j, n in enumerate(names)})
+    ridx = [i for i, t in enumerate(i0) if 100 * names.index('GP_SE_rate_log_') <= t < 100 * names.index('GP_SE_rate_log_') + 50]
+    pot[ridx] = -2 * 0.5 * rate * rate               # d(-c sum h^2)/d log h
+    np.testing.assert_allclose(gp.dlogp(p, prior=True), pot, atol=1e-12)
+    ref = orc.GP(('SE', 1.2, rate, None), 0.1, ('Bias', 0.1)).dlogp_natural(X, y)
+    kern = {(l, pn, kk): v for l, pn, kk, v in ref['kernel']}
+    want = np.concatenate([[ref['mean'][0][2]], [kern[(0, 'var', None)] * 1.2],
+                           [kern[(0, 'rate', i)] * rate[i] for i in range(2)], [kern[(1, 'var', None)] * 0.1]]) + pot
+    np.testing.assert_allclose(gp.dlogp(p), want, rtol=1e-8, atol=1e-8)
+    y2 = y.copy(); y2[5] = np.nan
+    np.testing.assert_allclose(gp.dlogp(p, outputs=y2), pot, atol=1e-12)     # constant -1e30 branch
+    q = dict(p); q['GP_Noise_var_log_'] = np.log(1e-7)
+    assert np.all(np.isfinite(gp.dlogp(q)))                                   # tt_to_num on the result
+    # jitter path: duplicate inputs, no noise; CholeskyRobust.grad re-uses the jittered factor
+    Xd = np.repeat(rng.uniform(0, 3, (30, 1)), 2, axis=0)
+    yd = np.sin(Xd[:, 0])
+    gj = g3.GaussianProcess(space=Xd, location=g3.Zero(), kernel=g3.SE(Xd), noisy=False)
+    gj.observed(Xd, yd)
+    pj = _params(gj, SE_var=1.0, SE_rate=[1.0])
+    got = gj.dlogp(pj)
+    assert gj._cache['stats']['tries'] >= 1
+    rj = orc.GP(('SE', 1.0, np.array([1.0]), None), None).dlogp_natural(Xd, yd)
+    wantj = np.array([v for *_, v in rj['kernel']])
+    np.testing.assert_allclose(got, wantj, rtol=1e-4, atol=1e-4 * np.abs(wantj).max())

@@ -127,3 +127,43 @@ def test_potrf_blocking_invariance(dev, monkeypatch):
     ref = scipy.linalg.cholesky(K, lower=True)
     for L in res:
         assert np.abs(L - ref).max() < 1e-11
+
+
+def test_dlogp_n8192_identities(dev):
+    """dlogp at BASELINE config-2 size through identities that need no CPU reference:
+    K^-1 K = I on sampled columns, alpha = K^-1 delta, trace identity sum_ij G_ij K_ij = delta^T alpha - N
+    for the var/noise slots, and a directional finite difference of the device logp"""
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d = 8192, 4
+    X, y, _ = _synth(N, d, 8, 1002)
+    var, rate, noise = 1.0, np.ones(d), 0.1
+    spec = orc.with_noise(('SE', var, rate, None), noise)
+    lp, st, (K, W), a, Xd = _factor(dev, spec, X, y)
+    Np = _lib.roundup(N)
+    prog = compile_spec(spec, d)
+    gmap = dev.grad_layout(prog)
+    Y, Ki, al = dev.alloc(Np, Np, np.float64), dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64)
+    slots = dev.gp_dlogp(prog, gmap, Xd, N, d, K, W, a, Y, Ki, al)
+    Kinv = dev.download(Ki, N, N)
+    Kinv = np.tril(Kinv) + np.tril(Kinv, -1).T
+    cols = [0, 17, 4095, 8191]
+    Kc = orc.kernel_cov(spec, X, X[cols])
+    Kc[cols, range(len(cols))] += noise           # the cross block carries no noise term
+    np.testing.assert_allclose(Kinv.dot(Kc), np.eye(N)[:, cols], atol=1e-9)
+    alpha = dev.download(al, 1, N)[0]
+    np.testing.assert_allclose(alpha, Kinv.dot(y), rtol=1e-9, atol=1e-9)
+    # var * dK/dvar + noise * dK/dnoise = K  =>  1/2 sum G_ij K_ij = 1/2 (y^T alpha - N)
+    g_var, g_noise = slots[gmap.var[0]], slots[gmap.var[1]]
+    assert abs(var * g_var + noise * g_noise - 0.5 * (y.dot(alpha) - N)) <= 1e-9 * N
+    # directional finite difference in (log var, log rate, log noise)
+    g_log = np.concatenate([[var * g_var], rate * slots[gmap.rate[0]:gmap.rate[0] + d], [noise * g_noise]])
+    v = np.array([0.3, -0.2, 0.5, 0.1, -0.4, 0.25])
+    h = 1e-5
+
+    def logp(t):
+        e = np.exp(t * v)
+        return _factor(dev, orc.with_noise(('SE', var * e[0], rate * e[1:1 + d], None), noise * e[-1]), X, y)[0]
+    fd = (logp(h) - logp(-h)) / (2 * h)
+    assert abs(fd - g_log.dot(v)) <= 1e-6 * max(1.0, abs(fd))

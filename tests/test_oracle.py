@@ -173,3 +173,134 @@ def test_cpu_hot_path_matches_oracle():
     assert abs(lp - gp.logp(X, y)) < 1e-9 * abs(lp)
     np.testing.assert_allclose(mean, gp.mean(Xs, X, y), atol=1e-9)
     np.testing.assert_allclose(var, gp.variance(Xs, X, y), atol=1e-9)
+
+
+# ------------------------------------------------------------------ gradient of logp
+def _bump(spec, leaf, pname, k, delta, cnt=None):
+    """copy of a kernel spec tree with one leaf parameter moved by delta"""
+    cnt = [0] if cnt is None else cnt
+    op = spec[0]
+    if op in ('sum', 'prod'):
+        a = _bump(spec[1], leaf, pname, k, delta, cnt)
+        return (op, a, _bump(spec[2], leaf, pname, k, delta, cnt))
+    if op in ('scale', 'shift'):
+        return (op, spec[1], _bump(spec[2], leaf, pname, k, delta, cnt))
+    me = cnt[0]
+    cnt[0] += 1
+    if me != leaf:
+        return spec
+    idx = dict(var=1)
+    idx.update({'SE': dict(rate=2), 'OU': dict(rate=2), 'MAT32': dict(rate=2), 'MAT52': dict(rate=2),
+                'RQ': dict(rate=2, alpha=3), 'COS': dict(freq=2), 'SINC': dict(freq=2),
+                'SIN': dict(freq=2, rate=3), 'SM': dict(freq=2, rate=3)}.get(op, {}))
+    s = list(spec)
+    if k is None:
+        s[idx[pname]] = s[idx[pname]] + delta
+    else:
+        v = np.array(s[idx[pname]], dtype=float)
+        v[k] += delta
+        s[idx[pname]] = v
+    return tuple(s)
+
+
+def _grad_specs(d):
+    from oracle.gen_golden import kernel_zoo
+    z = kernel_zoo(d)
+    z['SE+NOISE'] = ('sum', z['SE'], ('NOISE', 0.3))
+    return z
+
+
+@pytest.mark.parametrize('name', sorted(_grad_specs(3)))
+def test_kernel_cov_grads_match_finite_differences(name):
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 3, (30, 3))
+    spec = _grad_specs(3)[name]
+    K, grads = orc.kernel_cov_grads(spec, X)
+    np.testing.assert_allclose(K, orc.kernel_cov(spec, X), rtol=1e-14)
+    h = 1e-6
+    for leaf, pname, k, dK in grads:
+        fd = (orc.kernel_cov(_bump(spec, leaf, pname, k, h), X) - orc.kernel_cov(_bump(spec, leaf, pname, k, -h), X)) / (2 * h)
+        np.testing.assert_allclose(dK, fd, atol=2e-8 * max(1.0, np.abs(fd).max()), err_msg=str((name, leaf, pname, k)))
+
+
+def test_cholesky_grad_is_the_adjoint_of_the_factorisation():
+    """CholeskyRobust.grad (tensors.py:224-260): sum(Kbar * dK) == sum(Lbar * dL) for symmetric dK"""
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((12, 12))
+    K = A.dot(A.T) + 12 * np.eye(12)
+    L = np.linalg.cholesky(K)
+    Lbar = np.tril(rng.standard_normal((12, 12)))
+    Kbar = orc.cholesky_grad(L, Lbar)
+    S = rng.standard_normal((12, 12))
+    dK = (S + S.T) / 2
+    h = 1e-6
+    dL = (np.linalg.cholesky(K + h * dK) - np.linalg.cholesky(K - h * dK)) / (2 * h)
+    assert abs(np.sum(Kbar * dK) - np.sum(Lbar * dL)) < 1e-7
+
+
+@pytest.mark.parametrize('kname', ['SE', 'OU', 'MAT32', 'MAT52', 'RQ', 'SM', 'SE*COS', '(SE+OU)*(MAT32+0.5)', 'SE[dims]'])
+@pytest.mark.parametrize('mname', ['bias_identity', 'linear_boxcox', 'zero_arcsinh', 'zero_logshift', 'zero_linearmap'])
+def test_dlogp_matches_finite_differences_of_logp(kname, mname):
+    """the reverse-mode restatement (logp_cho -> CholeskyRobust.grad -> kernel / mean / mapping) against
+    central differences of the oracle's own logp, which the gpmm fixtures pin"""
+    rng = np.random.default_rng(0)
+    N, d = 40, 3
+    X = rng.uniform(0, 3, (N, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N) + 2.5
+    kf = _grad_specs(d)[kname]
+    mean, mapping = {'bias_identity': (('Bias', 0.3), ('Identity',)),
+                     'linear_boxcox': (('Linear', 0.1, np.array([0.2, -0.1, 0.05]), None), ('BoxCoxLinear', 1.0, 1.1, 1.2)),
+                     'zero_arcsinh': (('Zero',), ('ArcsinhLinear', 0.2, 1.5)),
+                     'zero_logshift': (('Zero',), ('LogShifted', -0.5)),
+                     'zero_linearmap': (('Zero',), ('LinearMapping', 0.3, 1.7))}[mname]
+    gp = orc.GP(kf, 0.1, mean, mapping)
+    g = gp.dlogp_natural(X, y)
+    h = 1e-5
+
+    def check(val, lp, what):
+        fd = (lp(h) - lp(-h)) / (2 * h)
+        assert abs(fd - val) <= 2e-6 * max(1.0, abs(val)), (what, val, fd)
+
+    for leaf, pname, k, val in g['kernel']:
+        def lp(dl):
+            g2 = orc.GP(kf, 0.1, mean, mapping)
+            g2.kn = _bump(gp.kn, leaf, pname, k, dl)
+            return g2.loglike(X, y)
+        check(val, lp, (leaf, pname, k))
+    for pname, k, val in g['mean']:
+        def lp(dl):
+            m = list(mean)
+            if pname in ('bias', 'constant'):
+                m[1] = m[1] + dl
+            else:
+                v = np.array(m[2], dtype=float)
+                v[k] += dl
+                m[2] = v
+            return orc.GP(kf, 0.1, tuple(m), mapping).loglike(X, y)
+        check(val, lp, (pname, k))
+    for i, (pname, val) in enumerate(g['mapping']):
+        def lp(dl):
+            m = list(mapping)
+            m[1 + i] = m[1 + i] + dl
+            return orc.GP(kf, 0.1, mean, tuple(m)).loglike(X, y)
+        check(val, lp, pname)
+
+
+@pytest.mark.parametrize('name', ['se_d1', 'se_d3', 'se_d4', 'ou_d2'])
+def test_dlogp_matches_reference_gpmm(golden_dir, name):
+    """dlogp against finite differences of the reference prototype's own NLL (sandbox/gpmm.py:128-130)"""
+    g = np.load(os.path.join(golden_dir, 'gpmm_%s.npz' % name))
+    kind, rate = str(g['kind']), g['rate']
+    gp = orc.GP((kind, float(g['var']), rate, None), float(g['noise']))
+    dg = {(l, p, k): v for l, p, k, v in gp.dlogp_natural(g['X'], g['y'])['kernel']}
+    got = np.array([dg[(1, 'var', None)] * float(g['noise']), dg[(0, 'var', None)] * float(g['var'])]
+                   + [dg[(0, 'rate', k)] * rate[k] for k in range(len(rate))])
+    np.testing.assert_allclose(got, g['dlogp_log'], rtol=1e-7, atol=1e-7)
+
+
+def test_dlogp_sentinel_branch_is_flat():
+    X = np.linspace(0, 1, 8)[:, None]
+    y = np.ones(8)
+    y[2] = np.inf
+    g = orc.GP(('SE', 1.0, np.ones(1), None), 0.1, ('Bias', 0.0)).dlogp_natural(X, y)
+    assert all(v == 0 for *_, v in g['kernel']) and all(v == 0 for *_, v in g['mean'])
