@@ -97,7 +97,9 @@ def main():
     ap.add_argument('--f32', action='store_true', help='float32 arithmetic (config 5 runs in fp32)')
     ap.add_argument('--cpu-n', type=int, default=8192, help='N of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
-    ap.add_argument('--panel', dest='nb', type=int, default=1024, help='block-column width of the multi-GPU distribution')
+    ap.add_argument('--grad', action='store_true', help='also time dlogp (K^-1 + kernel-parameter sums, SURVEY.md 8f rank 1) '
+                                                        'after the timed region; reported under "dlogp", never part of value')
+    ap.add_argument('--panel', dest='nb', type=int, default=512, help='block-column width of the multi-GPU distribution')
     args = ap.parse_args()
 
     import torch
@@ -236,6 +238,24 @@ def main():
                                'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],
                                'note': 'HIP events per launch on the launching stream; launches on the two '
                                        'look-ahead streams overlap, so summed launch time exceeds wall time'}
+        if world == 1 and args.grad:
+            gmap = dev.grad_layout(prog_n)
+            Yt = torch.empty((Np, Np), dtype=tdt, device=tdev)
+            Kit = torch.empty((Np, Np), dtype=tdt, device=tdev)
+            alt = torch.empty((1, Np), dtype=tdt, device=tdev)
+            Yd, Kid, ald = wrap(Yt, Np, Np), wrap(Kit, Np, Np), wrap(alt, 1, Np)
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                slots = dev.gp_dlogp(prog_n, gmap, Xd, N, d, Kd, Wd, ad, Yd, Kid, ald)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            tg = min(ts[1:])
+            out['dlogp'] = {'ms': tg * 1e3, 'potri_tflops': (2.0 * N ** 3 / 3.0) / tg / 1e12, 'nslots': int(gmap.nslots),
+                            'grad_natural': [float(v) for v in slots],
+                            'note': 'K^-1 (2N^3/3 flops) + alpha + one pass over K^-1 for the kernel-parameter sums; '
+                                    'after the timed region, not part of value'}
         if world == 1 and args.cpu_n > 0:
             cb, lp_cpu = cpu_baseline(N, d, M, seed, min(args.cpu_n, N))
             out['cpu_baseline'] = cb

@@ -80,8 +80,9 @@ def tt_to_bounded(r, lower=None, upper=None):
 
 class CholeskyRobust:
     """The Op protocol of tensors.py:174-263 reduced to what the path uses: calling the
-    object, `perform(node, inputs, output_storage)` and `infer_shape`; `grad` is out of scope
-    (SURVEY.md section 8f, rank 1)."""
+    object, `perform(node, inputs, output_storage)` and `infer_shape`.  The reverse-mode `grad`
+    (tensors.py:224-260) has no symbolic graph to act on here: the product path evaluates the
+    gradient of logp in closed form on the device (`GaussianProcess.th_dlogp`, `g3_gp_dlogp`)."""
     __props__ = ('lower', 'destructive')
 
     def __init__(self, device=None):
@@ -113,7 +114,8 @@ class CholeskyRobust:
         return self._cholesky(x)
 
     def grad(self, inputs, gradients):
-        raise NotImplementedError('dlogp (CholeskyRobust.grad, tensors.py:224-260) is not part of this path yet')
+        raise NotImplementedError('no symbolic graph: use GaussianProcess.dlogp (g3_gp_dlogp), which evaluates the '
+                                  'chain through CholeskyRobust.grad (tensors.py:224-260) in closed form')
 
 
 cholesky_robust = CholeskyRobust()
