@@ -17,6 +17,7 @@ G3_F64, G3_F32 = 0, 1
 G3_GRAM_LOWER, G3_GRAM_SCRUB, G3_GRAM_PAD_EYE = 1, 2, 4
 G3_PAD = 128       # matrices are padded to a multiple of the panel block (G3_LB in the library)
 G3_RHS_PAD = 128   # right-hand-side blocks are padded to a multiple of the 128-row tile
+G3_MAX_BATCH = 4096
 KINDS = dict(SE=0, OU=1, MAT32=2, MAT52=3, RQ=4, COS=5, SIN=6, SINC=7, SM=8, NOISE=9, WN=10)
 
 
@@ -77,6 +78,8 @@ _SIGS = {
                       C.POINTER(C.c_double)], C.c_int),
     'g3_gp_factor_predict': ([_P, C.POINTER(KernelProg), C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, _P, _P, _I64,
                               _I64, C.c_int, _P, _I64, _P, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_factor_batched': ([_P, C.POINTER(KernelProg), C.c_int, _P, _I64, _I64, C.c_int, _P, _I64, C.c_int, _P, _I64,
+                              _I64, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _P], C.c_int),
     'g3_grad_layout': ([C.POINTER(KernelProg), C.POINTER(GradMap)], C.c_int),

@@ -21,30 +21,15 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   if (e == hipSuccess) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority
-    // G3_BMASK (experiment): "stride:S" clears every S-th CU bit, "first:K" clears the first K
-    // bits of the side stream's CU mask, reserving those CUs for the critical-path stream
-    const char* bm = getenv("G3_BMASK");
-    if (bm && *bm) {
-      uint32_t mask[8];
-      for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
-      int v = atoi(strchr(bm, ':') ? strchr(bm, ':') + 1 : "0");
-      if (!strncmp(bm, "stride", 6) && v > 0) {
-        for (int b = 0; b < 256; b += v) mask[b >> 5] &= ~(1u << (b & 31));
-      } else if (!strncmp(bm, "first", 5)) {
-        for (int b = 0; b < v && b < 256; ++b) mask[b >> 5] &= ~(1u << (b & 31));
-      }
-      e = hipExtStreamCreateWithCUMask(&ctx->side_stream, 8, mask);
-    } else {
-      e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
-    }
+    e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
   }
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, G3_MAX_BATCH * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, 2 * sizeof(g3_kernel_prog));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_info, sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_info, G3_MAX_BATCH * sizeof(int), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_stats, 64 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_prog, 2 * sizeof(g3_kernel_prog), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, G3_MAX_BATCH * sizeof(int));
   if (e != hipSuccess) {
     g3_ctx_destroy(ctx);
     return G3_ERR_HIP;
@@ -66,6 +51,7 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   if (ctx->h_prog) (void)hipHostFree(ctx->h_prog);
   if (ctx->invd) (void)hipFree(ctx->invd);
   if (ctx->work) (void)hipFree(ctx->work);
+  if (ctx->bbuf) (void)hipFree(ctx->bbuf);
   if (ctx->prof_ev) {
     for (int i = 0; i < ctx->prof_cap; ++i) if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
@@ -243,7 +229,9 @@ __device__ __forceinline__ T wave_max(T v) {
 // tt_to_cov's lift  A_ii += (1e-6f - min) when min <= 0  (tensors.py:95-98)
 template <typename T>
 __global__ void __launch_bounds__(1024)
-diag_stats_kernel(T* A, int64_t n, int64_t ld, double* out, int lift) {
+diag_stats_kernel(T* A, int64_t n, int64_t ld, double* out, int lift, int64_t bstride) {
+  A += (int64_t)blockIdx.x * bstride;            // batch member (grid.x)
+  if (out) out += 3 * blockIdx.x;
   __shared__ double s_min[16], s_max[16], s_sum[16];
   __shared__ double s_m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -297,7 +285,10 @@ __global__ void scrub_kernel(T* A, int64_t n2, int64_t ld) {
 // out[0] = sum log L_ii ; out[1] = sum a_i^2 ; out[2] = #non-finite a ; out[3] = #bad diag
 template <typename T>
 __global__ void __launch_bounds__(1024)
-logp_terms_kernel(const T* L, int64_t n, int64_t ld, const T* a, double* out) {
+logp_terms_kernel(const T* L, int64_t n, int64_t ld, const T* a, double* out, int64_t bstride, int64_t astride) {
+  L += (int64_t)blockIdx.x * bstride;            // batch member (grid.x)
+  if (a) a += (int64_t)blockIdx.x * astride;
+  out += 4 * blockIdx.x;
   __shared__ double s0[16], s1[16], s2[16], s3[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double ld_sum = 0, ss = 0, nf = 0, bd = 0;
@@ -353,9 +344,9 @@ static int fetch_stats(g3_ctx* ctx, double* out, int cnt) {
 
 static int diag_stats_launch(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double* dout, int lift) {
   if (dt == G3_F64)
-    hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(1), dim3(1024), 0, ctx->stream, (double*)A, n, ld, dout, lift);
+    hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(1), dim3(1024), 0, ctx->stream, (double*)A, n, ld, dout, lift, (int64_t)0);
   else
-    hipLaunchKernelGGL((diag_stats_kernel<float>), dim3(1), dim3(1024), 0, ctx->stream, (float*)A, n, ld, dout, lift);
+    hipLaunchKernelGGL((diag_stats_kernel<float>), dim3(1), dim3(1024), 0, ctx->stream, (float*)A, n, ld, dout, lift, (int64_t)0);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -417,10 +408,10 @@ extern "C" int g3_scrub(g3_ctx* ctx, void* A, int64_t n1, int64_t n2, int64_t ld
 static int logp_terms_launch(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const void* a, g3_dtype dt) {
   if (dt == G3_F64)
     hipLaunchKernelGGL((logp_terms_kernel<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double*)L, n, ld,
-                       (const double*)a, ctx->d_stats);
+                       (const double*)a, ctx->d_stats, (int64_t)0, (int64_t)0);
   else
     hipLaunchKernelGGL((logp_terms_kernel<float>), dim3(1), dim3(1024), 0, ctx->stream, (const float*)L, n, ld,
-                       (const float*)a, ctx->d_stats);
+                       (const float*)a, ctx->d_stats, (int64_t)0, (int64_t)0);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -462,8 +453,11 @@ extern "C" int g3_rows_dot_ss(g3_ctx* ctx, const void* V, int64_t m, int64_t n, 
 
 // ----------------------------------------------------------------------------- fused path
 template <typename T>
-__global__ void pad_row_kernel(T* dst, int64_t ld, const T* src, int64_t n, int64_t npad, int64_t rows) {
-  // dst is rows x npad (row stride ld): row 0 = [src, 0...], other rows 0
+__global__ void pad_row_kernel(T* dst, int64_t ld, const T* src, int64_t n, int64_t npad, int64_t rows,
+                               int64_t dstride, int64_t sstride) {
+  // dst is rows x npad (row stride ld): row 0 = [src, 0...], other rows 0; grid.y = batch member
+  dst += (int64_t)blockIdx.y * dstride;
+  src += (int64_t)blockIdx.y * sstride;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
   for (int64_t r = 0; r < rows; ++r) dst[r * ld + j] = (r == 0 && j < n) ? src[j] : T(0);
@@ -491,10 +485,10 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     const unsigned nb = (unsigned)((Np + 255) / 256);
     if (dt == G3_F64)
       hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)rhs, ldk,
-                         (const double*)delta, N, Np, RB);
+                         (const double*)delta, N, Np, RB, (int64_t)0, (int64_t)0);
     else
       hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)rhs, ldk,
-                         (const float*)delta, N, Np, RB);
+                         (const float*)delta, N, Np, RB, (int64_t)0, (int64_t)0);
     G3_LAUNCH_CHECK();
     if (M > 0) {
       // V = tt_to_num(cov(Xs, X))  (elliptical.py:78-79)
@@ -598,6 +592,148 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
   out[4] = fallback;
   out[5] = (double)info0;
   return G3_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Batched evaluation: the caller pattern of logp_chain / fixed_logp / find_MAP restarts
+// (stochastic.py:515-564, 740-771: a Python loop, "TODO: Vectorized" in the reference) --
+// many hyper-parameter vectors on the same inputs.  All `batch` covariances are built by one
+// Gram launch (grid.z) and factored by ONE sweep whose GEMM / diagonal-block launches carry the
+// batch in grid.y, so a problem too small to fill 256 CUs on its own still does.
+static int same_structure(const g3_kernel_prog* a, const g3_kernel_prog* b) {
+  if (a->nleaf != b->nleaf || a->nprod != b->nprod) return 0;
+  for (int l = 0; l < a->nleaf; ++l) {
+    if (a->leaf[l].kind != b->leaf[l].kind || a->leaf[l].ndims != b->leaf[l].ndims) return 0;
+    for (int k = 0; k < a->leaf[l].ndims; ++k)
+      if (a->leaf[l].dims[k] != b->leaf[l].dims[k]) return 0;
+  }
+  for (int q = 0; q < a->nprod; ++q) {
+    if (a->prod[q].nfac != b->prod[q].nfac) return 0;
+    for (int f = 0; f < a->prod[q].nfac; ++f)
+      if (a->prod[q].fac[f] != b->prod[q].fac[f]) return 0;
+  }
+  return 1;
+}
+
+static int ensure_bbuf(g3_ctx* ctx, size_t bytes) {
+  if (ctx->bbuf_bytes >= bytes) return G3_OK;
+  if (ctx->bbuf) (void)hipFree(ctx->bbuf);
+  ctx->bbuf = nullptr;
+  ctx->bbuf_bytes = 0;
+  G3_HIP(hipMalloc(&ctx->bbuf, bytes));
+  ctx->bbuf_bytes = bytes;
+  return G3_OK;
+}
+
+extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const void* X, int64_t N,
+                                    int64_t ldx, int d, const void* delta, int64_t ldd, g3_dtype dt, void* K,
+                                    int64_t ldk, int64_t kstride, void* invd, void* a, double* out) {
+  if (!ctx) return -1;
+  if (!progs) return -2;
+  if (batch < 1 || batch > G3_MAX_BATCH) return -3;
+  if (!X) return -4;
+  if (N <= 0) return -5;
+  if (d < 1 || d > G3_MAXCOLS) return -7;
+  if (ldx < d) return -6;
+  if (!delta) return -8;
+  if (ldd < N) return -9;
+  if (!K) return -11;
+  const int64_t Np = g3_roundup(N, G3_LB), RB = 128;
+  const size_t es = g3_esize(dt);
+  const int64_t al = 16 / (int64_t)es;
+  if (ldk < Np || ldk % al) return -12;
+  if (kstride < (Np + RB) * ldk || kstride % al) return -13;
+  if (!invd) return -14;
+  if (!a) return -15;
+  if (!out) return -16;
+  for (int b = 0; b < batch; ++b) {
+    if (g3i_validate_prog(&progs[b], d)) return -2;
+    if (!same_structure(&progs[0], &progs[b])) return -2;
+  }
+  int rc = G3_OK;
+  if (batch == 1)
+    return gp_factor_impl(ctx, progs, X, N, ldx, d, delta, dt, K, ldk, invd, a, out, nullptr, nullptr, 0, 0, nullptr,
+                          nullptr);
+  // device copies of the programs, then the per-member statistics
+  const size_t pbytes = (size_t)batch * sizeof(g3_kernel_prog);
+  const size_t sbytes = (size_t)batch * 4 * sizeof(double);
+  rc = ensure_bbuf(ctx, pbytes + sbytes);
+  if (rc) return rc;
+  g3_kernel_prog* dprogs = (g3_kernel_prog*)ctx->bbuf;
+  double* dstats = (double*)((char*)ctx->bbuf + pbytes);
+  G3_HIP(hipMemcpyAsync(dprogs, progs, pbytes, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t wstride = Np * G3_LB;
+  // K_b = tt_to_cov(cov(X)) (elliptical.py:70-71), right-hand-side block = [delta_b; 0]
+  int pr = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)batch * ((double)N * d + 0.5 * (double)N * (N + 1)) * es);
+  rc = g3i_gram_batched(ctx, dprogs, progs, batch, X, N, ldx, d, dt, K, ldk, kstride, Np,
+                        G3_GRAM_LOWER | G3_GRAM_SCRUB | G3_GRAM_PAD_EYE);
+  if (rc) return rc;
+  const unsigned nb = (unsigned)((Np + 255) / 256);
+  char* rhs = (char*)K + (size_t)Np * ldk * es;
+  if (dt == G3_F64) {
+    hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(batch), dim3(1024), 0, ctx->stream, (double*)K, N, ldk,
+                       (double*)nullptr, 1, kstride);
+    hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb, batch), dim3(256), 0, ctx->stream, (double*)rhs, ldk,
+                       (const double*)delta, N, Np, RB, kstride, ldd);
+  } else {
+    hipLaunchKernelGGL((diag_stats_kernel<float>), dim3(batch), dim3(1024), 0, ctx->stream, (float*)K, N, ldk,
+                       (double*)nullptr, 1, kstride);
+    hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb, batch), dim3(256), 0, ctx->stream, (float*)rhs, ldk,
+                       (const float*)delta, N, Np, RB, kstride, ldd);
+  }
+  g3i_prof_end(ctx, pr);
+  G3_LAUNCH_CHECK();
+  // one sweep factors every member; a member whose pivot fails only stops its own launches
+  ctx->batch = batch;
+  ctx->bstride = kstride;
+  ctx->bstride_w = wstride;
+  ctx->bw_base = (const char*)invd;
+  ctx->bw_bytes = (size_t)batch * wstride * es;
+  pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)batch * ((double)N * N * N / 3.0 + (double)N * N));
+  rc = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, RB);
+  g3i_prof_end(ctx, pr);
+  if (!rc && hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    rc = G3_ERR_HIP;
+  if (!rc) rc = g3i_reset_info(ctx);
+  ctx->batch = 0;
+  ctx->bw_base = nullptr;
+  if (rc) return rc;
+  // a_b = first row of the solved right-hand-side block; log det and a^T a per member
+  G3_HIP(hipMemcpy2DAsync(a, (size_t)Np * es, rhs, (size_t)kstride * es, (size_t)Np * es, (size_t)batch,
+                          hipMemcpyDeviceToDevice, ctx->stream));
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((logp_terms_kernel<double>), dim3(batch), dim3(1024), 0, ctx->stream, (const double*)K, N, ldk,
+                       (const double*)a, dstats, kstride, Np);
+  else
+    hipLaunchKernelGGL((logp_terms_kernel<float>), dim3(batch), dim3(1024), 0, ctx->stream, (const float*)K, N, ldk,
+                       (const float*)a, dstats, kstride, Np);
+  G3_LAUNCH_CHECK();
+  double* hst = (double*)malloc(sbytes);
+  if (!hst) return G3_ERR_NOMEM;
+  if (hipMemcpyAsync(hst, dstats, sbytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    free(hst);
+    snprintf(ctx->err, sizeof(ctx->err), "g3_gp_factor_batched: statistics copy failed");
+    return G3_ERR_HIP;
+  }
+  int* infos = (int*)malloc(sizeof(int) * batch);
+  if (!infos) { free(hst); return G3_ERR_NOMEM; }
+  memcpy(infos, ctx->h_info, sizeof(int) * batch);
+  for (int b = 0; b < batch && !rc; ++b) {
+    double* o = out + 6 * b;
+    if (infos[b] == 0) {
+      o[0] = hst[4 * b]; o[1] = hst[4 * b + 1]; o[2] = hst[4 * b + 2];
+      o[3] = 0; o[4] = 0; o[5] = 0;
+    } else {
+      // CholeskyRobust's jitter schedule (tensors.py:203-222) for this member alone
+      rc = gp_factor_impl(ctx, &progs[b], X, N, ldx, d, (const char*)delta + (size_t)b * ldd * es, dt,
+                          (char*)K + (size_t)b * kstride * es, ldk, (char*)invd + (size_t)b * wstride * es,
+                          (char*)a + (size_t)b * Np * es, o, nullptr, nullptr, 0, 0, nullptr, nullptr);
+    }
+  }
+  free(hst);
+  free(infos);
+  return rc;
 }
 
 extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N,

@@ -29,8 +29,14 @@ constexpr int GROUP_M = 4; // row-blocks per raster group
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
 gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
-               int K, T alpha, T beta, int lower_only, const int* __restrict__ info, int tiles_m, int tiles_n) {
+               int K, T alpha, T beta, int lower_only, const int* __restrict__ info, int tiles_m, int tiles_n,
+               int64_t bsC, int64_t bsA, int64_t bsB) {
   using M = MfmaT<T>;
+  // batch member (grid.y); strides are 0 for a single product
+  C += (int64_t)blockIdx.y * bsC;
+  A += (int64_t)blockIdx.y * bsA;
+  B += (int64_t)blockIdx.y * bsB;
+  if (info != nullptr) info += blockIdx.y;
   using chunk_t = typename M::chunk_t;
   using acc_t = typename M::acc_t;
   constexpr int EPC = M::EPC;
@@ -219,7 +225,7 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
       nv += (g == ngroups - 1) ? (long long)rows * nc : (long long)GROUP_M * nc;
     }
   }
-  dim3 grid((unsigned)nv);
+  dim3 grid((unsigned)nv, (unsigned)g3_nbatch(ctx));
   // algorithmic flops: 2 k per output element that is wanted.  Profiling
   // tag: launches of the 128 x 128 tile with >= 1024 tiles are the bulk panel updates
   const int tag = (BM == 128 && BN == 128) ? (nv >= 1024 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
@@ -228,7 +234,8 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
                                   : (double)m * n;
   const int pr = g3i_prof_begin(ctx, tag, 2.0 * elems * (double)k);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, ctx->stream, (T*)C, ldc, (const T*)A, lda,
-                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info, tiles_m, tiles_n);
+                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info, tiles_m, tiles_n,
+                     g3_bstride_of(ctx, C), g3_bstride_of(ctx, A), g3_bstride_of(ctx, B));
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -240,7 +247,7 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
                     int lower_only, int wide) {
   // tile choice: big tiles when they still fill the chip, small tiles for the narrow
   // panel / leaf operations on the critical path of the factorisation
-  const int64_t blocks128 = (m / 128) * (n / 128) / (lower_only ? 2 : 1);
+  const int64_t blocks128 = (m / 128) * (n / 128) / (lower_only ? 2 : 1) * g3_nbatch(ctx);
   static int forced = -1;   // G3_GEMM_CFG: development override of the tile choice
   if (forced < 0) {
     const char* e = getenv("G3_GEMM_CFG");

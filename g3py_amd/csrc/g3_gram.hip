@@ -179,7 +179,11 @@ template <typename T, int D, bool SE_FAST>
 __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
             int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
-            T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym, int ntrig) {
+            T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym, int ntrig,
+            int64_t kstride) {
+  // grid.z = batch member: its own program (hyper-parameters) and output matrix, same inputs
+  if constexpr (!SE_FAST) prog += blockIdx.z;
+  K += (int64_t)blockIdx.z * kstride;
   int64_t bi = blockIdx.y, bj = blockIdx.x;
   if (flags & G3_GRAM_LOWER) {
     // 1-D grid over the tiles on or below the diagonal only: row-block b has b/2 + 1 column
@@ -320,7 +324,9 @@ int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_
   return G3_OK;
 }
 
-static int validate_prog(const g3_kernel_prog* p, int d) {
+int g3i_validate_prog(const g3_kernel_prog* p, int d);
+static int validate_prog(const g3_kernel_prog* p, int d) { return g3i_validate_prog(p, d); }
+int g3i_validate_prog(const g3_kernel_prog* p, int d) {
   if (p->nleaf < 0 || p->nleaf > G3_MAXLEAF || p->nprod < 0 || p->nprod > G3_MAXPROD) return 1;
   for (int l = 0; l < p->nleaf; ++l) {
     const g3_leaf& lf = p->leaf[l];
@@ -384,7 +390,7 @@ static int launch_gram_fast(g3_ctx* ctx, const SeParams<T, D>& se, const T* X1, 
   const size_t lds = (GT + GTN) * (D | 1) * sizeof(T);
   hipLaunchKernelGGL((gram_kernel<T, D, true>), grid, dim3(256), lds, ctx->stream,
                      (const g3_kernel_prog*)nullptr, se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad,
-                     n2pad, flags, sym, 0);
+                     n2pad, flags, sym, 0, (int64_t)0);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -418,10 +424,38 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
   SeParams<T, 1> dummy{};
   hipLaunchKernelGGL((gram_kernel<T, 1, false>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
-                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig);
+                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig, (int64_t)0);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
+
+// `batch` square Gram matrices of the same inputs, member b from dprogs[b] (device array, all of
+// one structure) into K + b * kstride: the generic kernel with grid.z = batch
+int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_prog* first_host, int batch,
+                     const void* X, int64_t n, int64_t ldx, int d, g3_dtype dt, void* K, int64_t ldk,
+                     int64_t kstride, int64_t npad, unsigned flags) {
+  dim3 grid = gram_grid(npad, npad, flags);
+  grid.z = (unsigned)batch;
+  int ntrig = prog_trig_pairs(first_host);
+  if (ntrig > 16) ntrig = 0;
+  if (dt == G3_F64) {
+    const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(double);
+    SeParams<double, 1> dummy{};
+    hipLaunchKernelGGL((gram_kernel<double, 1, false>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
+                       (const double*)X, n, ldx, (const double*)X, n, ldx, d, (double*)K, ldk, npad, npad, flags, 1,
+                       ntrig, kstride);
+  } else {
+    const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(float);
+    SeParams<float, 1> dummy{};
+    hipLaunchKernelGGL((gram_kernel<float, 1, false>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
+                       (const float*)X, n, ldx, (const float*)X, n, ldx, d, (float*)K, ldk, npad, npad, flags, 1,
+                       ntrig, kstride);
+  }
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+int g3i_validate_prog(const g3_kernel_prog* p, int d);
 
 extern "C" int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X1, int64_t n1, int64_t ldx1,
                        const void* X2, int64_t n2, int64_t ldx2, int d, g3_dtype dt, void* K, int64_t ldk,

@@ -18,8 +18,17 @@ struct g3_ctx {
   int la_nev;
   int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
   bool adopted;            // stream belongs to the caller
+  // batch mode (g3_gp_factor_batched): every MFMA GEMM and diagonal-block launch of a sweep acts on
+  // `batch` matrices at once (grid.y); operands inside the block-inverse buffer [bw_base, +bw_bytes)
+  // are `bstride_w` elements apart, everything else `bstride` elements
+  int batch;
+  int64_t bstride, bstride_w;
+  const char* bw_base;
+  size_t bw_bytes;
+  void* bbuf;              // device scratch of the batched entry points (programs, statistics)
+  size_t bbuf_bytes;
   // small device scratch
-  int* d_info;             // potrf info flag
+  int* d_info;             // potrf info flag (one per batch member, G3_MAX_BATCH of them)
   double* d_stats;         // 64 doubles of reduction outputs
   g3_kernel_prog* d_prog;  // kernel program (device copy, 2 slots)
   // pinned host mirrors
@@ -69,6 +78,15 @@ void g3i_prof_end(g3_ctx* ctx, int rec);
     }                                                                                         \
   } while (0)
 
+#define G3_MAX_BATCH 4096
+static inline int g3_nbatch(const g3_ctx* ctx) { return ctx->batch > 1 ? ctx->batch : 1; }
+// element stride between batch members for an operand at p (0 outside batch mode)
+static inline int64_t g3_bstride_of(const g3_ctx* ctx, const void* p) {
+  if (ctx->batch <= 1) return 0;
+  const char* c = (const char*)p;
+  return (ctx->bw_base && c >= ctx->bw_base && c < ctx->bw_base + ctx->bw_bytes) ? ctx->bstride_w : ctx->bstride;
+}
+
 static inline size_t g3_esize(g3_dtype dt) { return dt == G3_F64 ? 8 : 4; }
 static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
@@ -89,5 +107,9 @@ int g3i_reset_info(g3_ctx* ctx);
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt);
 int g3i_ensure_work(g3_ctx* ctx, size_t bytes);
 int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr);
+int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_prog* first_host, int batch,
+                     const void* X, int64_t n, int64_t ldx, int d, g3_dtype dt, void* K, int64_t ldk,
+                     int64_t kstride, int64_t npad, unsigned flags);
+int g3i_validate_prog(const g3_kernel_prog* p, int d);
 int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* invd, g3_dtype dt, void* Y,
               int64_t ldy, void* C, int64_t ldc);

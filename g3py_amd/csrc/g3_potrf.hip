@@ -152,13 +152,14 @@ __device__ __noinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t ba
 template <typename T, bool FACTOR>
 __global__ void __launch_bounds__(512)
 diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, int* info,
-                int64_t row_base) {
+                int64_t row_base, int64_t a_batch, int64_t w_batch) {
   using TO = TileOps<T>;
   using acc_t = typename TO::acc_t;
   using M = MfmaT<T>;
+  info += blockIdx.y;                       // batch member (grid.y)
   if (FACTOR && *info != 0) return;
-  A += (int64_t)blockIdx.x * a_stride;
-  W += (int64_t)blockIdx.x * w_stride;
+  A += (int64_t)blockIdx.x * a_stride + (int64_t)blockIdx.y * a_batch;
+  W += (int64_t)blockIdx.x * w_stride + (int64_t)blockIdx.y * w_batch;
   row_base += (int64_t)blockIdx.x * G3_LB;
   __shared__ DiagLds<T> S;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   // wave w owns block row w
@@ -244,8 +245,8 @@ static int64_t split_point(int64_t n, int64_t unit) {
 template <typename T>
 static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_dtype dt) {
   const int pr = g3i_prof_begin(ctx, G3_TAG_LEAF, 128.0 * 128.0 * 128.0 / 3.0);
-  hipLaunchKernelGGL((diag128m_kernel<T, true>), dim3(1), dim3(512), 0, ctx->stream, A, ld, (int64_t)0, W, LB,
-                     (int64_t)0, ctx->d_info, row_base);
+  hipLaunchKernelGGL((diag128m_kernel<T, true>), dim3(1, (unsigned)g3_nbatch(ctx)), dim3(512), 0, ctx->stream, A, ld,
+                     (int64_t)0, W, LB, (int64_t)0, ctx->d_info, row_base, g3_bstride_of(ctx, A), g3_bstride_of(ctx, W));
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -283,7 +284,7 @@ static int potrf_rec(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t row
 }
 
 int g3i_reset_info(g3_ctx* ctx) {
-  G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
   return G3_OK;
 }
 
@@ -395,7 +396,7 @@ int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* in
 // right-hand sides B: on return those rows hold B L^-T (the forward substitution rides along
 // with the panel solves and trailing updates of the factorisation -- no separate trsm pass).
 int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd, int64_t E) {
-  G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
   if (n == 0) return G3_OK;
 
   int64_t NB = ctx->nb_lookahead;
@@ -430,13 +431,13 @@ int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtyp
 
   const unsigned nb = (unsigned)(n / LB);
   if (dt == G3_F64)
-    hipLaunchKernelGGL((diag128m_kernel<double, false>), dim3(nb), dim3(512), 0, ctx->stream,
+    hipLaunchKernelGGL((diag128m_kernel<double, false>), dim3(nb, (unsigned)g3_nbatch(ctx)), dim3(512), 0, ctx->stream,
                        (double*)const_cast<void*>(L), ldl, LB * (ldl + 1), (double*)invd, LB, LB * LB,
-                       ctx->d_info, (int64_t)0);
+                       ctx->d_info, (int64_t)0, g3_bstride_of(ctx, L), g3_bstride_of(ctx, invd));
   else
-    hipLaunchKernelGGL((diag128m_kernel<float, false>), dim3(nb), dim3(512), 0, ctx->stream,
+    hipLaunchKernelGGL((diag128m_kernel<float, false>), dim3(nb, (unsigned)g3_nbatch(ctx)), dim3(512), 0, ctx->stream,
                        (float*)const_cast<void*>(L), ldl, LB * (ldl + 1), (float*)invd, LB, LB * LB,
-                       ctx->d_info, (int64_t)0);
+                       ctx->d_info, (int64_t)0, g3_bstride_of(ctx, L), g3_bstride_of(ctx, invd));
   G3_LAUNCH_CHECK();
   return G3_OK;
 }

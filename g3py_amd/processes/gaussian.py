@@ -147,6 +147,62 @@ class GaussianProcess(EllipticalProcess):
                 if getattr(h, 'name', None) in by_name:
                     nat[h.name] = nat[h.name] + (-alpha.dot(np.asarray(dinv, dtype=np.float64)) + float(dlogdet))
 
+    # ---- many hyper-parameter vectors on the same observations (stochastic.py:515-520)
+    def logp_chain(self, chain, prior=False, batch=None):
+        """one logp per row of a flat-parameter chain.  The reference loops over the rows
+        (stochastic.py:515-520; fixed_logp :526-532, "TODO: Vectorized"); here `batch` rows at a
+        time go through ONE Gram launch and ONE factorisation sweep (g3_gp_factor_batched), which
+        is what fills the GPU when a single N x N problem is too small to.  `batch` defaults to
+        as many members as fit in 4 GB of covariance workspace."""
+        chain = np.atleast_2d(np.asarray(chain, dtype=np.float64))
+        n_rows = len(chain)
+        t = self.dtype.type
+        out = np.empty(n_rows, dtype=self.dtype)
+        if prior or not self.is_observed or n_rows == 0:
+            for i in range(n_rows):
+                out[i] = self.logp(chain[i], array=True, prior=True)
+            return out
+        dev = self.device
+        X = self._x(self.inputs)
+        y = np.asarray(self.outputs, dtype=self.dtype).reshape(-1)
+        N, d = X.shape
+        Np = _lib.roundup(N)
+        kstride = (Np + _lib.G3_RHS_PAD) * Np
+        if batch is None:
+            batch = int(4e9 // (kstride * self.dtype.itemsize))
+        batch = max(1, min(int(batch), n_rows, _lib.G3_MAX_BATCH))
+        Xd = dev.upload(X)
+        K = dev.alloc(batch * (Np + _lib.G3_RHS_PAD), Np, self.dtype)
+        W = dev.alloc(batch * Np, _lib.G3_PAD, self.dtype)
+        a = dev.alloc(batch, Np, self.dtype)
+        npi = t(-0.5) * t(N) * np.log(t(2.0 * np.pi))
+        for lo in range(0, n_rows, batch):
+            rows = range(lo, min(lo + batch, n_rows))
+            progs, deltas, consts, live = [], [], [], []
+            for i in rows:
+                params = self.active.array_to_dict(chain[i])
+                values, logjac = self._values(params)
+                with np.errstate(all='ignore'):
+                    delta = np.asarray(self.f_mapping.inv(y, values), dtype=self.dtype) - self.f_location(X, values)
+                    det_m = self.f_mapping.logdet_dinv(y, values)
+                if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):     # gaussian.py:234-235
+                    out[i] = t(logjac + t(SENTINEL))
+                    continue
+                progs.append(self._prog(self.f_kernel_noise, values, d))
+                deltas.append(delta)
+                consts.append((logjac, det_m))
+                live.append(i)
+            if not live:
+                continue
+            dd = dev.upload(np.stack(deltas).astype(self.dtype))
+            stats = dev.gp_factor_batched(progs, Xd, N, d, dd, K, kstride, W, a)
+            for i, st, (logjac, det_m) in zip(live, stats, consts):
+                if not np.isfinite(st['logdet']) or st['nonfinite'] > 0:                  # gaussian.py:237
+                    out[i] = t(logjac + t(SENTINEL))
+                else:
+                    out[i] = t(logjac + t(npi + t(-0.5) * t(st['quad']) - t(st['logdet']) + det_m))
+        return out
+
     def th_logpredictive(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         loc, sd, values = self._loc_sd(space, inputs, outputs, params, prior, noise, sd_noise=True)
         return logp_cho_diag(vector, loc, sd, self.f_mapping, values, self.dtype)

@@ -227,6 +227,21 @@ int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_de
                 int64_t ldl, const void* invd_dev, const void* a_dev, g3_dtype dt, void* V_dev, int64_t ldv,
                 void* mu_dev, void* ss_dev);
 
+/* ---- batched evaluation -----------------------------------
+ * `batch` independent g3_gp_factor evaluations on the SAME inputs X with different kernel
+ * hyper-parameters and right-hand sides: the caller pattern of logp_chain / fixed_logp /
+ * find_MAP restarts (g3py/processes/stochastic.py:515-564, 740-771 -- a Python loop in the
+ * reference).  progs_host[b] must all have the same structure (leaf kinds, dims, products);
+ * delta_dev is batch x N with row stride ldd; K_dev holds the members kstride elements apart,
+ * each laid out as for g3_gp_factor ((roundup(N,128)+128) x ldk); invd_dev is batch x
+ * roundup(N,128) x 128; a_dev is batch x roundup(N,128); out_host is batch x 6 (as g3_gp_factor).
+ * One Gram launch (grid.z = batch) and ONE factorisation sweep whose MFMA-GEMM and
+ * diagonal-block launches carry the batch in grid.y; members whose first factorisation fails are
+ * re-run one at a time through the jitter schedule (tensors.py:203-222).  batch <= 4096. */
+int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs_host, int batch, const void* X_dev, int64_t N,
+                         int64_t ldx, int d, const void* delta_dev, int64_t ldd, g3_dtype dt, void* K_dev,
+                         int64_t ldk, int64_t kstride, void* invd_dev, void* a_dev, double* out_host);
+
 /* ---- gradient of logp w.r.t. the kernel hyper-parameters ----
  * Reference: StochasticProcess.th_dlogp = gradient(th_logp) (g3py/processes/stochastic.py:308-309;
  * g3py/libs/tensors.py:11-22), i.e. Theano's reverse mode through logp_cho (gaussian.py:208-224)

@@ -309,3 +309,48 @@ def test_dlogp_edge_branches():
     rj = orc.GP(('SE', 1.0, np.array([1.0]), None), None).dlogp_natural(Xd, yd)
     wantj = np.array([v for *_, v in rj['kernel']])
     np.testing.assert_allclose(got, wantj, rtol=1e-4, atol=1e-4 * np.abs(wantj).max())
+
+
+# ------------------------------------------------------------------ batched chains (stochastic.py:515-520)
+@pytest.mark.parametrize('name', ['gp_se_bias', 'gp_mat52cos_zero', 'wgp_boxcox', 'wgp_linear'])
+def test_logp_chain_batched_equals_row_by_row(golden_dir, name):
+    """g3_gp_factor_batched: every member of the batch equals the single evaluation of the same row
+    (and therefore the oracle fixture), including a row that needs the jitter schedule's neighbours"""
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs, y = g['X'], g['Xs'], g[name + '_y']
+    cls, kw, nat = PROCS[name](g3, X)
+    gp = cls(space=Xs, **kw)
+    gp.observed(X, y)
+    a0 = gp.active.dict_to_array(_params(gp, **nat))
+    rng = np.random.default_rng(3)
+    chain = a0 + 0.2 * rng.standard_normal((37, len(a0)))
+    chain[0] = a0
+    want = np.array([gp.logp(r, array=True) for r in chain])
+    got = gp.logp_chain(chain, batch=16)                       # 3 sweeps: 16 + 16 + 5 members
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    assert abs(got[0] - float(g[name + '_logp'])) <= 1e-8 * abs(float(g[name + '_logp']))
+    np.testing.assert_allclose(gp.logp_chain(chain), want, rtol=1e-10)      # one sweep
+
+
+def test_logp_chain_batched_edge_members():
+    """members that hit the -1e30 sentinel, the -inf Jacobian and the jitter schedule inside one batch"""
+    import g3py_amd as g3
+    rng = np.random.default_rng(4)
+    X = np.repeat(rng.uniform(0, 3, (40, 1)), 2, axis=0)      # duplicated inputs: singular without noise
+    y = np.sin(X[:, 0]) + 2.0
+    gp = g3.WarpedGaussianProcess(space=X, location=g3.Zero(), kernel=g3.SE(X), mapping=g3.LogShifted())
+    gp.observed(X, y)
+    base = _params(gp, SE_var=1.0, SE_rate=[1.0], Noise_var=0.1, LogShifted_shift=0.0)
+    rows = []
+    for noise, shift in [(0.1, 0.0), (1e-14, 0.0), (0.1, 5.0), (1e-7, 0.0), (0.3, -1.0)]:
+        p = dict(base)
+        p['WGP_Noise_var_log_'] = np.log(noise)
+        p['WGP_LogShifted_shift'] = np.asarray(shift)
+        rows.append(gp.active.dict_to_array(p))
+    chain = np.stack(rows)
+    want = np.array([gp.logp(r, array=True) for r in chain])
+    got = gp.logp_chain(chain)
+    assert want[2] == np.float32(-1e30) and want[3] == -np.inf     # log of a negative number; exp(x) <= 1e-6
+    np.testing.assert_array_equal(got[[2, 3]], want[[2, 3]])
+    np.testing.assert_allclose(got[[0, 1, 4]], want[[0, 1, 4]], rtol=1e-9)

@@ -167,3 +167,28 @@ def test_dlogp_n8192_identities(dev):
         return _factor(dev, orc.with_noise(('SE', var * e[0], rate * e[1:1 + d], None), noise * e[-1]), X, y)[0]
     fd = (logp(h) - logp(-h)) / (2 * h)
     assert abs(fd - g_log.dot(v)) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_batched_factor_n1024_b64(dev):
+    """64 SE hyper-parameter sets at N=1000 (ragged) in one sweep == 64 single evaluations"""
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d, B = 1000, 4, 64
+    X, y, _ = _synth(N, d, 8, 1010)
+    Np = _lib.roundup(N)
+    specs = [orc.with_noise(('SE', 1.0 + 0.01 * b, np.full(d, 1.0 + 0.005 * b), None), 0.1 + 0.001 * b) for b in range(B)]
+    progs = [compile_spec(s, d) for s in specs]
+    kstride = (Np + 128) * Np
+    K = dev.alloc(B * (Np + 128), Np, np.float64)
+    W = dev.alloc(B * Np, 128, np.float64)
+    a = dev.alloc(B, Np, np.float64)
+    deltas = np.stack([y + 0.01 * b for b in range(B)])
+    stats = dev.gp_factor_batched(progs, dev.upload(X), N, d, dev.upload(deltas), K, kstride, W, a)
+    for b in (0, 1, 31, 63):
+        lp, st, *_ = _factor(dev, specs[b], X, deltas[b])
+        got = -0.5 * N * np.log(2 * np.pi) - 0.5 * stats[b]['quad'] - stats[b]['logdet']
+        assert stats[b]['info'] == 0 and abs(got - lp) <= 1e-11 * abs(lp)
+    ref = orc.GP(specs[5][1], specs[5][2][1]).logp(X, deltas[5])
+    got5 = -0.5 * N * np.log(2 * np.pi) - 0.5 * stats[5]['quad'] - stats[5]['logdet']
+    assert abs(got5 - ref) <= 1e-9 * abs(ref)
