@@ -1,4 +1,4 @@
-from .hypers import Hypers, HyperVar, Model
+from .hypers import Hypers, HyperVar, Model, Freedom
 from .hypers.metrics import *
 from .hypers.kernels import *
 from .hypers.means import *
@@ -6,7 +6,10 @@ from .hypers.mappings import *
 from .stochastic import StochasticProcess, GraphicalModel
 from .elliptical import EllipticalProcess
 from .gaussian import GaussianProcess, WarpedGaussianProcess
+from .studentT import StudentTProcess, WarpedStudentTProcess
 
 # aliases of g3py/processes/__init__.py:9-16
 GP = GaussianProcess
 WGP = WarpedGaussianProcess
+TP = StudentTProcess
+WTP = WarpedStudentTProcess

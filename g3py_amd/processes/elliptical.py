@@ -53,11 +53,18 @@ class EllipticalProcess(StochasticProcess):
         self.f_location.check_potential()
         self.f_kernel_noise.check_potential()
         self.f_mapping.check_potential()
+        if self.f_degree is not None:                     # elliptical.py:49-52
+            self.f_degree.check_dims(None)
+            self.f_degree.check_hypers(self.name + '_')
+            self.f_degree.check_potential()
 
     def default_hypers(self):
         x, y = self.inputs, self.outputs
-        return {**self.f_location.default_hypers_dims(x, y), **self.f_kernel_noise.default_hypers_dims(x, y),
-                **self.f_mapping.default_hypers_dims(x, y)}
+        r = {**self.f_location.default_hypers_dims(x, y), **self.f_kernel_noise.default_hypers_dims(x, y),
+             **self.f_mapping.default_hypers_dims(x, y)}
+        if self.f_degree is not None:
+            r.update(self.f_degree.default_hypers_dims(x, y))
+        return r
 
     # ---------------------------------------------------------------- helpers
     def _values(self, params):
@@ -181,6 +188,23 @@ class EllipticalProcess(StochasticProcess):
     def th_define_process(self):
         pass   # the symbolic graph of elliptical.py:60-107 is replaced by the methods below
 
+    def th_freedom(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        """prior degrees of freedom, plus the number of observations a posteriori (elliptical.py:109-113)"""
+        if self.f_degree is None:
+            return None
+        values, _ = self._values(params)
+        nu = self.f_degree(values)
+        return self.dtype.type(nu if prior else nu + len(np.asarray(inputs)))
+
+    def th_logp(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        """sum of the free variables' log-densities (Flat: 0; FlatExp: the log-transform Jacobian
+        term; potentials) plus the observed term unless prior (stochastic.py:300-306)"""
+        _, logjac = self._values(params)
+        t = self.dtype.type
+        if prior:
+            return t(logjac)
+        return t(logjac + self.th_loglike(space, inputs, outputs, vector, params))
+
     def th_mapping_inv(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         values, _ = self._values(params)
         with np.errstate(all='ignore'):
@@ -290,4 +314,4 @@ class EllipticalProcess(StochasticProcess):
                 ('loglike', 'th_loglike'), ('mapping', 'th_mapping'), ('mapping_inv', 'th_mapping_inv'),
                 ('location', 'th_location'), ('kernel', 'th_kernel'), ('cholesky', 'th_cholesky'),
                 ('kernel_diag', 'th_kernel_diag'), ('kernel_sd', 'th_kernel_sd'),
-                ('cholesky_diag', 'th_cholesky_diag'), ('cross_mean', 'th_cross_mean'))
+                ('cholesky_diag', 'th_cholesky_diag'), ('cross_mean', 'th_cross_mean'), ('freedom', 'th_freedom'))

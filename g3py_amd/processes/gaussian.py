@@ -61,15 +61,6 @@ class GaussianProcess(EllipticalProcess):
         npi = t(-0.5) * t(n) * np.log(t(2.0 * np.pi))               # :218
         return t(npi + t(-0.5) * t(st['quad']) - t(st['logdet']) + c['det_m'])   # :219-232
 
-    def th_logp(self, space, inputs, outputs, vector, params, prior=False, noise=False):
-        """sum of the free variables' log-densities (Flat: 0; FlatExp: the log-transform
-        Jacobian term) plus the observed term unless prior (stochastic.py:300-306)"""
-        _, logjac = self._values(params)
-        t = self.dtype.type
-        if prior:
-            return t(logjac)
-        return t(logjac + self.th_loglike(space, inputs, outputs, vector, params))
-
     # ---- gradient of logp (stochastic.py:308-309; tensors.py:11-22, 224-260)
     def th_dlogp(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         """tt_to_num(gradient(th_logp, free variables)): flat vector over the model's variables in

@@ -161,6 +161,31 @@ class Hypers:
         return modelcontext().add(HyperVar(name, shape, positive=True))
 
 
+class Freedom(Hypers):
+    """degrees of freedom of the Student-t process: bound + degree with degree > 0
+    (hypers/__init__.py:144-160)"""
+
+    def __init__(self, x=None, name=None, degree=None, bound=np.float32(2.0)):
+        super().__init__(x, name)
+        self.degree = degree
+        self.bound = bound
+
+    def check_hypers(self, parent=''):
+        super().check_hypers(parent=parent)
+        if self.degree is None:
+            self.degree = Hypers.FlatExp(parent + self.name + '_degree')
+        self.hypers += [self.degree]
+
+    def default_hypers(self, x=None, y=None):
+        return {self.degree: np.float64(y.shape[0])}
+
+    def default_hypers_dims(self, x=None, y=None):
+        return dict(self.default_hypers(x, y))
+
+    def __call__(self, values=None):
+        return float(self.bound) + float(np.asarray(value_of(self.degree, values or {})))
+
+
 def value_of(h, values):
     """numeric value of a hyper slot: HyperVar -> looked up (natural space), constant -> itself"""
     if isinstance(h, HyperVar):

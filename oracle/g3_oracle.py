@@ -658,6 +658,72 @@ class GP:
         return out
 
 
+def logp_cho_t(value, mu, cho, freedom, mapping):
+    """WarpedStudentTDistribution.logp_cho -- g3py/processes/studentT.py:114-146."""
+    t = cho.dtype.type
+    delta_ = mapping.inv(value) - mu                                    # :115
+    if np.any(~np.isfinite(delta_)):
+        return t(np.float32(-1e30))
+    det_m = mapping.logdet_dinv(value)                                  # :130
+    if np.any(~np.isfinite(det_m)) or np.any(~np.isfinite(cho)):
+        return t(np.float32(-1e30))
+    with np.errstate(all='ignore'):
+        lcho = sp.linalg.solve_triangular(cho, delta_, lower=True, check_finite=False)   # :117
+        beta = lcho.T.dot(lcho)                                         # :118
+        n = t(cho.shape[0])
+        nu = t(freedom)
+        r1 = t(-0.5) * (nu + n) * np.log1p(beta / (nu - t(2)))          # :124
+        if t(np.float32(1e6)) <= nu:                                    # :125-126
+            r2 = -n * t(0.5) * np.log(t(2.0 * np.float32(np.pi)))
+        else:
+            from scipy.special import gammaln
+            r2 = t(gammaln((nu + n) * 0.5) - gammaln(nu * 0.5)) - t(0.5) * n * np.log((nu - t(2)) * t(np.float32(np.pi)))
+        r3 = -np.sum(np.log(np.diag(cho)))                              # :128
+    if np.any(~np.isfinite(lcho)):
+        return t(np.float32(-1e30))
+    return r1 + r2 + r3 + det_m                                         # :135
+
+
+class TP(GP):
+    """StudentTProcess / WarpedStudentTProcess -- g3py/processes/studentT.py:16-102.
+    `degree`: the FlatExp hyper; freedom = bound + degree with bound = 2 (hypers/__init__.py:144-160)."""
+
+    def __init__(self, kernel_f, degree, noise_var=None, mean=('Zero',), mapping=('Identity',), dtype=np.float64):
+        super().__init__(kernel_f, noise_var, mean, mapping, dtype)
+        self.degree = degree
+
+    def freedom(self, inputs=None, prior=False):
+        nu = float(np.float32(2.0)) + self.degree                      # Freedom.__call__
+        return nu if prior else nu + len(inputs)                       # elliptical.py:109-113
+
+    def scaling(self, inputs, outputs, prior=False):
+        """studentT.py:36-44"""
+        if prior:
+            return self.t(1.0)
+        cho = cholesky_robust(self.prior_kernel(inputs, True))
+        alpha = sp.linalg.solve_triangular(cho, self.mapping_outputs(outputs) - self.prior_location(inputs), lower=True)
+        beta = alpha.T.dot(alpha)
+        return (self.freedom(prior=True) + beta - 2.0) / (self.freedom(inputs) - 2.0)
+
+    def variance(self, space, inputs=None, outputs=None, prior=False, noise=False):
+        if self.warped:     # WarpedStudentTProcess.th_variance: Gauss-Hermite, no scaling (:88-94)
+            return super().variance(space, inputs, outputs, prior, noise)
+        return self.kernel_diag(space, inputs, prior, noise) * self.scaling(inputs, outputs, prior)   # :46-47
+
+    def covariance(self, space, inputs=None, outputs=None, prior=False, noise=False):
+        return self.kernel(space, inputs, prior, noise) * self.scaling(inputs, outputs, prior)       # :49-50
+
+    def quantiler(self, space, inputs=None, outputs=None, q=0.975, prior=False, noise=False):
+        p = stats.t.ppf(q, df=self.freedom(inputs, prior))              # :53
+        return self.map(self.location(space, inputs, outputs, prior, noise)
+                        + p * self.kernel_sd(space, inputs, prior, noise))
+
+    def loglike(self, inputs, outputs):
+        cho = cholesky_robust(self.prior_kernel(inputs, True))
+        return logp_cho_t(np.asarray(outputs, dtype=self.dtype), self.prior_location(inputs), cho,
+                          self.freedom(prior=True), self.map)
+
+
 # --------------------------------------------------------------------------- CPU baseline
 def cpu_hot_path(X, y, Xs, var=1.0, rate=1.0, noise=0.1):
     """One pass of the benchmark hot path on the CPU (bench.py `cpu_baseline`, kind "port"):

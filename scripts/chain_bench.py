@@ -49,10 +49,26 @@ def main():
             lp = dict(sum(r, []))
             res[S] = (t, lp)
             del bufs, devs
+        # one batched sweep (g3_gp_factor_batched)
+        dv = g3.Device(0)
+        progs = [compile_spec(('sum', ('SE', v, np.full(d, r), None), ('NOISE', nz)), d) for v, r, nz in hyp]
+        kstride = (Np + 128) * Np
+        K = dv.alloc(B * (Np + 128), Np, np.float64)
+        W = dv.alloc(B * Np, 128, np.float64)
+        a = dv.alloc(B, Np, np.float64)
+        Xd, dd = dv.upload(X), dv.upload(np.tile(y, (B, 1)))
+        dv.gp_factor_batched(progs, Xd, N, d, dd, K, kstride, W, a)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            st = dv.gp_factor_batched(progs, Xd, N, d, dd, K, kstride, W, a)
+        tb = (time.perf_counter() - t0) / reps
+        lpb = {i: -0.5 * N * np.log(2 * np.pi) - 0.5 * s_['quad'] - s_['logdet'] for i, s_ in enumerate(st)}
+        res['batched'] = (tb, lpb)
         base = res[1][1]
         for S, (t, lp) in res.items():
             assert all(abs(lp[i] - base[i]) <= 1e-9 * abs(base[i]) for i in range(B))
-        print('N=%5d  ' % N + '  '.join('S=%d: %.2f ms/eval (%.0f eval/s)' % (S, t / B * 1e3, B / t) for S, (t, _) in res.items()), flush=True)
+        print('N=%5d  ' % N + '  '.join('S=%s: %.3f ms/eval (%.0f eval/s, %.1f TF)' % (S, t / B * 1e3, B / t, B * N ** 3 / 3 / t / 1e12) for S, (t, _) in res.items()), flush=True)
 
 
 if __name__ == '__main__':

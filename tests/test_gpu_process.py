@@ -354,3 +354,43 @@ def test_logp_chain_batched_edge_members():
     assert want[2] == np.float32(-1e30) and want[3] == -np.inf     # log of a negative number; exp(x) <= 1e-6
     np.testing.assert_array_equal(got[[2, 3]], want[[2, 3]])
     np.testing.assert_allclose(got[[0, 1, 4]], want[[0, 1, 4]], rtol=1e-9)
+
+
+# ------------------------------------------------------------------ Student-t process (studentT.py)
+@pytest.mark.parametrize('warped', [False, True])
+def test_student_t_process_matches_oracle(golden_dir, warped):
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs = g['X'], g['Xs']
+    y = g['wgp_boxcox_y'] if warped else g['gp_se_bias_y']
+    r = np.array([0.9, 1.2])
+    if warped:
+        tp = g3.WTP(space=Xs, location=g3.Bias(), kernel=g3.SE(X), mapping=g3.BoxCoxLinear())
+        nat = dict(SE_var=1.0, SE_rate=r, Noise_var=0.1, Bias_Bias=0.2, Freedom_degree=3.5,
+                   BoxCoxLinear_shift=1.0, BoxCoxLinear_scale=1.0, BoxCoxLinear_power=1.2)
+        ref = orc.TP(('SE', 1.0, r, None), 3.5, 0.1, ('Bias', 0.2), ('BoxCoxLinear', 1.0, 1.0, 1.2))
+    else:
+        tp = g3.TP(space=Xs, location=g3.Bias(), kernel=g3.SE(X))
+        nat = dict(SE_var=1.1, SE_rate=r, Noise_var=0.1, Bias_Bias=0.3, Freedom_degree=3.5)
+        ref = orc.TP(('SE', 1.1, r, None), 3.5, 0.1, ('Bias', 0.3))
+    tp.observed(X, y)
+    assert tp.name == ('WTP' if warped else 'TP') and tp.name + '_Freedom_degree_log_' in [v.key for v in tp.model.vars]
+    assert np.isclose(np.exp(tp.params_default[tp.name + '_Freedom_degree_log_']), len(y))
+    p = _params(tp, **nat)
+    lp = ref.logp(X, y)
+    assert abs(tp.logp(p) - lp) <= 1e-8 * abs(lp)
+    assert tp.freedom(p) == 5.5 + len(y) and tp.freedom(p, prior=True) == 5.5
+    np.testing.assert_allclose(tp.mean(p), ref.mean(Xs, X, y), atol=1e-8)
+    np.testing.assert_allclose(tp.variance(p), ref.variance(Xs, X, y), atol=1e-8)
+    np.testing.assert_allclose(tp.variance(p, noise=True), ref.variance(Xs, X, y, noise=True), atol=1e-8)
+    np.testing.assert_allclose(tp.quantiler(p, q=0.9), ref.quantiler(Xs, X, y, 0.9), atol=1e-7)
+    if not warped:
+        np.testing.assert_allclose(tp.covariance(p), ref.covariance(Xs, X, y), atol=1e-8)
+        Z = g['Z']
+        np.testing.assert_allclose(tp.sampler(p, samples=Z.shape[1], rand=Z), ref.sampler(Xs, X, y, Z), atol=2e-6)
+    else:
+        assert not hasattr(tp, 'covariance')
+    assert tp.sampler(p, samples=3).shape == (len(Xs), 3)
+    out = tp.predict(p, var=True, quantiles=True)
+    assert np.all(out.quantile_up >= out.quantile_down) and np.all(np.isfinite(out.std))

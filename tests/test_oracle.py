@@ -304,3 +304,30 @@ def test_dlogp_sentinel_branch_is_flat():
     y[2] = np.inf
     g = orc.GP(('SE', 1.0, np.ones(1), None), 0.1, ('Bias', 0.0)).dlogp_natural(X, y)
     assert all(v == 0 for *_, v in g['kernel']) and all(v == 0 for *_, v in g['mean'])
+
+
+# ------------------------------------------------------------------ Student-t process
+def test_student_t_known_answers():
+    """n = 1: the density is scipy's univariate t with scale^2 = K (nu - 2) / nu; nu -> infinity: the
+    Gaussian logp; posterior scaling = 1 when beta = n (studentT.py:36-44,114-135)"""
+    from scipy import stats
+    X = np.array([[0.3]])
+    y = np.array([0.7])
+    tp = orc.TP(('SE', 1.3, np.ones(1), None), degree=3.0, noise_var=0.2)
+    nu, K = 5.0, 1.5
+    want = stats.t(df=nu, scale=np.sqrt(K * (nu - 2) / nu)).logpdf(0.7)
+    assert abs(tp.logp(X, y) - want) < 1e-7       # the reference's normaliser uses float32 pi (studentT.py:122)
+    rng = np.random.default_rng(1)
+    X = rng.uniform(0, 3, (30, 2))
+    y = np.sin(X.sum(1))
+    kf = ('SE', 1.0, np.ones(2), None)
+    big = orc.TP(kf, degree=1e7, noise_var=0.1)
+    # nu >= 1e6 switches to the Gaussian normaliser in float32 pi (:125): compare to 1e-6
+    assert abs(big.logp(X, y) - orc.GP(kf, 0.1).logp(X, y)) < 1e-5 * abs(orc.GP(kf, 0.1).logp(X, y))
+    tp = orc.TP(kf, degree=4.0, noise_var=0.1)
+    s = tp.scaling(X, y)
+    L = np.linalg.cholesky(orc.kernel_cov(orc.with_noise(kf, 0.1), X))
+    beta = np.sum(np.linalg.solve(L, y) ** 2)
+    assert abs(s - (6.0 + beta - 2) / (6.0 + 30 - 2)) < 1e-12
+    Xs = rng.uniform(0, 3, (5, 2))
+    np.testing.assert_allclose(tp.variance(Xs, X, y), orc.GP(kf, 0.1).variance(Xs, X, y) * s, rtol=1e-12)
