@@ -368,7 +368,29 @@ gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const
   const int tid = threadIdx.x;
   for (int s = 0; s < width; ++s) acc_s[s * GG_THREADS + tid] = 0.0;
   const SlotAcc add{acc_s, lo, width, tid};
-  const int nleaf = prog->nleaf, nprod = prog->nprod;
+  // the program is read many times per pair with data-dependent indices: keep it in LDS
+  // (scalar loads from global memory in the inner loops would stall every wave)
+  __shared__ g3_kernel_prog sp;
+  __shared__ double qconst[G3_MAXLEAF];
+  __shared__ int need_lv;
+  for (int e = tid; e < (int)(sizeof(g3_kernel_prog) / 4); e += GG_THREADS)
+    reinterpret_cast<int*>(&sp)[e] = reinterpret_cast<const int*>(prog)[e];
+  __syncthreads();
+  const int nleaf = sp.nleaf, nprod = sp.nprod;
+  if (tid == 0) {
+    // dK/d(leaf l) is the constant sum of its coefficients when every product has one factor
+    int multi = 0;
+    for (int p = 0; p < nprod; ++p) multi |= sp.prod[p].nfac > 1;
+    need_lv = multi;
+    for (int l = 0; l < G3_MAXLEAF; ++l) {
+      double q = 0.0;
+      for (int p = 0; p < nprod; ++p)
+        if (sp.prod[p].nfac == 1 && sp.prod[p].fac[0] == l) q += sp.prod[p].coef;
+      qconst[l] = q;
+    }
+  }
+  __syncthreads();
+  const bool multi = need_lv != 0;
   const int64_t nt = (N + GG_T - 1) / GG_T;
   const int64_t ntiles = nt * (nt + 1) / 2;
   for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
@@ -396,12 +418,17 @@ gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const
       const double* xi = xi_s + rr * dp;
       // G_ij with the symmetric pair (j, i) folded in
       const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj_s[c] - (double)G[i * ldg + j]);
-      for (int l = 0; l < nleaf; ++l) lv_s[l * GG_THREADS + tid] = leaf_value(prog->leaf[l], xi, xj, diag);
+      if (!multi) {
+        for (int l = 0; l < nleaf; ++l)
+          if (qconst[l] != 0.0) leaf_grad(sp.leaf[l], l, map, xi, xj, diag, g * qconst[l], add);
+        continue;
+      }
+      for (int l = 0; l < nleaf; ++l) lv_s[l * GG_THREADS + tid] = leaf_value(sp.leaf[l], xi, xj, diag);
       for (int l = 0; l < nleaf; ++l) {
         // dK/d(leaf l) = sum over the products that contain it of coef * the other factors
         double q = 0.0;
         for (int p = 0; p < nprod; ++p) {
-          const g3_prod& pr = prog->prod[p];
+          const g3_prod& pr = sp.prod[p];
           bool has = false;
           double v = pr.coef;
           for (int f = 0; f < pr.nfac; ++f) {
@@ -410,7 +437,7 @@ gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const
           }
           if (has) q += v;
         }
-        if (q != 0.0) leaf_grad(prog->leaf[l], l, map, xi, xj, diag, g * q, add);
+        if (q != 0.0) leaf_grad(sp.leaf[l], l, map, xi, xj, diag, g * q, add);
       }
     }
   }
