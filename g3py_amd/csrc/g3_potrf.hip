@@ -12,6 +12,7 @@
 // against W^T, so all O(N^3) work runs on the matrix pipe (g3_gemm.hip).  Large matrices use a
 // flat right-looking sweep over panels with one-panel look-ahead on two streams.
 #include "g3_internal.h"
+#include <vector>
 #include "g3_mfma.h"
 #include <stdlib.h>
 
@@ -325,7 +326,31 @@ int g3i_ensure_work(g3_ctx* ctx, size_t bytes) {
 template <typename T>
 static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t NB, g3_dtype dt, int64_t E) {
   const int64_t R = n + E;   // rows: the square part plus E appended right-hand-side rows
-  const int nblk = (int)((n + NB - 1) / NB);
+  // panel boundaries: NB-wide panels while the trailing matrix is large, narrower ones near the
+  // end, where the bulk stream runs out of work and the latency of the critical-path chain
+  // (diagonal-block kernels, small GEMMs) is what is left -- narrow panels shorten that chain
+  // exactly as they do for a small stand-alone problem (G3_NB_TAIL=0 keeps NB throughout)
+  std::vector<int64_t> bnd;
+  {
+    static int taper = -1;
+    if (taper < 0) {
+      const char* e = getenv("G3_NB_TAIL");
+      taper = e ? atoi(e) : 10;   // halve the width while the remaining size is <= taper * width
+    }
+    int64_t r0 = 0;
+    while (r0 < n) {
+      int64_t w = NB;
+      if (taper) {
+        const int64_t rem = n - r0;
+        while (w > 256 && rem <= (int64_t)taper * w) w /= 2;
+      }
+      w = g3_roundup(w, LB);
+      bnd.push_back(r0);
+      r0 += w;
+    }
+    bnd.push_back(n);
+  }
+  const int nblk = (int)bnd.size() - 1;
   if (ctx->la_nev < 2 * nblk) {
     if (ctx->la_ev) {
       for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
@@ -339,7 +364,7 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
   hipEvent_t* evP = ctx->la_ev;           // panel k final (stream A)
   hipEvent_t* evB = ctx->la_ev + nblk;    // block column k+2 carries the update with panel k (stream B)
   hipStream_t sA = ctx->stream, sB = ctx->side_stream;
-  auto r = [&](int k) { return (int64_t)k * NB < n ? (int64_t)k * NB : n; };
+  auto r = [&](int k) { return k < nblk ? bnd[k] : n; };
   auto nbk = [&](int k) { return r(k + 1) - r(k); };
   int rc = G3_OK;
   // B must not start before everything already queued on A (Gram, memsets) is done
