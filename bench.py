@@ -99,7 +99,7 @@ def main():
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
     ap.add_argument('--grad', action='store_true', help='also time dlogp (K^-1 + kernel-parameter sums, SURVEY.md 8f rank 1) '
                                                         'after the timed region; reported under "dlogp", never part of value')
-    ap.add_argument('--panel', dest='nb', type=int, default=512, help='block-column width of the multi-GPU distribution')
+    ap.add_argument('--panel', dest='nb', type=int, default=0, help='row-block height of the multi-GPU distribution (0 = 1024 up to 4 GPUs, 512 beyond)')
     args = ap.parse_args()
 
     import torch
@@ -177,12 +177,14 @@ def main():
         parallelism = '1gpu'
     else:
         from g3py_amd.distributed import DistributedGP
+        if args.nb <= 0:
+            args.nb = 1024 if world <= 4 else 512
         dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, torch_device=tdev, dtype=npdt)
         result = {}
 
         def step():
             result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
-        parallelism = '1d-block-cyclic x%d (nb=%d), RCCL panel broadcast' % (world, args.nb)
+        parallelism = 'row-block-cyclic x%d (nb=%d): RCCL diagonal-factor broadcast + panel all-gather, look-ahead' % (world, args.nb)
 
     for _ in range(args.warmup):
         step()

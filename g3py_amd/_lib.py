@@ -61,12 +61,14 @@ _SIGS = {
     'g3_copy2d': ([_P, _P, _I64, _P, _I64, _I64, _I64, C.c_int], C.c_int),
     'g3_gram': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
                  _I64, _I64, C.c_uint], C.c_int),
+    'g3_gram_rows': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, _I64, _I64, C.c_int, _P, _I64, C.c_uint], C.c_int),
     'g3_gram_diag': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, C.c_int, _P], C.c_int),
     'g3_cov_lift': ([_P, _P, _I64, _I64, C.c_int], C.c_int),
     'g3_scrub': ([_P, _P, _I64, _I64, _I64, C.c_int], C.c_int),
     'g3_gemm_nt': ([_P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, C.c_double, C.c_double, C.c_int,
                     C.c_int], C.c_int),
     'g3_potrf': ([_P, _P, _I64, _I64, C.c_int, _P, C.POINTER(C.c_int)], C.c_int),
+    'g3_potrf_nowait': ([_P, _P, _I64, _I64, C.c_int, _P, _P], C.c_int),
     'g3_potrf_robust': ([_P, _P, _I64, _P, _I64, _I64, C.c_int, C.c_int, C.POINTER(C.c_int),
                          C.POINTER(C.c_int), C.POINTER(C.c_double)], C.c_int),
     'g3_trsm_rlt': ([_P, _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P], C.c_int),

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
             int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
             T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym, int ntrig,
-            int64_t kstride) {
+            int64_t kstride, int64_t diag_off) {
   // grid.z = batch member: its own program (hyper-parameters) and output matrix, same inputs
   if constexpr (!SE_FAST) prog += blockIdx.z;
   K += (int64_t)blockIdx.z * kstride;
@@ -266,7 +266,7 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
     for (int q = 0; q < 2; ++q) {
       const int64_t j = ja + q;
       if (i < n1 && j < n2) {
-        const bool dg = sym && (i == j);
+        const bool dg = sym && (i + diag_off == j);   // diag_off: row offset of a row block of a square matrix
         if (SE_FAST) {
           const T* xi = xi_s + rr * dp;
           T dd = T(0);
@@ -286,7 +286,7 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
         }
         if (scr) v[q] = scrub(v[q]);
       } else {
-        v[q] = (eye && i == j) ? T(1) : T(0);
+        v[q] = (eye && i + diag_off == j) ? T(1) : T(0);
       }
     }
     T* p = K + i * ldk + ja;
@@ -352,6 +352,9 @@ static dim3 gram_grid(int64_t n1pad, int64_t n2pad, unsigned flags) {
   return dim3((unsigned)tc, (unsigned)tr);
 }
 
+// row offset of the block being built by g3_gram_rows (0 for every other entry point)
+static inline int64_t ctx_diag_off(const g3_ctx* ctx) { return ctx->gram_diag_off; }
+
 // recognise  var*SE(x[:, 0:d]) (+ Noise)  so the common case takes the register fast path
 template <typename T, int D>
 static bool match_se(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
@@ -390,7 +393,7 @@ static int launch_gram_fast(g3_ctx* ctx, const SeParams<T, D>& se, const T* X1, 
   const size_t lds = (GT + GTN) * (D | 1) * sizeof(T);
   hipLaunchKernelGGL((gram_kernel<T, D, true>), grid, dim3(256), lds, ctx->stream,
                      (const g3_kernel_prog*)nullptr, se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad,
-                     n2pad, flags, sym, 0, (int64_t)0);
+                     n2pad, flags, sym, 0, (int64_t)0, ctx_diag_off(ctx));
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -424,7 +427,7 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
   SeParams<T, 1> dummy{};
   hipLaunchKernelGGL((gram_kernel<T, 1, false>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
-                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig, (int64_t)0);
+                     ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig, (int64_t)0, ctx_diag_off(ctx));
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -443,13 +446,13 @@ int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_
     SeParams<double, 1> dummy{};
     hipLaunchKernelGGL((gram_kernel<double, 1, false>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
                        (const double*)X, n, ldx, (const double*)X, n, ldx, d, (double*)K, ldk, npad, npad, flags, 1,
-                       ntrig, kstride);
+                       ntrig, kstride, (int64_t)0);
   } else {
     const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(float);
     SeParams<float, 1> dummy{};
     hipLaunchKernelGGL((gram_kernel<float, 1, false>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
                        (const float*)X, n, ldx, (const float*)X, n, ldx, d, (float*)K, ldk, npad, npad, flags, 1,
-                       ntrig, kstride);
+                       ntrig, kstride, (int64_t)0);
   }
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -482,6 +485,40 @@ extern "C" int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X1, 
                           ldk, n1pad, n2pad, flags, sym);
   return gram_t<float>(ctx, prog, (const float*)X1, n1, ldx1, (const float*)X2, n2, ldx2, d, (float*)K, ldk,
                        n1pad, n2pad, flags, sym);
+}
+
+// Rows [row0, row0 + nrows) and columns [0, row0 + nrows) of the SQUARE covariance of X (the
+// row-block layout of the multi-GPU driver): NOISE / WN act on the true diagonal i + row0 == j,
+// rows / columns beyond N carry the identity (G3_GRAM_PAD_EYE) or zero.
+extern "C" int g3_gram_rows(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N, int64_t ldx, int d,
+                            int64_t row0, int64_t nrows, g3_dtype dt, void* K, int64_t ldk, unsigned flags) {
+  if (!ctx) return -1;
+  if (!prog) return -2;
+  if (!X) return -3;
+  if (N < 0) return -4;
+  if (d < 1 || d > G3_MAXCOLS) return -6;
+  if (ldx < d) return -5;
+  if (validate_prog(prog, d)) return -2;
+  if (row0 < 0) return -7;
+  if (nrows < 0) return -8;
+  if (!K) return -10;
+  if (ldk < row0 + nrows) return -11;
+  if (flags & G3_GRAM_LOWER) return -12;
+  if (nrows == 0) return G3_OK;
+  const size_t es = g3_esize(dt);
+  const int64_t n1 = row0 < N ? (N - row0 < nrows ? N - row0 : nrows) : 0;
+  const int64_t n2 = N < row0 + nrows ? N : row0 + nrows;
+  const void* X1 = (const char*)X + (size_t)(row0 < N ? row0 : 0) * ldx * es;
+  ctx->gram_diag_off = row0;
+  int rc;
+  if (dt == G3_F64)
+    rc = gram_t<double>(ctx, prog, (const double*)X1, n1, ldx, (const double*)X, n2, ldx, d, (double*)K, ldk, nrows,
+                        row0 + nrows, flags, 1);
+  else
+    rc = gram_t<float>(ctx, prog, (const float*)X1, n1, ldx, (const float*)X, n2, ldx, d, (float*)K, ldk, nrows,
+                       row0 + nrows, flags, 1);
+  ctx->gram_diag_off = 0;
+  return rc;
 }
 
 extern "C" int g3_gram_diag(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t n, int64_t ldx,

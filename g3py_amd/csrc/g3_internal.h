@@ -25,6 +25,7 @@ struct g3_ctx {
   int64_t bstride, bstride_w;
   const char* bw_base;
   size_t bw_bytes;
+  int64_t gram_diag_off;   // row offset of the block g3_gram_rows is building (0 otherwise)
   void* bbuf;              // device scratch of the batched entry points (programs, statistics)
   size_t bbuf_bytes;
   // small device scratch

@@ -491,6 +491,28 @@ extern "C" int g3_potrf(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtyp
   return read_info(ctx, info_host);
 }
 
+// the first non-zero info of a sequence of factorisations, kept on the device
+__global__ void info_merge_kernel(const int* info, int* accum) {
+  if (*accum == 0 && *info != 0) *accum = *info;
+}
+
+// g3_potrf without the host synchronisation: the caller supplies a 4-byte device accumulator that
+// keeps the first non-zero info of all calls made with it (read it once, at the end of a sweep).
+extern "C" int g3_potrf_nowait(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, void* invd_dev,
+                               int* info_accum_dev) {
+  if (!ctx) return -1;
+  if (!A_dev) return -2;
+  if (n < 0 || n % G3_LB) return -3;
+  if (ld < n || ld % (16 / (int64_t)g3_esize(dt))) return -4;
+  if (!invd_dev) return -6;
+  if (!info_accum_dev) return -7;
+  int rc = g3i_potrf(ctx, A_dev, n, ld, dt, invd_dev);
+  if (rc) return rc;
+  hipLaunchKernelGGL(info_merge_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_info, info_accum_dev);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
 extern "C" int g3_trsm_rlt(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, void* B_dev,
                            int64_t m, int64_t ldb, g3_dtype dt, const void* invd_dev) {
   if (!ctx) return -1;

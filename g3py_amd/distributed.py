@@ -1,29 +1,36 @@
 """Multi-GPU GP hot path: the N x N covariance block-partitioned over the GPUs of one node.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  The lower triangle
-of K is cut into NB-wide block columns, dealt round-robin to the ranks (1-D block-cyclic); a
-rank stores each of its block columns as one tall row-major panel (rows r_j.. of columns
-r_j..r_j+nb).  The reference has no distributed code at all; the
-algebra is the same Gram + Cholesky + triangular solves as the single-GPU path
-(g3py/libs/tensors.py:197-222, g3py/processes/gaussian.py:208-224, elliptical.py:81-97).
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  The reference has no
+distributed code at all; the algebra is the same Gram + Cholesky +
+triangular solves as the single-GPU path (g3py/libs/tensors.py:197-222,
+g3py/processes/gaussian.py:208-224, elliptical.py:81-97).
 
-  Gram        every rank builds exactly its own panels from the replicated N x d input: no
-              communication.
-  Cholesky    right-looking over panels with one-panel look-ahead: the owner factors the
-              diagonal block and solves the panel (g3_potrf + g3_trsm_rlt), BROADCASTS the
-              panel; the owner of the next panel updates and factors it first and its
-              broadcast is issued asynchronously while all ranks apply the current panel to
-              the rest of their block columns (MFMA SYRK/GEMM).
-  Solves      the right-hand sides B = [delta^T; K(Xs, X)] are appended as extra ROWS to every
-              panel (block column j of B lives with block column j of K), so the panel solves
-              and trailing updates of the factorisation also compute B L^-T: no separate
-              triangular-solve phase and no extra communication (the broadcast panels simply
-              carry 128 + roundup(M, 128) more rows).
-  Scalars     log det, a^T a, posterior mean / variance pieces: one all-reduce of a short vector.
+Layout: ROW-block-cyclic.  The (identity-padded) covariance is cut into nb-row blocks dealt
+round-robin to the ranks; a rank keeps its row blocks stacked in one local matrix (full width, so
+the rows below any block are one contiguous slab), followed by its share of the right-hand-side
+rows [delta^T; K(Xs, X)] (128-row chunks, also dealt round-robin), which ride through the
+factorisation exactly as on one GPU.
 
-Only broadcast and all_reduce are used, so the same driver runs on RCCL and, for tests, on gloo.
-All tile arithmetic goes through a `PanelOps` object: `HipPanelOps` (libg3hip, the product)
-or a test double supplied by tests/ (world_size-2 gloo runs on CPU).
+Why rows and not block columns: with block columns the owner of column k+1 needs ALL of panel k
+before it can factor, so the chain  receive panel -> update -> factor -> send panel  serialises a
+whole-panel transfer per step.  With row blocks only the nb x nb diagonal factor travels on the
+critical path; the panel itself is computed in parallel (every rank solves its own rows) and
+exchanged by an all-gather in which every GPU sends and receives over all of its xGMI links at
+once.  Per step k:
+
+  1. every rank: its rows below block k (and its right-hand-side rows)  <-  . L_kk^-T     (local trsm)
+  2. all-gather of those panel rows (asynchronous)
+  3. look-ahead: the owner of block k+1 already has the rows it needs -- it updates its diagonal
+     block with its own panel rows, factors it and broadcasts the nb x nb factor (+ the inverses of
+     its 128 x 128 diagonal blocks) while the all-gather is in flight
+  4. every rank: trailing update of its own row blocks with the gathered panel (MFMA GEMMs)
+
+Gram: every rank builds exactly its own rows from the replicated N x d input: no communication.
+Scalars (log det, a^T a, posterior mean / variance pieces): one broadcast of a = L^-1 delta and
+one all-reduce of a short vector.  Only broadcast, all_gather and all_reduce are used, so the
+same driver runs on RCCL and, for tests, on gloo.  All tile arithmetic goes through a
+`PanelOps` object: `HipPanelOps` (libg3hip, the product) or a test double supplied by tests/
+(world_size-2 gloo runs on CPU).
 """
 import numpy as np
 
@@ -43,6 +50,20 @@ class HipPanelOps:
         from . import _lib
         from .device import compile_spec
         self._lib, self._compile = _lib, compile_spec
+        self._dt = _lib.dtype_code(self.dtype)
+        # look-ahead: the next diagonal block is factored on a second stream through a second
+        # library context (its own info flag and scratch, so the two streams never share state)
+        # while the main stream applies the trailing update; potrf info is accumulated on the
+        # device and read once per sweep
+        self.dev_main = dev
+        self.dev_side = type(dev)(dev.index)
+        self.side = torch.cuda.Stream(device=device, priority=-1)
+        self.dev_side.set_stream(self.side.cuda_stream)
+        self.info_dev = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def _chk(self, rc, what):
+        if rc:
+            raise self._lib.G3Error('%s failed (%d): %s' % (what, rc, self.dev.lib.g3_last_error(self.dev.ctx).decode()))
 
     def _w(self, t, rows=None, cols=None):
         rows = t.shape[0] if rows is None else rows
@@ -58,75 +79,96 @@ class HipPanelOps:
     def from_host(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=self.dtype)).to(self.device)
 
-    def gram_panel(self, out, X, N, Np, r0, nb, spec):
-        """out[(Np-r0) x nb] = lower part of tt_to_num(K(X, X))[r0:, r0:r0+nb] (+ identity padding)"""
+    def gram_rows(self, out, X, N, r0, nb, spec):
+        """out[nb x >= r0+nb] <- rows [r0, r0+nb), columns [0, r0+nb) of tt_to_num(K(X, X)), identity padded"""
+        import ctypes as C
         d = X.shape[1]
-        Xv = X[r0:] if r0 < N else X[:1]
-        n_rows = max(N - r0, 0)
         prog = self._compile(spec, d)
-        flags = self._lib.G3_GRAM_LOWER | self._lib.G3_GRAM_SCRUB | self._lib.G3_GRAM_PAD_EYE
-        xw = self.dev.wrap(Xv.data_ptr(), n_rows, d, X.stride(0), self.dtype, keep=X)
-        self.dev.gram(prog, xw, None, d, self._w(out), Np - r0, nb, flags)
+        flags = self._lib.G3_GRAM_SCRUB | self._lib.G3_GRAM_PAD_EYE
+        rc = self.dev.lib.g3_gram_rows(self.dev.ctx, C.byref(prog), X.data_ptr(), N, X.stride(0), d, r0, nb, self._dt,
+                                       out.data_ptr(), out.stride(0), flags)
+        self._chk(rc, 'g3_gram_rows')
 
-    def diag_min(self, panel, n):
+    def rhs_rows(self, out, chunk, Xs, M, X, N, spec, delta):
+        """out[128 x Np]: chunk 0 = [delta; 0 ...]; chunk c >= 1 = tt_to_num(K(Xs[(c-1)*128 : c*128], X)), zero padded"""
+        out.zero_()
+        if chunk == 0:
+            out[0, :N] = delta[:N]
+            return
+        s0 = (chunk - 1) * 128
+        m = max(min(128, M - s0), 0)
+        if m > 0:
+            d = X.shape[1]
+            prog = self._compile(spec, d)
+            xs = self.dev.wrap(Xs[s0:].data_ptr(), m, d, Xs.stride(0), self.dtype, keep=Xs)
+            xw = self.dev.wrap(X.data_ptr(), N, d, X.stride(0), self.dtype, keep=X)
+            self.dev.gram(prog, xs, xw, d, self._w(out), m, N, self._lib.G3_GRAM_SCRUB)
+
+    def diag_min(self, blk, n):
         import ctypes as C
         out = (C.c_double * 3)()
-        rc = self.dev.lib.g3_diag_stats(self.dev.ctx, panel.data_ptr(), n, panel.stride(0), self._lib.dtype_code(self.dtype), out)
-        if rc:
-            raise self._lib.G3Error('g3_diag_stats failed %d' % rc)
+        self._chk(self.dev.lib.g3_diag_stats(self.dev.ctx, blk.data_ptr(), n, blk.stride(0), self._dt, out), 'g3_diag_stats')
         return out[0], out[1]
 
-    def diag_add(self, panel, n, value):
-        import ctypes as C
-        rc = self.dev.lib.g3_diag_add(self.dev.ctx, panel.data_ptr(), n, panel.stride(0), self._lib.dtype_code(self.dtype), float(value))
-        if rc:
-            raise self._lib.G3Error('g3_diag_add failed %d' % rc)
+    def diag_add(self, blk, n, value):
+        self._chk(self.dev.lib.g3_diag_add(self.dev.ctx, blk.data_ptr(), n, blk.stride(0), self._dt, float(value)), 'g3_diag_add')
 
-    def potrf_panel(self, panel, rows, nb, W):
-        """factor the top nb x nb block in place, then solve the rows below against it"""
-        import ctypes as C
-        info = C.c_int(0)
-        dt = self._lib.dtype_code(self.dtype)
-        rc = self.dev.lib.g3_potrf(self.dev.ctx, panel.data_ptr(), nb, panel.stride(0), dt, W.data_ptr(), C.byref(info))
-        if rc:
-            raise self._lib.G3Error('g3_potrf failed %d' % rc)
-        if rows > nb and info.value == 0:
-            below = panel[nb:]
-            rc = self.dev.lib.g3_trsm_rlt(self.dev.ctx, panel.data_ptr(), nb, panel.stride(0), below.data_ptr(), rows - nb,
-                                          below.stride(0), dt, W.data_ptr())
-            if rc:
-                raise self._lib.G3Error('g3_trsm_rlt failed %d' % rc)
-        return info.value
+    def potrf_block(self, L, nb, W):
+        """factor the nb x nb block in place (lower), W <- inverses of its 128 x 128 diagonal blocks;
+        no host synchronisation: the first failing pivot is kept in info_dev (see read_info)"""
+        self._chk(self.dev.lib.g3_potrf_nowait(self.dev.ctx, L.data_ptr(), nb, L.stride(0), self._dt, W.data_ptr(),
+                                               self.info_dev.data_ptr()), 'g3_potrf_nowait')
 
-    def syrk_update(self, C_, A, B, m, n, k):
-        """C[m x n] -= A[m x k] B[n x k]^T on and below C's diagonal"""
-        self.dev.gemm_nt(self._w(C_, m, n), self._w(A, m, k), self._w(B, n, k), m, n, k, alpha=-1.0, beta=1.0, lower_only=True)
+    def reset_info(self):
+        self.info_dev.zero_()
 
-    def rhs_block(self, out, Xs, M, X, N, r0, nb, spec, delta):
-        """out[E x nb], E = 128 + Mp: row 0 = delta[r0:r0+nb]; rows 128..128+M = tt_to_num(K(Xs, X[r0:r0+nb]))"""
-        d = X.shape[1]
-        out.zero_()
-        ncols = max(min(nb, N - r0), 0)
-        if ncols > 0:
-            prog = self._compile(spec, d)
-            xs = self.dev.wrap(Xs.data_ptr(), M, d, Xs.stride(0), self.dtype, keep=Xs)
-            xv = X[r0:]
-            xw = self.dev.wrap(xv.data_ptr(), ncols, d, X.stride(0), self.dtype, keep=X)
-            v = out[128:]
-            self.dev.gram(prog, xs, xw, d, self._w(v), M, ncols, self._lib.G3_GRAM_SCRUB)
-            out[0, :ncols] = delta[r0:r0 + ncols]
+    def read_info(self):
+        return int(self.info_dev.item())
 
-    def block_stats(self, rhs, Ljj, M, nb, nvalid):
-        """(sum log diag L_jj over valid rows, a_j^T a_j, dot[M], ss[M]) with a_j = row 0 of the
-        solved right-hand-side block and V_j = its rows 128..128+M"""
-        a = rhs[0:1]
-        V = rhs[128:]
-        st = self.dev.logp_terms(self._w(Ljj, nb, nb), max(nvalid, 1), self._w(a, 1, nb)) if nvalid > 0 else [0.0, 0.0, 0, 0]
-        dot, ss = self.alloc(1, M), self.alloc(1, M)
-        self.dev.rows_dot_ss(self._w(V, M, nb), M, nb, self._w(a, 1, nb), self._w(dot, 1, M), self._w(ss, 1, M))
-        # a beyond nvalid is exactly zero (zero right-hand side in the identity padding)
-        quad = float((a[0, :] * a[0, :]).sum().item())
-        return st[0], quad, dot[0].double().cpu().numpy(), ss[0].double().cpu().numpy()
+    def lookahead(self):
+        """context: work issued inside runs on the look-ahead stream, after everything queued so far"""
+        import contextlib
+        torch, ops = self.torch, self
+
+        @contextlib.contextmanager
+        def cm():
+            main = torch.cuda.current_stream(ops.device)
+            ops.side.wait_stream(main)
+            with torch.cuda.stream(ops.side):
+                ops.dev = ops.dev_side
+                try:
+                    yield
+                finally:
+                    ops.dev = ops.dev_main
+        return cm()
+
+    def join_lookahead(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def trsm(self, L, nb, W, B, m):
+        """B[m x nb] <- B L^-T"""
+        if m > 0:
+            self._chk(self.dev.lib.g3_trsm_rlt(self.dev.ctx, L.data_ptr(), nb, L.stride(0), B.data_ptr(), m, B.stride(0),
+                                               self._dt, W.data_ptr()), 'g3_trsm_rlt')
+
+    def gemm_sub(self, C_, A, B, m, n, k, lower_only=False):
+        """C[m x n] -= A[m x k] B[n x k]^T"""
+        if m > 0 and n > 0:
+            self.dev.gemm_nt(self._w(C_, m, n), self._w(A, m, k), self._w(B, n, k), m, n, k, alpha=-1.0, beta=1.0,
+                             lower_only=lower_only)
+
+    def logdet_block(self, D, nv):
+        """sum of log of the first nv diagonal entries"""
+        if nv <= 0:
+            return 0.0
+        return self.dev.logp_terms(self._w(D, nv, nv), nv, None)[0]
+
+    def rows_dot(self, V, a, n):
+        """(V a, row sums of V^2) over the first n columns, as float64 NumPy vectors"""
+        m = V.shape[0]
+        dot, ss = self.alloc(1, m), self.alloc(1, m)
+        self.dev.rows_dot_ss(self._w(V, m, n), m, n, self._w(a, 1, n), self._w(dot, 1, m), self._w(ss, 1, m))
+        return dot[0].double().cpu().numpy(), ss[0].double().cpu().numpy()
 
     def sync(self):
         self.dev.sync()
@@ -135,44 +177,80 @@ class HipPanelOps:
 class DistributedGP:
     """One evaluation of logp + posterior mean / variance over `world` ranks."""
 
-    def __init__(self, dev, dist, rank, world, N, d, M, nb=1024, torch_device=None, ops=None, dtype=np.float64):
+    def __init__(self, dev, dist, rank, world, N, d, M, nb=512, torch_device=None, ops=None, dtype=np.float64):
         import torch
         self.dist, self.rank, self.world = dist, rank, world
         self.N, self.d, self.M = N, d, M
         pad = 128
-        self.nb = max(pad, (nb // pad) * pad)
-        self.Np = (N + pad - 1) // pad * pad
+        self.nb = nb = max(pad, (nb // pad) * pad)
+        self.Np = (N + nb - 1) // nb * nb                # identity-padded to whole row blocks
+        self.nblk = self.Np // nb
         self.Mp = (M + pad - 1) // pad * pad
-        self.E = 128 + self.Mp                          # right-hand-side rows: delta block + K(Xs, .)
-        self.R = self.Np + self.E
-        self.blocks = block_ranges(self.Np, self.nb)
+        self.nchunk = 1 + self.Mp // pad                 # right-hand-side chunks: delta block + K(Xs, .) rows
         self.ops = ops if ops is not None else HipPanelOps(dev, torch, torch_device, dtype)
         self.torch = torch
         o = self.ops
-        # owned panels: rows r_j..Np of block column j, then the E right-hand-side rows
-        self.panels, self.W = {}, {}
-        for j, (r0, nbj) in enumerate(self.blocks):
-            if j % world == rank:
-                self.panels[j] = o.alloc(self.R - r0, nbj)
-                self.W[j] = o.alloc(nbj, 128)
-        self.recv = [o.alloc(self.R, self.nb), o.alloc(self.R, self.nb)]   # double-buffered panel landing zone
+        self.my_blocks = [I for I in range(self.nblk) if self.owner(I) == rank]
+        self.my_chunks = [c for c in range(self.nchunk) if c % world == rank]
+        self.rows_mat = len(self.my_blocks) * nb
+        self.rows_rhs = len(self.my_chunks) * pad
+        self.loff = {I: t * nb for t, I in enumerate(self.my_blocks)}
+        self.A = o.zeros(self.rows_mat + self.rows_rhs, self.Np)          # local rows, full width
+        # nb x nb diagonal factor followed by the inverses of its 128 x 128 diagonal blocks (double buffer)
+        self.dbuf = [o.zeros(1, nb * nb + nb * pad), o.zeros(1, nb * nb + nb * pad)]
+        self._perms = {}
+        cmax = max(self._perm(0)[0], 1) if self.nblk > 1 else 1
+        self.send = o.zeros(max(cmax, 1) * nb, nb)
+        self.gath = o.zeros(world * max(cmax, 1) * nb, nb)
         self.last = {}
-        self._alias = {}
 
-    def owner(self, j):
-        return j % self.world
+    def owner(self, I):
+        """row blocks are dealt in boustrophedon order (0..P-1, P-1..0, ...): the trailing-update work
+        of block I grows like I^2, and the snake keeps the ranks' shares within a few per cent of
+        each other where plain round-robin leaves the last rank with up to 1.4x the mean"""
+        P = self.world
+        r = I % (2 * P)
+        return r if r < P else 2 * P - 1 - r
+
+    def _perm(self, k):
+        """index tensor that puts the all-gathered panel blocks of step k into global block order:
+        entry s (global block k + 1 + s) = position of that block in the rank-major gather buffer"""
+        if k not in self._perms:
+            P = self.world
+            nbelow = self.nblk - 1 - k
+            cnt = (max(len([I for I in range(k + 1, self.nblk) if self.owner(I) == q]) for q in range(P))
+                   if nbelow > 0 else 0)
+            seen = [0] * P
+            idx = []
+            for I in range(k + 1, self.nblk):
+                q = self.owner(I)
+                idx.append(q * cnt + seen[q])
+                seen[q] += 1
+            t = self.torch.tensor(idx, dtype=self.torch.int64)
+            self._perms[k] = (cnt, t.to(self.A.device) if self.A.is_cuda else t)
+        return self._perms[k]
+
+    def _LW(self, k):
+        nb = self.nb
+        f = self.dbuf[k % 2]
+        return f[0, :nb * nb].view(nb, nb), f[0, nb * nb:].view(nb, 128)
+
+    def _diag(self, I):
+        """the nb x nb diagonal block of an owned row block (a view of the local matrix)"""
+        nb = self.nb
+        return self.A[self.loff[I]:self.loff[I] + nb, I * nb:(I + 1) * nb]
 
     # ---------------------------------------------------------------- build
     def _build(self, spec, spec_cross, X, Xs, delta, jitter):
-        o = self.ops
+        o, nb = self.ops, self.nb
         lmin = np.inf
-        for j, P in self.panels.items():
-            r0, nbj = self.blocks[j]
-            o.gram_panel(P[:self.Np - r0], X, self.N, self.Np, r0, nbj, spec)
-            o.rhs_block(P[self.Np - r0:], Xs, self.M, X, self.N, r0, nbj, spec_cross, delta)
-            nv = max(min(nbj, self.N - r0), 0)
+        for I in self.my_blocks:
+            o.gram_rows(self.A[self.loff[I]:self.loff[I] + nb], X, self.N, I * nb, nb, spec)
+            nv = max(min(nb, self.N - I * nb), 0)
             if nv > 0:
-                lmin = min(lmin, o.diag_min(P, nv)[0])
+                lmin = min(lmin, o.diag_min(self._diag(I), nv)[0])
+        for t, c in enumerate(self.my_chunks):
+            o.rhs_rows(self.A[self.rows_mat + t * 128:self.rows_mat + (t + 1) * 128], c, Xs, self.M, X, self.N, spec_cross, delta)
         # tt_to_cov (tensors.py:95-98): min over the WHOLE diagonal
         t = self.torch.tensor([lmin if np.isfinite(lmin) else 1e300], dtype=self.torch.float64)
         gmin = float(self._allreduce(t, 'min')[0])
@@ -180,68 +258,108 @@ class DistributedGP:
         if not gmin > 0:
             add += float(np.float32(1e-6)) - gmin
         if add != 0.0:
-            for j, P in self.panels.items():
-                r0, nbj = self.blocks[j]
-                nv = max(min(nbj, self.N - r0), 0)
+            for I in self.my_blocks:
+                nv = max(min(nb, self.N - I * nb), 0)
                 if nv > 0:
-                    o.diag_add(P, nv, add)
+                    o.diag_add(self._diag(I), nv, add)
 
     def _allreduce(self, t, op='sum'):
         dist = self.dist
         if self.world == 1:
             return t
         opmap = {'sum': dist.ReduceOp.SUM, 'min': dist.ReduceOp.MIN, 'max': dist.ReduceOp.MAX}
-        dev_t = t.to(self.recv[0].device) if self.recv[0].is_cuda else t
+        dev_t = t.to(self.A.device) if self.A.is_cuda else t
         dist.all_reduce(dev_t, op=opmap[op])
         return dev_t.cpu()
 
-    def _panel(self, k):
-        """the (rows x nb_k) tensor holding panel k on this rank (own storage or landing zone)"""
-        r0, nbk = self.blocks[k]
-        if self.owner(k) == self.rank:
-            return self.panels[k]
-        if k not in self._alias:   # contiguous (rows x nb_k) alias of the landing zone
-            rows = self.R - r0
-            self._alias[k] = self.recv[k % 2].view(-1)[:rows * nbk].view(rows, nbk)
-        return self._alias[k]
-
-    def _bcast(self, k, async_op):
+    def _bcast(self, t, src, async_op):
         if self.world == 1:
             return None
-        return self.dist.broadcast(self._panel(k), src=self.owner(k), async_op=async_op)
+        return self.dist.broadcast(t, src=src, async_op=async_op)
 
-    def _apply(self, k, j):
-        """block column j (and its right-hand-side rows) -= panel k contribution (lower part only)"""
-        rk, nbk = self.blocks[k]
-        rj, nbj = self.blocks[j]
-        rows = self._panel(k)[rj - rk:]
-        self.ops.syrk_update(self.panels[j], rows, rows, self.R - rj, nbj, nbk)
+    def _allgather(self, out, inp):
+        """out (world * rows x nb) <- every rank's inp (rows x nb); asynchronous"""
+        if self.world == 1:
+            out.copy_(inp)
+            return None
+        if hasattr(self.dist, 'all_gather_into_tensor'):
+            try:
+                return self.dist.all_gather_into_tensor(out, inp, async_op=True)
+            except (RuntimeError, NotImplementedError):
+                pass
+        chunks = list(out.view(self.world, inp.shape[0], inp.shape[1]).unbind(0))
+        return self.dist.all_gather(chunks, inp, async_op=True)
+
+    @staticmethod
+    def _wait(work):
+        if work is not None and hasattr(work, 'wait'):
+            work.wait()
 
     # ---------------------------------------------------------------- factorisation + solves in one sweep
+    def _factor_block(self, k):
+        """owner only: factor diagonal block k into the broadcast buffer"""
+        o = self.ops
+        L, W = self._LW(k)
+        D = self._diag(k)
+        L.copy_(D)
+        o.potrf_block(L, self.nb, W)
+        D.copy_(L)                                       # kept for the log-determinant
+
     def factor(self, spec, spec_cross, X, Xs, delta, jitter=0.0):
         """returns the global potrf info (0 = success)"""
-        o = self.ops
-        self._alias = {}
+        o, nb, P, A = self.ops, self.nb, self.world, self.A
         self._build(spec, spec_cross, X, Xs, delta, jitter)
-        nblk = len(self.blocks)
-        info = 0
+        o.reset_info()
         if self.owner(0) == self.rank:
-            info = max(info, o.potrf_panel(self.panels[0], self.R, self.blocks[0][1], self.W[0]))
-        work = self._bcast(0, async_op=False)
-        for k in range(nblk):
-            if work is not None and hasattr(work, 'wait'):
-                work.wait()
-            work = None
-            if k + 1 < nblk:
-                if self.owner(k + 1) == self.rank:      # look-ahead: next panel first
-                    self._apply(k, k + 1)
-                    r1, nb1 = self.blocks[k + 1]
-                    info = max(info, o.potrf_panel(self.panels[k + 1], self.R - r1, nb1, self.W[k + 1]))
-                work = self._bcast(k + 1, async_op=True)
-            for j in self.panels:
-                if j > k + 1:
-                    self._apply(k, j)
-        t = self._allreduce(self.torch.tensor([float(info)], dtype=self.torch.float64), 'max')
+            self._factor_block(0)
+        work_b = self._bcast(self.dbuf[0], self.owner(0), async_op=False)
+        for k in range(self.nblk):
+            self._wait(work_b)
+            if P == 1:
+                o.join_lookahead()
+            work_b = None
+            L, W = self._LW(k)
+            c0, c1 = k * nb, (k + 1) * nb
+            t0 = sum(1 for I in self.my_blocks if I <= k)            # my blocks at or above k
+            r_lo = t0 * nb
+            # 1. panel rows of everything I own below block k, right-hand-side rows included
+            o.trsm(L, nb, W, A[r_lo:, c0:c1], A.shape[0] - r_lo)
+            nbelow = self.nblk - 1 - k                                # global blocks below k
+            cnt, perm = self._perm(k)                                 # blocks per rank (padded), global order
+            work_g = None
+            if nbelow > 0:
+                mine = self.rows_mat - r_lo
+                if mine > 0:
+                    self.send[:mine].copy_(A[r_lo:self.rows_mat, c0:c1])
+                # 2. all-gather, issued BEFORE the look-ahead work so that it only waits for the solve
+                work_g = self._allgather(self.gath[:P * cnt * nb], self.send[:cnt * nb])
+            # 3. look-ahead (own stream): factor the next diagonal block from local data and send it on
+            #    its way while the main stream goes on to the trailing update
+            if k + 1 < self.nblk:
+                if self.owner(k + 1) == self.rank:
+                    with o.lookahead():
+                        lo = self.loff[k + 1]
+                        Pn = A[lo:lo + nb, c0:c1]
+                        o.gemm_sub(A[lo:lo + nb, c1:c1 + nb], Pn, Pn, nb, nb, nb, lower_only=True)
+                        self._factor_block(k + 1)
+                        work_b = self._bcast(self.dbuf[(k + 1) % 2], self.owner(k + 1), async_op=True)
+                else:
+                    work_b = self._bcast(self.dbuf[(k + 1) % 2], self.owner(k + 1), async_op=True)
+            # 4. trailing update with the gathered panel in global block order
+            if nbelow > 0:
+                self._wait(work_g)
+                G = self.gath[:P * cnt * nb].view(P * cnt, nb * nb)
+                G = G.index_select(0, perm).view(nbelow * nb, nb)   # block s <-> global block k + 1 + s
+                for I in self.my_blocks:
+                    if I >= k + 2:
+                        lo = self.loff[I]
+                        n = (I - k) * nb
+                        o.gemm_sub(A[lo:lo + nb, c1:c1 + n], A[lo:lo + nb, c0:c1], G, nb, n, nb)
+                if self.rows_rhs > 0:
+                    n = nbelow * nb
+                    o.gemm_sub(A[self.rows_mat:, c1:c1 + n], A[self.rows_mat:, c0:c1], G, self.rows_rhs, n, nb)
+        o.join_lookahead()
+        t = self._allreduce(self.torch.tensor([float(o.read_info())], dtype=self.torch.float64), 'max')
         return int(t[0])
 
     def factor_robust(self, spec, spec_cross, X, Xs, delta):
@@ -252,11 +370,10 @@ class DistributedGP:
             # jitter from the diagonal of the (lifted) covariance: rebuild and gather mean / min
             self._build(spec, spec_cross, X, Xs, delta, 0.0)
             s, cnt, mn = 0.0, 0, np.inf
-            for j, P in self.panels.items():
-                r0, nbj = self.blocks[j]
-                nv = max(min(nbj, self.N - r0), 0)
+            for I in self.my_blocks:
+                nv = max(min(self.nb, self.N - I * self.nb), 0)
                 if nv > 0:
-                    a, b = self.ops.diag_min(P, nv)
+                    a, b = self.ops.diag_min(self._diag(I), nv)
                     mn, s, cnt = min(mn, a), s + b * nv, cnt + nv
             t = self._allreduce(self.torch.tensor([s, float(cnt)], dtype=self.torch.float64), 'sum')
             mean = float(t[0]) / max(float(t[1]), 1.0)
@@ -280,16 +397,27 @@ class DistributedGP:
 
     def stats(self):
         """(logdet, quad, mean_pieces[M], ss[M]) summed over all ranks"""
-        o, M = self.ops, self.M
+        o, M, nb, Np = self.ops, self.M, self.nb, self.Np
         acc = np.zeros(2 + 2 * M)
-        for j, P in self.panels.items():
-            rj, nbj = self.blocks[j]
-            nv = max(min(nbj, self.N - rj), 0)
-            ld, q, dot, ss = o.block_stats(P[self.Np - rj:], P, M, nbj, nv)
-            acc[0] += ld
-            acc[1] += q
-            acc[2:2 + M] += dot
-            acc[2 + M:] += ss
+        for I in self.my_blocks:
+            acc[0] += o.logdet_block(self._diag(I), max(min(nb, self.N - I * nb), 0))
+        # a = L^-1 delta is row 0 of right-hand-side chunk 0 (rank 0); everyone needs it for V a
+        a = o.zeros(1, Np)
+        if 0 in self.my_chunks:
+            a.copy_(self.A[self.rows_mat:self.rows_mat + 1])
+        self._wait(self._bcast(a, self.owner(0), async_op=False))
+        if self.rank == self.owner(0):
+            acc[1] = float((a[0].double() * a[0].double()).sum().item())
+        for t, c in enumerate(self.my_chunks):
+            if c == 0:
+                continue
+            s0 = (c - 1) * 128
+            m = max(min(128, M - s0), 0)
+            if m > 0:
+                V = self.A[self.rows_mat + t * 128:self.rows_mat + t * 128 + m]
+                dot, ss = o.rows_dot(V, a, Np)
+                acc[2 + s0:2 + s0 + m] += dot
+                acc[2 + M + s0:2 + M + s0 + m] += ss
         t = self._allreduce(self.torch.from_numpy(acc), 'sum').numpy()
         return float(t[0]), float(t[1]), t[2:2 + M], t[2 + M:]
 

@@ -161,6 +161,12 @@ int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
 int g3_potrf(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, void* invd_dev,
              int* info_host);
 
+/* g3_potrf without the host synchronisation (look-ahead streams of the multi-GPU driver):
+ * info_accum_dev is a 4-byte DEVICE integer, zeroed by the caller, that keeps the first non-zero
+ * info of all calls made with it; invd_dev is required. */
+int g3_potrf_nowait(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, void* invd_dev,
+                    int* info_accum_dev);
+
 /* CholeskyRobust.perform (tensors.py:197-222): non-destructive, never fails.
  * L (lower, strict upper zeroed) <- chol(K); on info != 0 runs the reference's jitter
  * schedule (dK = mean(diag)*1e-6, lift non-positive diagonals, up to `maxtries` (20)
@@ -226,6 +232,14 @@ int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog_cross, const void* Xs_de
                 int64_t ldxs, const void* X_dev, int64_t N, int64_t ldx, int d, const void* L_dev,
                 int64_t ldl, const void* invd_dev, const void* a_dev, g3_dtype dt, void* V_dev, int64_t ldv,
                 void* mu_dev, void* ss_dev);
+
+/* Row block of the square covariance (the layout of the multi-GPU driver, g3py_amd/distributed.py):
+ * K_dev (nrows x (row0 + nrows), row stride ldk) <- rows [row0, row0 + nrows), columns
+ * [0, row0 + nrows) of Kernel.cov(X) with the SQUARE-case semantics of kernels.py:360-385 (NOISE /
+ * WN on the true diagonal only).  Rows / columns beyond N: identity with G3_GRAM_PAD_EYE, else 0.
+ * flags: G3_GRAM_SCRUB, G3_GRAM_PAD_EYE (G3_GRAM_LOWER is refused). */
+int g3_gram_rows(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X_dev, int64_t N, int64_t ldx, int d,
+                 int64_t row0, int64_t nrows, g3_dtype dt, void* K_dev, int64_t ldk, unsigned flags);
 
 /* ---- batched evaluation -----------------------------------
  * `batch` independent g3_gp_factor evaluations on the SAME inputs X with different kernel

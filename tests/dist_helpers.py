@@ -26,62 +26,81 @@ class NumpyPanelOps:
     def from_host(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
 
-    def gram_panel(self, out, X, N, Np, r0, nb, spec):
+    def gram_rows(self, out, X, N, r0, nb, spec):
         from oracle import g3_oracle as orc
-        Xn = X.numpy()
+        o = out.numpy()
+        o[:, :r0 + nb] = 0
+        rows = max(min(nb, N - r0), 0)
+        cols = min(N, r0 + nb)
+        if rows > 0:
+            K = orc.tt_to_num(orc.kernel_cov(spec, X.numpy()[:cols], None))      # square semantics (noise on the diagonal)
+            o[:rows, :cols] = K[r0:r0 + rows]
+        for i in range(rows, nb):          # identity padding
+            o[i, r0 + i] = 1.0
+
+    def rhs_rows(self, out, chunk, Xs, M, X, N, spec, delta):
+        from oracle import g3_oracle as orc
         o = out.numpy()
         o[:] = 0
-        rows = max(N - r0, 0)
-        cols = max(min(nb, N - r0), 0)
-        if cols > 0:
-            K = orc.tt_to_num(orc.kernel_cov(spec, Xn[r0:], None))[:, :cols]
-            o[:rows, :cols] = K
-        for i in range(Np - r0):       # identity padding
-            if i >= rows and i < nb:
-                o[i, i] = 1.0
+        if chunk == 0:
+            o[0, :N] = delta.numpy()[:N]
+            return
+        s0 = (chunk - 1) * 128
+        m = max(min(128, M - s0), 0)
+        if m > 0:
+            o[:m, :N] = orc.tt_to_num(orc.kernel_cov(spec, Xs.numpy()[s0:s0 + m], X.numpy()[:N]))
 
-    def diag_min(self, panel, n):
-        dg = np.diag(panel.numpy()[:n, :n])
+    def diag_min(self, blk, n):
+        dg = np.diag(blk.numpy()[:n, :n])
         return float(dg.min()), float(dg.mean())
 
-    def diag_add(self, panel, n, value):
-        p = panel.numpy()
+    def diag_add(self, blk, n, value):
+        p = blk.numpy()
         p[np.arange(n), np.arange(n)] += value
 
-    def potrf_panel(self, panel, rows, nb, W):
-        p = panel.numpy()
+    def potrf_block(self, L, nb, W):
+        p = L.numpy()
         A = np.tril(p[:nb, :nb])
         A = A + np.tril(A, -1).T
         try:
-            L = scipy.linalg.cholesky(A, lower=True)
+            F = scipy.linalg.cholesky(A, lower=True)
         except Exception:
-            return 1
-        p[:nb, :nb] = np.where(np.tril(np.ones((nb, nb), bool)), L, p[:nb, :nb])
-        if rows > nb:
-            p[nb:rows] = scipy.linalg.solve_triangular(L, p[nb:rows].T, lower=True).T
-        return 0
+            self._info = max(getattr(self, '_info', 0), 1)
+            return
+        p[:nb, :nb] = F
 
-    def syrk_update(self, C, A, B, m, n, k):
-        c = C.numpy()
-        upd = A.numpy()[:m, :k] @ B.numpy()[:n, :k].T
-        mask = np.tril(np.ones((m, n), bool))
-        c[:m, :n] -= np.where(mask, upd, 0.0)
+    def reset_info(self):
+        self._info = 0
 
-    def rhs_block(self, out, Xs, M, X, N, r0, nb, spec, delta):
-        from oracle import g3_oracle as orc
-        o = out.numpy()
-        o[:] = 0
-        cols = max(min(nb, N - r0), 0)
-        if cols > 0:
-            o[128:128 + M, :cols] = orc.tt_to_num(orc.kernel_cov(spec, Xs.numpy(), X.numpy()[r0:r0 + cols]))
-            o[0, :cols] = delta.numpy()[r0:r0 + cols]
+    def read_info(self):
+        return getattr(self, '_info', 0)
 
-    def block_stats(self, rhs, Ljj, M, nb, nvalid):
-        x = rhs.numpy()
-        a = x[0, :nb]
-        V = x[128:128 + M, :nb]
-        ld = float(np.sum(np.log(np.diag(Ljj.numpy()[:nvalid, :nvalid])))) if nvalid > 0 else 0.0
-        return ld, float(a @ a), V @ a, (V ** 2).sum(1)
+    def lookahead(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_lookahead(self):
+        pass
+
+    def trsm(self, L, nb, W, B, m):
+        if m > 0:
+            b = B.numpy()
+            b[:m, :nb] = scipy.linalg.solve_triangular(np.tril(L.numpy()[:nb, :nb]), b[:m, :nb].T, lower=True).T
+
+    def gemm_sub(self, C, A, B, m, n, k, lower_only=False):
+        if m > 0 and n > 0:
+            c = C.numpy()
+            upd = A.numpy()[:m, :k] @ B.numpy()[:n, :k].T
+            if lower_only:
+                upd = np.where(np.tril(np.ones((m, n), bool)), upd, 0.0)
+            c[:m, :n] -= upd
+
+    def logdet_block(self, D, nv):
+        return float(np.sum(np.log(np.diag(D.numpy()[:nv, :nv])))) if nv > 0 else 0.0
+
+    def rows_dot(self, V, a, n):
+        v = V.numpy()[:, :n]
+        return v @ a.numpy()[0, :n], (v ** 2).sum(1)
 
     def sync(self):
         pass
@@ -96,7 +115,7 @@ def synth(N, d, M, seed):
     return X, y, Xs
 
 
-def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_path):
+def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_path, dup=False):
     """one rank of a distributed run; rank 0 writes (logp, mean, var) to out_path"""
     import torch
     import torch.distributed as dist
@@ -108,7 +127,10 @@ def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_
         from g3py_amd.distributed import DistributedGP
         from oracle import g3_oracle as orc
         X, y, Xs = synth(N, d, M, 77)
-        spec_n = orc.with_noise(spec_f, noise)
+        if dup:                      # duplicated inputs: singular without noise -> the jitter schedule
+            X[1::2] = X[0::2][:len(X[1::2])]
+            y = np.sin(X.sum(1) / np.sqrt(d))
+        spec_n = orc.with_noise(spec_f, noise) if noise is not None else spec_f
         if use_gpu:
             import g3py_amd as g3
             tdev = torch.device('cuda', 0)
@@ -124,6 +146,7 @@ def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_
         lp = dgp.step(spec_n, spec_f, o.from_host(X), o.from_host(Xs), o.from_host(y))
         if rank == 0:
             prior = np.diag(orc.kernel_cov(spec_f, Xs))
-            np.savez(out_path, logp=lp, mean=dgp.last['mean'], var=np.maximum(prior - dgp.last['ss'], 0))
+            np.savez(out_path, logp=lp, mean=dgp.last['mean'], var=np.maximum(prior - dgp.last['ss'], 0),
+                     tries=dgp.last['tries'])
     finally:
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
-"""world_size-2 (and 3) gloo runs of the multi-rank driver on CPU: ownership, panel broadcast
-order with look-ahead, all-reduce of partial solves.  The tile arithmetic is a NumPy test double
+"""world_size-2 (and 3, 4) gloo runs of the multi-rank driver on CPU: row-block ownership, the
+diagonal-factor broadcast with look-ahead, the panel all-gather and its re-ordering into global
+block order, the right-hand-side chunks, the closing all-reduce.  The tile arithmetic is a NumPy test double
 (tests/dist_helpers.py); the expected values come from the oracle."""
 import os
 import socket
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('world,N,nb', [(2, 700, 256), (3, 520, 128), (2, 300, 512)])
+@pytest.mark.parametrize('world,N,nb', [(2, 700, 256), (3, 520, 128), (2, 300, 512), (4, 1100, 128), (1, 400, 128)])
 def test_block_cyclic_driver_matches_oracle(tmp_path, world, N, nb):
     import torch.multiprocessing as mp
     from oracle import g3_oracle as orc
@@ -35,6 +36,24 @@ def test_block_cyclic_driver_matches_oracle(tmp_path, world, N, nb):
     assert abs(float(r['logp']) - ref) <= 1e-9 * abs(ref)
     np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-9)
     np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-9)
+
+
+def test_distributed_jitter_schedule(tmp_path):
+    """a singular covariance (duplicated inputs, no noise): every rank follows the same jitter
+    schedule (tensors.py:203-213) and the result equals the oracle's robust path"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    world, N, d, M, nb = 2, 300, 2, 10, 128
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', False, spec_f, None, out, True), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    X[1::2] = X[0::2][:len(X[1::2])]
+    y = np.sin(X.sum(1) / np.sqrt(d))
+    ref = orc.GP(spec_f, None).logp(X, y)
+    assert int(r['tries']) >= 1
+    assert abs(float(r['logp']) - ref) <= 1e-5 * abs(ref)
 
 
 def test_block_ranges_and_ownership():
