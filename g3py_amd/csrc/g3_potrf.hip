@@ -112,35 +112,39 @@ __device__ __noinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t ba
   T row[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) row[c] = D[i * TS + c];
-  T rp[16];
+  // Factor and invert in ONE column sweep.  Lane i holds row i of the tile and column i of
+  // W = inv(L): w[r] = W[r][i] = (delta_ri - sum_{k<r} L[r][k] W[k][i]) / L[r][r].  Once column j
+  // of L is final, the scalars L[c][j] (c > j) that the trailing update broadcasts are exactly
+  // the ones the forward substitution for W needs, so both use the same v_readlane.
+  T w[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) w[r] = (r == i) ? T(1) : T(0);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     T p = readlane_t(row[j], j);
+    T rpj, lj;
     if (FACTOR) {
       if (!(p > T(0))) {   // also catches NaN
         if (lane == 0) atomicCAS(info, 0, (int)(base + j + 1));
         p = T(1);
       }
-      rp[j] = fast_rsqrt(p);
-      T dg = p * rp[j];
-      dg = fma(T(0.5) * rp[j], fma(-dg, dg, p), dg);
-      const T lj = (i > j) ? row[j] * rp[j] : ((i == j) ? dg : T(0));
-      row[j] = lj;
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) row[c] = fma(-lj, readlane_t(lj, c), row[c]);
+      rpj = fast_rsqrt(p);
+      T dg = p * rpj;
+      dg = fma(T(0.5) * rpj, fma(-dg, dg, p), dg);
+      lj = (i > j) ? row[j] * rpj : ((i == j) ? dg : T(0));
     } else {
-      rp[j] = fast_rcp(p);
-      if (i < j) row[j] = T(0);
+      rpj = fast_rcp(p);
+      lj = (i >= j) ? row[j] : T(0);
     }
-  }
-  // inverse: lane c holds column c of W; W[i][c] = (delta_ic - sum_{k<i} L[i][k] W[k][c]) / L[i][i]
-  T w[16];
+    row[j] = lj;
+    const T wj = w[j] * rpj;          // row j of W is final
+    w[j] = wj;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    T acc = (r == i) ? T(1) : T(0);
-#pragma unroll
-    for (int k = 0; k < r; ++k) acc = fma(-readlane_t(row[k], r), w[k], acc);
-    w[r] = acc * rp[r];
+    for (int c = j + 1; c < 16; ++c) {
+      const T s = readlane_t(lj, c);  // L[c][j]
+      if (FACTOR) row[c] = fma(-lj, s, row[c]);
+      w[c] = fma(-s, wj, w[c]);
+    }
   }
   if (lane < 16) {
 #pragma unroll
