@@ -1,0 +1,87 @@
+"""Property tests of the HIP path (symmetry, positive semi-definiteness,
+permutation invariance of logp, invariance to the panel width, ragged and tiny sizes)."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = {
+    'SE': lambda r, f: ('SE', 1.3, r, None),
+    'OU': lambda r, f: ('OU', 0.9, r, None),
+    'MAT32': lambda r, f: ('MAT32', 1.1, r, None),
+    'MAT52': lambda r, f: ('MAT52', 0.7, r, None),
+    'RQ': lambda r, f: ('RQ', 1.2, r, 1.7, None),
+    'SE+COS*SE': lambda r, f: ('sum', ('SE', 1.0, r, None), ('prod', ('COS', 0.5, f, None), ('SE', 1.0, 0.3 * r, None))),
+    'SM': lambda r, f: ('SM', 0.9, f, 0.3 * r, None),
+}
+_cfg = dict(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import g3py_amd as g3
+    return g3.Device.default()
+
+
+def _logp(dev, spec, X, y):
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d = X.shape
+    Np = _lib.roundup(N)
+    K, a, W = dev.alloc(Np + 128, Np, np.float64), dev.alloc(1, Np, np.float64), dev.alloc_inverses(Np, np.float64)
+    st_ = dev.gp_factor(compile_spec(spec, d), dev.upload(X), N, d, dev.upload(y), K, W, a)
+    return -0.5 * N * np.log(2 * np.pi) - 0.5 * st_['quad'] - st_['logdet'], st_
+
+
+@settings(**_cfg)
+@given(n=st.integers(1, 330), d=st.integers(1, 5), kname=st.sampled_from(sorted(KERNELS)), seed=st.integers(0, 10 ** 6))
+def test_gram_is_symmetric_psd_and_matches_oracle(dev, n, d, kname, seed):
+    from oracle import g3_oracle as orc
+    from g3py_amd.device import compile_spec
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 3, (n, d))
+    spec = KERNELS[kname](np.linspace(0.6, 1.4, d), np.linspace(0.11, 0.23, d))
+    out = dev.alloc(n, n, np.float64)
+    dev.gram(compile_spec(spec, d), dev.upload(X), None, d, out, n, n, 0)
+    K = dev.download(out)
+    np.testing.assert_allclose(K, orc.kernel_cov(spec, X), rtol=1e-11, atol=1e-12)
+    assert np.array_equal(K, K.T) or np.max(np.abs(K - K.T)) <= 1e-15 * np.max(np.abs(K))
+    assert np.linalg.eigvalsh((K + K.T) / 2).min() >= -1e-9 * max(1.0, np.abs(K).max())
+
+
+@settings(**_cfg)
+@given(n=st.integers(1, 400), d=st.integers(1, 4), kname=st.sampled_from(['SE', 'OU', 'MAT52', 'RQ']), seed=st.integers(0, 10 ** 6))
+def test_logp_is_permutation_invariant_and_matches_oracle(dev, n, d, kname, seed):
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 3, (n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    kf = KERNELS[kname](np.linspace(0.6, 1.4, d), None)
+    spec = orc.with_noise(kf, 0.1)
+    lp, st_ = _logp(dev, spec, X, y)
+    assert st_['info'] == 0
+    ref = orc.GP(kf, 0.1).logp(X, y)
+    assert abs(lp - ref) <= 1e-9 * max(1.0, abs(ref))
+    p = rng.permutation(n)
+    lp2, _ = _logp(dev, spec, X[p], y[p])
+    assert abs(lp2 - lp) <= 1e-10 * max(1.0, abs(lp))
+
+
+@pytest.mark.parametrize('nb', [128, 256, 384, 1024])
+def test_logp_is_invariant_to_the_panel_width(nb):
+    """the blocked sweep (look-ahead, tapered panels) must not depend on NB beyond rounding"""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); import g3py_amd as g3\n"
+            "from tests.test_gpu_properties import _logp\n"
+            "rng = np.random.default_rng(5); X = rng.uniform(0, 6, (3000, 3)); y = np.sin(X.sum(1))\n"
+            "spec = ('sum', ('SE', 1.0, np.ones(3), None), ('NOISE', 0.1))\n"
+            "print(float(_logp(g3.Device.default(), spec, X, y)[0]).hex())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, G3_NB=str(nb))
+    got = float.fromhex(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().split()[-1])
+    env = dict(os.environ, G3_NB='512', G3_NB_TAIL='0')
+    base = float.fromhex(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().split()[-1])
+    assert abs(got - base) <= 1e-11 * abs(base)
