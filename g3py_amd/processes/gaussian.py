@@ -90,24 +90,34 @@ class GaussianProcess(EllipticalProcess):
         flat = np.where(np.isnan(flat), 0.0, np.where(np.isinf(flat), float(np.float32(1e10)), flat))   # tt_to_num
         return flat.astype(self.dtype)
 
+    def _dlogp_scale(self, values, c, st, nat):
+        return 1.0
+
     def _dloglike(self, values, inputs, outputs, nat):
         """adds d loglike / d (natural-space hyper) into `nat`"""
         from ..device import spec_leaves
         dev = self.device
         c = self._factor(values, inputs, outputs)
-        self._solve(c, values, 'logp')
+        st = self._solve(c, values, 'logp')
         N, d, Np = c['N'], c['d'], c['Np']
+        # d logp / d beta = -s / 2 with beta = |L^-1 delta|^2: s = 1 for the Gaussian density; the
+        # Student-t density supplies its own s (and its degrees-of-freedom term) through the hook
+        s = float(self._dlogp_scale(values, c, st, nat))
         if c.get('grad') is None:
             prog = self._prog(self.f_kernel_noise, values, d)
             gmap = dev.grad_layout(prog)
             Y = dev.alloc(Np, Np, self.dtype)
             Kinv = dev.alloc(Np, Np, self.dtype)
             alpha = dev.alloc(1, Np, self.dtype)
-            slots = dev.gp_dlogp(prog, gmap, c['Xd'], N, d, c['Kd'], c['Wd'], c['ad'], Y, Kinv, alpha)
-            c['grad'] = dict(prog=prog, gmap=gmap, slots=slots, alpha=dev.download(alpha, 1, N)[0].astype(np.float64))
+            ad = c['ad']
+            if s != 1.0:      # G = s alpha alpha^T - K^-1: hand the device sqrt(s) a, it returns sqrt(s) alpha
+                ad = dev.upload((dev.download(c['ad']) * np.sqrt(s)).astype(self.dtype))
+            slots = dev.gp_dlogp(prog, gmap, c['Xd'], N, d, c['Kd'], c['Wd'], ad, Y, Kinv, alpha)
+            c['grad'] = dict(prog=prog, gmap=gmap, slots=slots,
+                             alpha=np.sqrt(s) * dev.download(alpha, 1, N)[0].astype(np.float64))
             del Y, Kinv                                   # 2 N^2 of HBM: released as soon as the sums exist
         g = c['grad']
-        prog, gmap, slots, alpha = g['prog'], g['gmap'], g['slots'], g['alpha']
+        prog, gmap, slots, alpha = g['prog'], g['gmap'], g['slots'], g['alpha']   # alpha = s K^-1 delta
         # kernel hypers: leaf parameter slots -> the HyperVars that fed them
         by_name = {v.name: v for v in self.model.vars}
         refs = spec_leaves(self.f_kernel_noise.spec(_Refs(), d))

@@ -363,6 +363,39 @@ class StochasticProcess:
                                                                    prior=prior, noise=True)
         return values
 
+    def sample(self, params=None, space=None, inputs=None, outputs=None, samples=1, prior=False, noise=False):
+        """models.py:443-446"""
+        S = self.predict(params=params, space=space, inputs=inputs, outputs=outputs, mean=False, std=False, var=False,
+                         cov=False, median=False, quantiles=False, quantiles_noise=False, samples=samples, prior=prior,
+                         noise=noise)
+        return S['samples']
+
+    def scores(self, params=None, space=None, hidden=None, inputs=None, outputs=None, logp=False, logpred=False,
+               bias=True, variance=False, median=False, *args, **kwargs):
+        """the scoring harness that consumes mean / variance / median / logpredictive (models.py:449-469):
+        `_l1`, `_l2`, `_mse`, `_rmse`, `_median_l1`, `_median_l2`, `_logp`, `_loglike`, `_logprior`, `_nlpd`"""
+        if hidden is None:
+            hidden = self.hidden
+        pred = self.predict(params=params, space=space, inputs=inputs, outputs=outputs, mean=True, var=variance,
+                            median=median, distribution=logpred)
+        scores = DictObj()
+        if bias:
+            scores['_l1'] = np.mean(np.abs(pred.mean - hidden))
+            scores['_l2'] = np.mean((pred.mean - hidden) ** 2)
+        if variance:
+            scores['_mse'] = np.mean((pred.mean - hidden) ** 2 + pred.variance)
+            scores['_rmse'] = np.sqrt(scores['_mse'])
+        if median:
+            scores['_median_l1'] = np.mean(np.abs(pred.median - hidden))
+            scores['_median_l2'] = np.mean((pred.median - hidden) ** 2)
+        if logp:
+            scores['_logp'] = self.logp(params)
+            scores['_loglike'] = self.loglike(params)
+            scores['_logprior'] = self.logp(params, prior=True)
+        if logpred:
+            scores['_nlpd'] = - pred.logpredictive(hidden) / len(hidden)
+        return scores
+
     def logp_chain(self, chain, prior=False):
         """stochastic.py:515-520: one logp per row of a flat-parameter chain"""
         out = np.empty(len(chain))

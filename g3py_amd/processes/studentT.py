@@ -7,11 +7,12 @@ covariances (:36-49), t quantiles (:51-55) and inverse-gamma scaled draws (:57-6
 """
 import numpy as np
 from scipy import stats
-from scipy.special import gammaln
+from scipy.special import gammaln, digamma
 
 from .. import _lib
 from .elliptical import EllipticalProcess, SENTINEL
-from .hypers import Freedom
+from .gaussian import GaussianProcess
+from .hypers import Freedom, HyperVar
 
 
 class StudentTProcess(EllipticalProcess):
@@ -41,6 +42,21 @@ class StudentTProcess(EllipticalProcess):
             else:
                 r2 = t(gammaln((nu + n) * 0.5) - gammaln(nu * 0.5)) - t(0.5) * n * np.log((nu - t(2)) * t(np.float32(np.pi)))
             return t(r1 + r2 - t(st['logdet']) + c['det_m'])                             # :127-135
+
+    # ---- gradient of logp: the Gaussian chain rule with d logp / d beta = -s/2, s = (nu + n) / (nu - 2 + beta),
+    #      plus the degrees-of-freedom term (what Theano's reverse mode gives for studentT.py:114-135)
+    th_dlogp = GaussianProcess.th_dlogp
+    _dloglike = GaussianProcess._dloglike
+
+    def _dlogp_scale(self, values, c, st, nat):
+        nu, n, beta = float(self.f_degree(values)), float(c['N']), float(st['quad'])
+        deg = self.f_degree.degree
+        if isinstance(deg, HyperVar) and deg.name in nat:
+            g = -0.5 * np.log1p(beta / (nu - 2.0)) + 0.5 * (nu + n) * beta / ((nu - 2.0) * (nu - 2.0 + beta))
+            if not float(np.float32(1e6)) <= nu:
+                g += 0.5 * digamma((nu + n) * 0.5) - 0.5 * digamma(nu * 0.5) - 0.5 * n / (nu - 2.0)
+            nat[deg.name] = nat[deg.name] + g
+        return (nu + n) / (nu - 2.0 + beta)
 
     # ---- posterior scaling (studentT.py:36-49)
     def th_scaling(self, space, inputs, outputs, vector, params, prior=False, noise=False):
@@ -91,6 +107,8 @@ class StudentTProcess(EllipticalProcess):
         dev.gemm_nt(out, Zt, Ld, Sp, Mp, Mp)                      # (L Z)^T in the MFMA GEMM
         g = loc[:, None] + dev.download(out, S, M).T
         return np.array([self.mapping(params, space, inputs, outputs=k.T) for k in g.T]).T
+
+    _methods = EllipticalProcess._methods + (('dlogp', 'th_dlogp'),)
 
 
 class WarpedStudentTProcess(StudentTProcess):

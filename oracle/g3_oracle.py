@@ -627,6 +627,10 @@ class GP:
         return self.t(lp) + self.loglike(inputs, outputs)
 
 
+    def _dlogp_scale(self, beta, n):
+        """d logp / d beta = -s/2: s = 1 for the Gaussian density (gaussian.py:219)"""
+        return 1.0
+
     def dlogp_natural(self, inputs, outputs):
         """Gradient of `logp` (observed term; the Flat priors and the log-transform Jacobian are
         constants) with respect to the NATURAL-space parameters, as the reference's
@@ -649,7 +653,10 @@ class GP:
             return zero
         a = sp.linalg.solve_triangular(cho, delta_, lower=True)
         alpha = sp.linalg.solve_triangular(cho, a, lower=True, trans='T')
-        # logp = -1/2 a^T a - sum log L_ii + ...:  Lbar = tril(alpha a^T) - diag(1/L_ii); delta_bar = -alpha
+        # logp = f(beta) - sum log L_ii + ..., beta = a^T a, f' = -s/2:
+        #   Lbar = s tril(alpha a^T) - diag(1/L_ii); delta_bar = -s alpha
+        sc = self._dlogp_scale(float(a.dot(a)), len(a))
+        alpha = sc * alpha
         Lbar = np.tril(np.outer(alpha, a)) - np.diag(1.0 / np.diag(cho))
         Kbar = cholesky_grad(cho, Lbar)
         out = dict(kernel=[(l, p, k, float(np.sum(Kbar * dK))) for l, p, k, dK in kg],
@@ -717,6 +724,22 @@ class TP(GP):
         p = stats.t.ppf(q, df=self.freedom(inputs, prior))              # :53
         return self.map(self.location(space, inputs, outputs, prior, noise)
                         + p * self.kernel_sd(space, inputs, prior, noise))
+
+    def _dlogp_scale(self, beta, n):
+        """r1 = -1/2 (nu + n) log1p(beta / (nu - 2))  (studentT.py:124)  =>  d r1 / d beta = -s/2"""
+        nu = self.freedom(prior=True)
+        return (nu + n) / (nu - 2.0 + beta)
+
+    def dlogp_degree(self, inputs, outputs):
+        """d logp / d degree (natural space): r1 and r2 of studentT.py:124-126 differentiated"""
+        from scipy.special import digamma
+        cho = cholesky_robust(self.prior_kernel(inputs, True))
+        a = sp.linalg.solve_triangular(cho, self.mapping_outputs(outputs) - self.prior_location(inputs), lower=True)
+        beta, n, nu = float(a.dot(a)), float(len(a)), self.freedom(prior=True)
+        g = -0.5 * np.log1p(beta / (nu - 2.0)) + 0.5 * (nu + n) * beta / ((nu - 2.0) * (nu - 2.0 + beta))
+        if not float(np.float32(1e6)) <= nu:
+            g += 0.5 * digamma((nu + n) * 0.5) - 0.5 * digamma(nu * 0.5) - 0.5 * n / (nu - 2.0)
+        return g
 
     def loglike(self, inputs, outputs):
         cho = cholesky_robust(self.prior_kernel(inputs, True))

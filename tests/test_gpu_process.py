@@ -394,3 +394,54 @@ def test_student_t_process_matches_oracle(golden_dir, warped):
     assert tp.sampler(p, samples=3).shape == (len(Xs), 3)
     out = tp.predict(p, var=True, quantiles=True)
     assert np.all(out.quantile_up >= out.quantile_down) and np.all(np.isfinite(out.std))
+
+
+def test_scores_harness_matches_oracle(golden_dir):
+    """StochasticProcess.scores (models.py:449-469): the caller of mean / variance / median / logpredictive"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs, y = g['X'], g['Xs'], g['gp_se_bias_y']
+    r = np.array([0.9, 1.2])
+    hidden = np.sin(Xs.sum(1) / np.sqrt(2))
+    gp = g3.GaussianProcess(space=Xs, location=g3.Bias(), kernel=g3.SE(X), hidden=hidden)
+    gp.observed(X, y)
+    p = _params(gp, SE_var=1.1, SE_rate=r, Noise_var=0.1, Bias_Bias=0.3)
+    sc = gp.scores(p, logp=True, logpred=True, variance=True, median=True)
+    ref = orc.GP(('SE', 1.1, r, None), 0.1, ('Bias', 0.3))
+    m, v = ref.mean(Xs, X, y), ref.variance(Xs, X, y)
+    assert set(sc) == {'_l1', '_l2', '_mse', '_rmse', '_median_l1', '_median_l2', '_logp', '_loglike', '_logprior', '_nlpd'}
+    np.testing.assert_allclose(sc['_l1'], np.mean(np.abs(m - hidden)), rtol=1e-8)
+    np.testing.assert_allclose(sc['_l2'], np.mean((m - hidden) ** 2), rtol=1e-8)
+    np.testing.assert_allclose(sc['_mse'], np.mean((m - hidden) ** 2 + v), rtol=1e-8)
+    np.testing.assert_allclose(sc['_rmse'], np.sqrt(np.mean((m - hidden) ** 2 + v)), rtol=1e-8)
+    np.testing.assert_allclose(sc['_logp'], ref.logp(X, y), rtol=1e-9)
+    np.testing.assert_allclose(sc['_nlpd'], -ref.logpredictive(hidden, Xs, X, y) / len(hidden), rtol=1e-7)
+    assert sc['_logprior'] == 0 and gp.sample(p, samples=2).shape == (len(Xs), 2)
+
+
+def test_student_t_dlogp_matches_oracle(golden_dir):
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs, y = g['X'], g['Xs'], g['gp_se_bias_y']
+    r = np.array([0.9, 1.2])
+    tp = g3.TP(space=Xs, location=g3.Bias(), kernel=g3.SE(X))
+    tp.observed(X, y)
+    nat = dict(SE_var=1.1, SE_rate=r, Noise_var=0.1, Bias_Bias=0.3, Freedom_degree=3.5)
+    p = _params(tp, **nat)
+    got = tp.dlogp(p)
+    ref = orc.TP(('SE', 1.1, r, None), 3.5, 0.1, ('Bias', 0.3))
+    gr = ref.dlogp_natural(X, y)
+    kern = {(l, pn, k): v for l, pn, k, v in gr['kernel']}
+    want = {'TP_Bias_Bias': [gr['mean'][0][2]], 'TP_SE_var_log_': [kern[(0, 'var', None)] * 1.1],
+            'TP_SE_rate_log_': [kern[(0, 'rate', i)] * r[i] for i in range(2)],
+            'TP_Noise_var_log_': [kern[(1, 'var', None)] * 0.1],
+            'TP_Freedom_degree_log_': [ref.dlogp_degree(X, y) * 3.5]}
+    flat = np.concatenate([want[v.key] for v in tp.model.vars])
+    np.testing.assert_allclose(got, flat, rtol=1e-8, atol=1e-8)
+    a = tp.active.dict_to_array(p)
+    v = np.random.default_rng(0).standard_normal(len(a))
+    h = 1e-5
+    fd = (float(tp.logp(a + h * v, array=True)) - float(tp.logp(a - h * v, array=True))) / (2 * h)
+    assert abs(fd - got.dot(v)) <= 1e-5 * max(1.0, abs(fd))

@@ -331,3 +331,33 @@ def test_student_t_known_answers():
     assert abs(s - (6.0 + beta - 2) / (6.0 + 30 - 2)) < 1e-12
     Xs = rng.uniform(0, 3, (5, 2))
     np.testing.assert_allclose(tp.variance(Xs, X, y), orc.GP(kf, 0.1).variance(Xs, X, y) * s, rtol=1e-12)
+
+
+def test_student_t_dlogp_matches_finite_differences():
+    rng = np.random.default_rng(2)
+    N, d = 35, 2
+    X = rng.uniform(0, 3, (N, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N) + 2.0
+    r = np.array([0.8, 1.2])
+    mk = lambda var, rate, noise, bias, deg, shift: orc.TP(('SE', var, rate, None), deg, noise, ('Bias', bias), ('ArcsinhLinear', shift, 1.3))
+    base = dict(var=1.1, rate=r, noise=0.1, bias=0.3, deg=3.0, shift=0.2)
+    tp = mk(**base)
+    g = tp.dlogp_natural(X, y)
+    h = 1e-5
+
+    def fd(key, k=None):
+        def lp(dl):
+            q = dict(base)
+            if k is None:
+                q[key] = q[key] + dl
+            else:
+                v = np.array(q[key], dtype=float)
+                v[k] += dl
+                q[key] = v
+            return mk(**q).loglike(X, y)
+        return (lp(h) - lp(-h)) / (2 * h)
+    kern = {(l, p, k): v for l, p, k, v in g['kernel']}
+    for val, f in [(kern[(0, 'var', None)], fd('var')), (kern[(0, 'rate', 0)], fd('rate', 0)), (kern[(0, 'rate', 1)], fd('rate', 1)),
+                   (kern[(1, 'var', None)], fd('noise')), (g['mean'][0][2], fd('bias')), (g['mapping'][0][1], fd('shift')),
+                   (tp.dlogp_degree(X, y), fd('deg'))]:
+        assert abs(val - f) <= 2e-6 * max(1.0, abs(val)), (val, f)
