@@ -51,6 +51,9 @@ __device__ __forceinline__ float fast_rcp(float p) {
 //                 A(i,j) -= L(i,k) L(j,k)^T for k < j <= i and W(i,j) -= L(i,k) W(k,j) for j <= k
 // Three barriers per block step (24 per block) instead of one per column (128), and all O(n^3)
 // work on the matrix pipe.  FACTOR = false: A already holds L, only W is formed.
+#ifndef G3_DIAG16_MFMA
+#define G3_DIAG16_MFMA 1   // fp64: 4 x 4-blocked diagonal tiles on the matrix pipe (0: column sweep)
+#endif
 constexpr int TS = 17;   // LDS tile row stride in elements (16 + 1: conflict-free fragment reads)
 template <typename T>
 struct DiagLds {
@@ -154,6 +157,122 @@ __device__ __noinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t ba
   }
 }
 
+// fp64 variant of diag16 that keeps the O(16^3) part on the matrix pipe.  The 16 x 16 tile is
+// processed in four 4-column block steps; per step every lane redundantly factors and inverts the
+// 4 x 4 diagonal block from LDS broadcast reads (the only sequential arithmetic: 4 pivots instead
+// of 16), forms ITS element of the 16 x 4 panel directly in MFMA operand layout (lane = (row, k)),
+// and one v_mfma_f64_16x16x4 applies the rank-4 trailing update to the whole tile.  The inverse is
+// carried along the same way (W rows of the block by one MFMA, rows below by another); for f64
+// accumulator register q holds exactly tile rows 4q..4q+3, so those MFMAs take their B operand
+// straight from the accumulator with no cross-lane traffic.
+template <bool FACTOR>
+__device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info, int64_t base) {
+  using M = MfmaT<double>;
+  using acc_t = typename M::acc_t;
+  const int row = lane & 15, kq = lane >> 4;      // this lane's (row, k) in MFMA A-operand layout
+  acc_t tA = TileOps<double>::load(D, lane);      // the tile, C layout
+  acc_t aW;
+  double pvq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) aW[r] = (M::row(lane, r) == (lane & 15)) ? 1.0 : 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = 4 * q;
+    // 1. the 4 x 4 diagonal block: Cholesky factor l and inverse w4 (every lane, uniform data)
+    double d[4][4], l[4][4], w4[4][4], rp[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        d[a][b] = (b <= a) ? D[(c0 + a) * TS + c0 + b] : 0.0;
+        l[a][b] = 0.0;
+        w4[a][b] = 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double p = d[j][j];
+      if (FACTOR) {
+        if (!(p > 0.0)) {   // also catches NaN
+          if (lane == 0) atomicCAS(info, 0, (int)(base + c0 + j + 1));
+          p = 1.0;
+        }
+        rp[j] = fast_rsqrt(p);
+        double dg = p * rp[j];
+        dg = fma(0.5 * rp[j], fma(-dg, dg, p), dg);
+        l[j][j] = dg;
+#pragma unroll
+        for (int a = j + 1; a < 4; ++a) l[a][j] = d[a][j] * rp[j];
+#pragma unroll
+        for (int a = j + 1; a < 4; ++a)
+#pragma unroll
+          for (int b = j + 1; b <= a; ++b) d[a][b] = fma(-l[a][j], l[b][j], d[a][b]);
+      } else {
+        rp[j] = fast_rcp(p);
+#pragma unroll
+        for (int a = j; a < 4; ++a) l[a][j] = d[a][j];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      w4[b][b] = rp[b];
+#pragma unroll
+      for (int a = b + 1; a < 4; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int m = b; m < a; ++m) acc = fma(l[a][m], w4[m][b], acc);
+        w4[a][b] = -acc * rp[a];
+      }
+    }
+    // 2. this lane's panel element P[row][kq] = sum_{m <= kq} T[row][c0 + m] * w4[kq][m]
+    double pv;
+    const int ra = row - c0;                      // row inside the diagonal block when 0 <= ra < 4
+    if (FACTOR) {
+      double t[4], cf[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        t[m] = D[row * TS + c0 + m];
+        cf[m] = 0.0;
+#pragma unroll
+        for (int k = m; k < 4; ++k) cf[m] = (kq == k) ? w4[k][m] : cf[m];
+      }
+      pv = t[0] * cf[0];
+#pragma unroll
+      for (int m = 1; m < 4; ++m) pv = fma(t[m], cf[m], pv);
+      if (ra < 4) {                               // the diagonal block itself (exact factor), zero above it
+        double lv = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) lv = (ra == a && kq == b) ? l[a][b] : lv;
+        pv = lv;
+      }
+    } else {
+      pv = (ra >= 4 || (ra >= 0 && kq <= ra)) ? D[row * TS + c0 + kq] : 0.0;
+    }
+    // 3. rank-4 trailing update of the whole tile, back to LDS for the next block step
+    if (FACTOR) {
+      tA = M::mfma(-pv, pv, tA);
+      TileOps<double>::store(D, tA, lane);
+    }
+    // 4. the finished columns c0..c0+3 of L: kept until the sweep is over (the tile stores of the
+    //    later block steps overwrite the whole tile)
+    pvq[q] = pv;
+    // 5. inverse: rows of this block, then the rows below
+    double ah = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) ah = (ra == a && kq == b) ? w4[a][b] : ah;
+    const acc_t R = M::mfma(ah, aW[q], acc_t{0, 0, 0, 0});
+    const double pb = (ra >= 4) ? pv : 0.0;
+    aW = M::mfma(-pb, R[q], aW);
+    aW[q] = R[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) D[row * TS + 4 * q + kq] = pvq[q];
+  TileOps<double>::store(Wd, aW, lane);
+}
+
 template <typename T, bool FACTOR>
 __global__ void __launch_bounds__(512)
 diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, int* info,
@@ -191,7 +310,10 @@ diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w
     const int par = k & 1;
     if (w == k) {
       TO::store(S.D[par], aA[k], lane);
-      diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
+      if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
+        diag16m<FACTOR>((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
+      else
+        diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
       if (FACTOR) aA[k] = TO::load(S.D[par], lane);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
