@@ -222,6 +222,9 @@ def main():
         }
         ph = {k: v['ms'] / args.steps for k, v in prof.items() if v['count']}
         out['phases_ms'] = ph
+        if prof['gram']['count'] and prof['gram']['ms'] > 0:
+            # algorithmic bytes of the lower-triangle Gram (N d s read + N(N+1)/2 s written) per second
+            out['gram_gbps'] = prof['gram']['work'] / (prof['gram']['ms'] * 1e-3) / 1e9
         if prof['potrf']['count']:
             # the factorisation phase also carries the 1 + M right-hand-side rows; cholesky_tflops counts
             # only N^3/3 over that phase (conservative), factor_solve_tflops counts the solves too
