@@ -273,87 +273,119 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
   TileOps<double>::store(Wd, aW, lane);
 }
 
+// The program of wave W (block row W) of the diagonal-block kernel, with W a compile-time constant:
+// every "does this wave take part" test folds away, so the register allocator sees the true
+// lifetime of each accumulator tile instead of the union over all waves.
+//
+// Register budget: the kernel sits on the critical path while the bulk GEMM keeps every CU busy
+// with two 4-wave workgroups of ~224 VGPRs.  It must fit next to ONE of them (the half CU that a
+// retiring GEMM workgroup leaves behind): 8 waves x <= 144 VGPRs and <= 96 KiB of LDS.  Otherwise
+// it waits for a whole CU to drain -- measured 494 us per launch instead of 43.  So accumulator
+// tiles exist only while they are live: A(W, j) is written out the moment it is final (step j),
+// W(W, j) comes into existence at step j, and nothing is live across the call that factors the
+// diagonal tile (wave W publishes its old W row before it, and rebuilds the row from LDS after).
+template <typename T, bool FACTOR, int W>
+__device__ __forceinline__ void diag128_wave(T* A, int64_t ld, T* Wg, int64_t ldw, int* info, int64_t row_base,
+                                             DiagLds<T>& S, int lane) {
+  using TO = TileOps<T>;
+  using acc_t = typename TO::acc_t;
+  using M = MfmaT<T>;
+  acc_t aA[8], aW[8];
+#pragma unroll
+  for (int j = 0; j <= W; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * W + M::row(lane, r), col = 16 * j + (lane & 15);
+      aA[j][r] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
+    }
+  }
+  // Per block step: [wave k: 16 x 16 factor + inverse] B1 [waves i > k: panel tile and
+  // T_i = L(i,k) W_dd] B2 [trailing updates; wave k rebuilds its own W row meanwhile].  Buffers
+  // written by wave k+1 for the NEXT step have the other parity, so no third barrier is needed and
+  // wave k+1 (the lightest in the trailing phase) starts its diagonal tile while the others update.
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int par = k & 1;
+    if (W == k) {
+#pragma unroll
+      for (int j = 0; j < k; ++j) TO::store(S.Wr[par][j], aW[j], lane);   // old W(k, j): consumers multiply by T_i
+      TO::store(S.D[par], aA[k], lane);
+      if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
+        diag16m<FACTOR>((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
+      else
+        diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
+      if (FACTOR) {                         // the diagonal tile of L is final: write it out
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = M::row(lane, r), col = lane & 15;
+          if (row >= col) A[(int64_t)(16 * k + row) * ld + 16 * k + col] = S.D[par][row * TS + col];
+        }
+      }
+    }
+    __syncthreads();                       // W_dd and the old row k of W are published
+    if (W > k) {
+      TO::store(S.P[W], aA[k], lane);
+      if (FACTOR) {
+        const acc_t lk = TO::mul_nt(S.P[W], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);   // L(W,k) = A(W,k) W_dd^T
+        TO::store(S.P[W], lk, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)         // final: write it out, its registers are free from here on
+          A[(int64_t)(16 * W + M::row(lane, r)) * ld + 16 * k + (lane & 15)] = lk[r];
+      }
+      // T_W = L(W,k) W_dd: W(W,j) -= T_W W_old(k,j) for j < k, and W(W,k) = -T_W (W_old(k,k) = I)
+      const acc_t t = TO::mul_nn(S.P[W], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);
+      aW[k] = -t;
+      TO::store(S.Tt[W], t, lane);
+    }
+    __syncthreads();                       // the panel L(:, k) is published
+    if (W > k) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (FACTOR && j > k && j <= W) aA[j] = TO::mul_nt(S.P[W], S.P[j], aA[j], T(-1), lane);
+        if (j < k) aW[j] = TO::mul_nn(S.Tt[W], S.Wr[par][j], aW[j], T(-1), lane);
+      }
+    } else if (W == k) {          // off the critical path: W(k, :) <- W_dd W_old(k, :)
+#pragma unroll
+      for (int j = 0; j < k; ++j) aW[j] = TO::mul_nn(S.Wd[par], S.Wr[par][j], acc_t{0, 0, 0, 0}, T(1), lane);
+      aW[k] = TO::load(S.Wd[par], lane);
+    }
+  }
+  // write back W (full 128 x 128 block row, upper part zero); L went out tile by tile
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * W + M::row(lane, r), col = 16 * j + (lane & 15);
+      T v = T(0);
+      if (j <= W) v = (row >= col) ? aW[j <= W ? j : 0][r] : T(0);
+      Wg[(int64_t)row * ldw + col] = v;
+    }
+  }
+}
+
 template <typename T, bool FACTOR>
 __global__ void __launch_bounds__(512)
 diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, int* info,
                 int64_t row_base, int64_t a_batch, int64_t w_batch) {
-  using TO = TileOps<T>;
-  using acc_t = typename TO::acc_t;
-  using M = MfmaT<T>;
   info += blockIdx.y;                       // batch member (grid.y)
   if (FACTOR && *info != 0) return;
   A += (int64_t)blockIdx.x * a_stride + (int64_t)blockIdx.y * a_batch;
   W += (int64_t)blockIdx.x * w_stride + (int64_t)blockIdx.y * w_batch;
   row_base += (int64_t)blockIdx.x * G3_LB;
   __shared__ DiagLds<T> S;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   // wave w owns block row w
-  acc_t aA[8], aW[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    aW[j] = acc_t{0, 0, 0, 0};
-    aA[j] = acc_t{0, 0, 0, 0};
-    if (j <= w) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * w + M::row(lane, r), col = 16 * j + (lane & 15);
-        aA[j][r] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
-        aW[j][r] = (row == col) ? T(1) : T(0);
-      }
-    }
-  }
-  // Per block step: [wave k: 16 x 16 factor + inverse] B1 [waves i > k: panel tile and
-  // T_i = L(i,k) W_dd] B2 [trailing updates; wave k scales its own W row meanwhile].  Buffers
-  // written by wave k+1 for the NEXT step have the other parity, so no third barrier is needed and
-  // wave k+1 (the lightest in the trailing phase) starts its diagonal tile while the others update.
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int par = k & 1;
-    if (w == k) {
-      TO::store(S.D[par], aA[k], lane);
-      if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
-        diag16m<FACTOR>((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
-      else
-        diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
-      if (FACTOR) aA[k] = TO::load(S.D[par], lane);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < k) TO::store(S.Wr[par][j], aW[j], lane);     // old W(k, j): consumers multiply by T_i
-    }
-    __syncthreads();                       // W_dd and the old row k of W are published
-    if (w > k) {
-      TO::store(S.P[w], aA[k], lane);
-      if (FACTOR) {
-        aA[k] = TO::mul_nt(S.P[w], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);   // L(w,k) = A(w,k) W_dd^T
-        TO::store(S.P[w], aA[k], lane);
-      }
-      // T_w = L(w,k) W_dd: W(w,j) -= T_w W_old(k,j) for j < k, and W(w,k) -= T_w (W_old(k,k) = I)
-      const acc_t t = TO::mul_nn(S.P[w], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);
-      aW[k] -= t;
-      TO::store(S.Tt[w], t, lane);
-    }
-    __syncthreads();                       // the panel L(:, k) is published
-    if (w > k) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (FACTOR && j > k && j <= w) aA[j] = TO::mul_nt(S.P[w], S.P[j], aA[j], T(-1), lane);
-        if (j < k) aW[j] = TO::mul_nn(S.Tt[w], S.Wr[par][j], aW[j], T(-1), lane);
-      }
-    } else if (w == k) {                   // off the critical path: W(k, :) <- W_dd W(k, :)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < k) aW[j] = TO::mul_nn(S.Wd[par], S.Wr[par][j], acc_t{0, 0, 0, 0}, T(1), lane);
-      aW[k] = TO::load(S.Wd[par], lane);
-    }
-  }
-  // write back: L (lower part only, strict upper never written) and W (full 128 x 128, upper zero)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * w + M::row(lane, r), col = 16 * j + (lane & 15);
-      if (FACTOR && j <= w && row >= col) A[(int64_t)row * ld + col] = aA[j][r];
-      W[(int64_t)row * ldw + col] = (j <= w && row >= col) ? aW[j][r] : T(0);
-    }
+  const int lane = threadIdx.x & 63;
+  // wave index as a scalar: the eight wave programs below are selected by a uniform branch, so a
+  // wave only ever executes (and counts the barriers of) its own program
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  switch (w) {
+    case 0: diag128_wave<T, FACTOR, 0>(A, ld, W, ldw, info, row_base, S, lane); break;
+    case 1: diag128_wave<T, FACTOR, 1>(A, ld, W, ldw, info, row_base, S, lane); break;
+    case 2: diag128_wave<T, FACTOR, 2>(A, ld, W, ldw, info, row_base, S, lane); break;
+    case 3: diag128_wave<T, FACTOR, 3>(A, ld, W, ldw, info, row_base, S, lane); break;
+    case 4: diag128_wave<T, FACTOR, 4>(A, ld, W, ldw, info, row_base, S, lane); break;
+    case 5: diag128_wave<T, FACTOR, 5>(A, ld, W, ldw, info, row_base, S, lane); break;
+    case 6: diag128_wave<T, FACTOR, 6>(A, ld, W, ldw, info, row_base, S, lane); break;
+    default: diag128_wave<T, FACTOR, 7>(A, ld, W, ldw, info, row_base, S, lane); break;
   }
 }
 
