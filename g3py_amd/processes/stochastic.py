@@ -21,6 +21,7 @@ class GraphicalModel:
         self.model = Model(name)
         self.components = DictObj()
         self.current_params = None
+        self.fix_vars()
 
     def add_component(self, component):
         self.components[component.name] = component
@@ -53,6 +54,41 @@ class GraphicalModel:
     @property
     def bijection(self):
         return GraphicalModel._Bijection(self)
+
+    # ---- fixed chains (models.py:270-296): some variables are pinned to the rows of a chain / datatrace,
+    #      the others are the ones an optimiser or sampler moves
+    def fix_vars(self, datatrace=None, keys=None):
+        """`datatrace`: 2-D array or DataFrame whose first `ndim` columns are flat parameter vectors;
+        `keys`: the names (transformed keys or natural names) of the variables that stay fixed"""
+        if datatrace is None or keys is None:
+            self.fixed_keys, self.fixed_datatrace, self.fixed_chain, self.fixed_dims = [], None, None, []
+            return
+        self.fixed_keys = list(keys)
+        self.fixed_datatrace = datatrace.copy()
+        values = getattr(self.fixed_datatrace, 'values', self.fixed_datatrace)
+        self.fixed_chain = np.array(np.asarray(values)[:, :self.ndim], dtype=np.float64)
+        dims, o = [], 0
+        for v in self.model.vars:
+            if v.key in self.fixed_keys or v.name in self.fixed_keys:
+                dims += list(range(o, o + v.size))
+            o += v.size
+        self.fixed_dims = sorted(dims)
+
+    @property
+    def sampling_dims(self):
+        return sorted(set(range(self.ndim)) - set(self.fixed_dims))
+
+    def sampling_params(self, params):
+        if isinstance(params, dict):
+            return self.dict_to_array(params)[self.sampling_dims]
+        return np.asarray(params)[self.sampling_dims]
+
+    def dict_from_sampling_array(self, params):
+        if self.fixed_datatrace is None:
+            return self.array_to_dict(params)
+        r = self.dict_to_array(self.params)
+        r[self.sampling_dims] = params
+        return self.array_to_dict(r)
 
     # ---- parameters
     def set_params(self, params=None):
@@ -402,3 +438,29 @@ class StochasticProcess:
         for i in range(len(out)):
             out[i] = self.logp(chain[i], array=True, prior=prior)
         return out
+
+    # ---- averages over a fixed chain (stochastic.py:522-564): the rows of active.fixed_chain with
+    #      the sampling dimensions overwritten by `sampling_params`
+    def _fixed_rows(self, sampling_params):
+        if self.active.fixed_chain is None:
+            raise ValueError('no fixed chain: call active.fix_vars(datatrace, keys) first')
+        self.active.fixed_chain[:, self.active.sampling_dims] = sampling_params
+        return self.active.fixed_chain
+
+    def fixed_logp(self, sampling_params, return_array=False):
+        r = self.logp_chain(self._fixed_rows(sampling_params))          # one batched sweep where available
+        return r if return_array else np.mean(r)
+
+    def fixed_logprior(self, sampling_params, return_array=False):
+        r = self.logp_chain(self._fixed_rows(sampling_params), prior=True)
+        return r if return_array else np.mean(r)
+
+    def fixed_loglike(self, sampling_params, return_array=False):
+        rows = self._fixed_rows(sampling_params)
+        r = self.logp_chain(rows) - self.logp_chain(rows, prior=True)
+        return r if return_array else np.mean(r)
+
+    def fixed_dlogp(self, sampling_params, return_array=False):
+        rows = self._fixed_rows(sampling_params)
+        r = np.array([self.dlogp(p, array=True)[self.active.sampling_dims] for p in rows])
+        return r if return_array else np.mean(r, axis=0)

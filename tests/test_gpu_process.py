@@ -445,3 +445,33 @@ def test_student_t_dlogp_matches_oracle(golden_dir):
     h = 1e-5
     fd = (float(tp.logp(a + h * v, array=True)) - float(tp.logp(a - h * v, array=True))) / (2 * h)
     assert abs(fd - got.dot(v)) <= 1e-5 * max(1.0, abs(fd))
+
+
+def test_fixed_chain_averages(golden_dir):
+    """fixed_logp / fixed_loglike / fixed_logprior / fixed_dlogp (stochastic.py:522-564) over a chain whose
+    noise column is pinned: the batched sweep equals the row-by-row evaluation"""
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'oracle_process.npz'))
+    X, Xs, y = g['X'], g['Xs'], g['gp_se_bias_y']
+    gp = g3.GaussianProcess(space=Xs, location=g3.Bias(), kernel=g3.SE(X))
+    gp.observed(X, y)
+    a0 = gp.active.dict_to_array(_params(gp, SE_var=1.1, SE_rate=[0.9, 1.2], Noise_var=0.1, Bias_Bias=0.3))
+    rng = np.random.default_rng(6)
+    chain = a0 + 0.1 * rng.standard_normal((9, len(a0)))
+    gp.active.fix_vars(chain, ['GP_Noise_var_log_'])
+    assert gp.active.fixed_dims == [4] and gp.active.sampling_dims == [0, 1, 2, 3]
+    sp = gp.active.sampling_params(a0) + 0.05
+    rows = chain.copy()
+    rows[:, :4] = sp
+    want = np.array([gp.logp(r, array=True) for r in rows])
+    np.testing.assert_allclose(gp.fixed_logp(sp, return_array=True), want, rtol=1e-10)
+    assert abs(gp.fixed_logp(sp) - want.mean()) <= 1e-10 * abs(want.mean())
+    np.testing.assert_allclose(gp.fixed_loglike(sp, return_array=True), want, rtol=1e-10)      # flat priors
+    assert gp.fixed_logprior(sp) == 0
+    gd = gp.fixed_dlogp(sp)
+    assert gd.shape == (4,)
+    np.testing.assert_allclose(gd, np.mean([gp.dlogp(r, array=True)[:4] for r in rows], axis=0), rtol=1e-10)
+    d = gp.active.dict_from_sampling_array(sp)
+    np.testing.assert_allclose(gp.active.dict_to_array(d)[:4], sp)
+    gp.active.fix_vars()
+    assert gp.active.fixed_chain is None and gp.active.sampling_dims == list(range(5))
