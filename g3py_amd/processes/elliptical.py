@@ -309,9 +309,23 @@ class EllipticalProcess(StochasticProcess):
     def th_covariance(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         return self.th_kernel(space, inputs, outputs, vector, params, prior=prior, noise=noise)
 
+    # ---- errors of the predictive mean against a supplied vector (stochastic.py:315-326)
+    def th_error_l1(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        mean = self.th_mean(space, inputs, outputs, vector, params, prior=prior, noise=noise)
+        return np.mean(np.abs(np.asarray(vector, dtype=self.dtype) - mean))
+
+    def th_error_l2(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        mean = self.th_mean(space, inputs, outputs, vector, params, prior=prior, noise=noise)
+        return np.mean((np.asarray(vector, dtype=self.dtype) - mean) ** 2)
+
+    def th_error_mse(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        d = np.abs(np.asarray(vector, dtype=self.dtype) - np.asarray(outputs, dtype=self.dtype))
+        return np.mean(d) ** 2 + np.var(d)
+
     _methods = (('mean', 'th_mean'), ('median', 'th_median'), ('variance', 'th_variance'), ('std', 'th_std'),
                 ('covariance', 'th_covariance'), ('logpredictive', 'th_logpredictive'), ('logp', 'th_logp'),
                 ('loglike', 'th_loglike'), ('mapping', 'th_mapping'), ('mapping_inv', 'th_mapping_inv'),
                 ('location', 'th_location'), ('kernel', 'th_kernel'), ('cholesky', 'th_cholesky'),
                 ('kernel_diag', 'th_kernel_diag'), ('kernel_sd', 'th_kernel_sd'),
-                ('cholesky_diag', 'th_cholesky_diag'), ('cross_mean', 'th_cross_mean'), ('freedom', 'th_freedom'))
+                ('cholesky_diag', 'th_cholesky_diag'), ('cross_mean', 'th_cross_mean'), ('freedom', 'th_freedom'),
+                ('error_l1', 'th_error_l1'), ('error_l2', 'th_error_l2'), ('error_mse', 'th_error_mse'))

@@ -418,6 +418,11 @@ def test_scores_harness_matches_oracle(golden_dir):
     np.testing.assert_allclose(sc['_logp'], ref.logp(X, y), rtol=1e-9)
     np.testing.assert_allclose(sc['_nlpd'], -ref.logpredictive(hidden, Xs, X, y) / len(hidden), rtol=1e-7)
     assert sc['_logprior'] == 0 and gp.sample(p, samples=2).shape == (len(Xs), 2)
+    # error statistics against a supplied vector (stochastic.py:315-326)
+    np.testing.assert_allclose(gp.error_l1(p, vector=hidden), sc['_l1'], rtol=1e-12)
+    np.testing.assert_allclose(gp.error_l2(p, vector=hidden), sc['_l2'], rtol=1e-12)
+    dv = np.abs(y[:len(y)] - y[::-1])
+    np.testing.assert_allclose(gp.error_mse(p, vector=y[::-1]), np.mean(dv) ** 2 + np.var(dv), rtol=1e-12)
 
 
 def test_student_t_dlogp_matches_oracle(golden_dir):
