@@ -21,11 +21,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('world,N,nb', [(2, 700, 256), (3, 520, 128), (2, 300, 512), (4, 1100, 128), (1, 400, 128)])
-def test_block_cyclic_driver_matches_oracle(tmp_path, world, N, nb):
+@pytest.mark.parametrize('world,N,nb,M', [(2, 700, 256, 20), (3, 520, 128, 300), (2, 300, 512, 20), (4, 1100, 128, 130),
+                                          (1, 400, 128, 20), (8, 2100, 128, 20)])
+def test_block_cyclic_driver_matches_oracle(tmp_path, world, N, nb, M):
     import torch.multiprocessing as mp
     from oracle import g3_oracle as orc
-    d, M = 3, 20
+    d = 3
     spec_f = ('SE', 1.0, np.ones(d), None)
     out = str(tmp_path / 'res.npz')
     mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', False, spec_f, 0.1, out), nprocs=world, join=True)
