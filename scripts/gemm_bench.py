@@ -23,13 +23,13 @@ for (m, n, k, lower) in shapes:
     Ad = dev.wrap(A.data_ptr(), max(m, n), k, k, DT)
     Cd = dev.wrap(C.data_ptr(), m, n, n, DT)
     for _ in range(2):
-        dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=1.0, lower_only=bool(lower))
+        dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=float(os.environ.get('G3_BETA', '1.0')), lower_only=bool(lower))
     torch.cuda.synchronize()
     reps = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=1.0, lower_only=bool(lower))
+        dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=float(os.environ.get('G3_BETA', '1.0')), lower_only=bool(lower))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
