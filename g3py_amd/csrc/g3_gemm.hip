@@ -175,7 +175,71 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     __syncthreads();
   }
 
-  // epilogue: 16 consecutive columns per 16 lanes (128 B f64 / 64 B f32 segments per row)
+  // ---- epilogue.  The accumulators are in MFMA layout (a lane holds 4 rows x 1 column of each
+  // 16 x 16 tile): written straight to C that is 128-byte pieces scattered over 64 rows per
+  // instruction, and with beta != 0 the same pattern is read first -- measured 6 % of a K = 1024
+  // launch for the read alone.  Instead the tile goes through the (now idle) staging LDS in
+  // 32-row chunks and every global access is a full row segment: 64 consecutive 16-byte vectors,
+  // BN * sizeof(T) contiguous bytes per row (1 KiB for the 128-column fp64 tile).
+  constexpr int RC = 32;                                   // rows per chunk
+  constexpr int PITCH = BN * (int)sizeof(T) + 128;         // +128 B: rows r, r+1 land in different bank halves
+  constexpr int VPR = BN * (int)sizeof(T) / 16;            // 16-byte vectors per row
+  constexpr int RPP = NT / VPR;                            // rows per pass of the whole workgroup
+  constexpr int NPASS = RC / RPP;
+  static_assert(RC * PITCH <= 2 * (BM + BN) * ROWB, "epilogue chunk must fit in the staging LDS");
+  static_assert(NT % VPR == 0 && RC % RPP == 0 && BM % RC == 0, "epilogue tiling");
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (ldc % EPC == 0);
+  if (vec_ok) {
+    const int col_l = lane & 15;
+    const int vrow = tid / VPR, vcol = (tid % VPR) * EPC;  // this thread's row (within a pass) and first column
+#pragma unroll
+    for (int c = 0; c < BM / RC; ++c) {
+      // global reads of the chunk first (they overlap the LDS traffic below)
+      chunk_t cold[NPASS];
+      if (beta != T(0)) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          const int row = m0 + c * RC + p * RPP + vrow, col = n0 + vcol;
+          cold[p] = chunk_t{};
+          if (!(lower_only && col > row)) cold[p] = *reinterpret_cast<const chunk_t*>(C + (int64_t)row * ldc + col);
+        }
+      }
+      // accumulators of the waves that own rows of this chunk -> LDS (row-major)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if ((wm + i * 16) / RC == c) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int rl = (wm + i * 16) % RC + M::row(lane, r);
+              *reinterpret_cast<T*>(smem + rl * PITCH + (wn + j * 16 + col_l) * (int)sizeof(T)) = acc[i][j][r];
+            }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int rl = p * RPP + vrow;
+        const int row = m0 + c * RC + rl, col = n0 + vcol;
+        if (lower_only && col > row) continue;
+        chunk_t v = *reinterpret_cast<const chunk_t*>(smem + rl * PITCH + vcol * (int)sizeof(T));
+        v = v * alpha;
+        if (beta != T(0)) v = v + cold[p] * beta;
+        T* dst = C + (int64_t)row * ldc + col;
+        if (!lower_only || col + EPC - 1 <= row) {
+          *reinterpret_cast<chunk_t*>(dst) = v;
+        } else {                                           // the vector straddles the diagonal
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            if (col + e <= row) dst[e] = v[e];
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // fallback (C not 16-byte aligned): element-wise from the MFMA layout
   const int col_l = lane & 15;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
