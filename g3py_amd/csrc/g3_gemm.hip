@@ -166,6 +166,29 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // epilogue geometry (see below).  (Requesting the first chunk of C before the last K tile would
+  // hide its latency too, but costs 25 VGPRs: the kernel must stay <= 224 so that the
+  // critical-path diagonal kernel still fits beside one of these workgroups.)
+  constexpr int RC = 32;                                   // rows per chunk
+  constexpr int PITCH = BN * (int)sizeof(T) + 128;         // +128 B: rows r, r+1 land in different bank halves
+  constexpr int VPR = BN * (int)sizeof(T) / 16;            // 16-byte vectors per row
+  constexpr int RPP = NT / VPR;                            // rows per pass of the whole workgroup
+  constexpr int NPASS = RC / RPP;
+  constexpr int NCH = BM / RC;
+  static_assert(RC * PITCH <= 2 * (BM + BN) * ROWB, "epilogue chunk must fit in the staging LDS");
+  static_assert(NT % VPR == 0 && RC % RPP == 0 && BM % RC == 0, "epilogue tiling");
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (ldc % EPC == 0);
+  const bool rmw = vec_ok && beta != T(0);
+  const int vrow = tid / VPR, vcol = (tid % VPR) * EPC;    // this thread's row (within a pass) and first column
+  chunk_t cnext[NPASS];
+  auto fetch_c = [&](int c) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int row = m0 + c * RC + p * RPP + vrow, col = n0 + vcol;
+      cnext[p] = chunk_t{};
+      if (!(lower_only && col > row)) cnext[p] = *reinterpret_cast<const chunk_t*>(C + (int64_t)row * ldc + col);
+    }
+  };
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) stage(buf ^ 1, (kt + 1) * BK);
@@ -181,29 +204,16 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   // launch for the read alone.  Instead the tile goes through the (now idle) staging LDS in
   // 32-row chunks and every global access is a full row segment: 64 consecutive 16-byte vectors,
   // BN * sizeof(T) contiguous bytes per row (1 KiB for the 128-column fp64 tile).
-  constexpr int RC = 32;                                   // rows per chunk
-  constexpr int PITCH = BN * (int)sizeof(T) + 128;         // +128 B: rows r, r+1 land in different bank halves
-  constexpr int VPR = BN * (int)sizeof(T) / 16;            // 16-byte vectors per row
-  constexpr int RPP = NT / VPR;                            // rows per pass of the whole workgroup
-  constexpr int NPASS = RC / RPP;
-  static_assert(RC * PITCH <= 2 * (BM + BN) * ROWB, "epilogue chunk must fit in the staging LDS");
-  static_assert(NT % VPR == 0 && RC % RPP == 0 && BM % RC == 0, "epilogue tiling");
-  const bool vec_ok = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (ldc % EPC == 0);
   if (vec_ok) {
     const int col_l = lane & 15;
-    const int vrow = tid / VPR, vcol = (tid % VPR) * EPC;  // this thread's row (within a pass) and first column
+    if (rmw) fetch_c(0);
 #pragma unroll
-    for (int c = 0; c < BM / RC; ++c) {
-      // global reads of the chunk first (they overlap the LDS traffic below)
+    for (int c = 0; c < NCH; ++c) {
+      // this chunk's C vectors were requested one step ago; request the next chunk's now
       chunk_t cold[NPASS];
-      if (beta != T(0)) {
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-          const int row = m0 + c * RC + p * RPP + vrow, col = n0 + vcol;
-          cold[p] = chunk_t{};
-          if (!(lower_only && col > row)) cold[p] = *reinterpret_cast<const chunk_t*>(C + (int64_t)row * ldc + col);
-        }
-      }
+      for (int p = 0; p < NPASS; ++p) cold[p] = cnext[p];
+      if (rmw && c + 1 < NCH) fetch_c(c + 1);
       // accumulators of the waves that own rows of this chunk -> LDS (row-major)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -225,7 +235,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
         if (lower_only && col > row) continue;
         chunk_t v = *reinterpret_cast<const chunk_t*>(smem + rl * PITCH + vcol * (int)sizeof(T));
         v = v * alpha;
-        if (beta != T(0)) v = v + cold[p] * beta;
+        if (rmw) v = v + cold[p] * beta;
         T* dst = C + (int64_t)row * ldc + col;
         if (!lower_only || col + EPC - 1 <= row) {
           *reinterpret_cast<chunk_t*>(dst) = v;
