@@ -18,9 +18,10 @@ st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 dev.set_stream(st.cuda_stream)
 for (m, n, k, lower) in shapes:
-    A = torch.rand((max(m, n), k), dtype=TDT, device='cuda') - 0.5
+    lda = max(k, int(os.environ.get('G3_LDA', '0')))      # G3_LDA: the operand is a column block of a wider matrix
+    A = torch.rand((max(m, n), lda), dtype=TDT, device='cuda') - 0.5
     C = torch.rand((m, n), dtype=TDT, device='cuda')
-    Ad = dev.wrap(A.data_ptr(), max(m, n), k, k, DT)
+    Ad = dev.wrap(A.data_ptr(), max(m, n), k, lda, DT)
     Cd = dev.wrap(C.data_ptr(), m, n, n, DT)
     for _ in range(2):
         dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=float(os.environ.get('G3_BETA', '1.0')), lower_only=bool(lower))
