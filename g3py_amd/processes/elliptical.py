@@ -239,26 +239,37 @@ class EllipticalProcess(StochasticProcess):
         _, mu, _, _, _ = self._cross(c, values, space, False, kernel=cross_kernel)
         return loc + mu
 
-    def th_kernel(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+    def _kernel_dev(self, space, inputs, outputs, params, prior, noise):
+        """prior / posterior covariance of `space` as a DEVICE matrix: (K, M, rows of K)"""
         values, _ = self._values(params)
         dev = self.device
         if prior:
-            K, M, _ = self._prior_gram(values, space, noise)
-            return dev.download(K)
+            K, M, Mp = self._prior_gram(values, space, noise)
+            return K, M, Mp
         c = self._factor(values, inputs, outputs)
         self._solve(c, values, c['which'] or 'post')
         V, _, _, M, Mp = self._cross(c, values, space, noise)
         K, _, _ = self._prior_gram(values, space, noise, pad=True)
         dev.gemm_nt(K, V, V, Mp, Mp, c['Np'], alpha=-1.0, beta=1.0)        # elliptical.py:86-91
-        return dev.download(K, M, M)
+        return K, M, Mp
+
+    def th_kernel(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        K, M, _ = self._kernel_dev(space, inputs, outputs, params, prior, noise)
+        return self.device.download(K, M, M)
+
+    def th_cholesky_dev(self, space, inputs, outputs, vector, params, prior=False, noise=False):
+        """cholesky_robust of the prior / posterior covariance, kept on the device: (L zero-padded to
+        a multiple of 128, M, padded size) -- what the samplers multiply the normal draws with"""
+        dev = self.device
+        K, M, _ = self._kernel_dev(space, inputs, outputs, params, prior, noise)
+        Mp = _lib.roundup(M, _lib.G3_RHS_PAD)
+        Ld = dev.alloc(Mp, Mp, self.dtype, zero=True)
+        dev.potrf_robust(K, Ld, M)                                        # elliptical.py:72,76,88,92
+        return Ld, M, Mp
 
     def th_cholesky(self, space, inputs, outputs, vector, params, prior=False, noise=False):
-        dev = self.device
-        K = self.th_kernel(space, inputs, outputs, vector, params, prior=prior, noise=noise)
-        M = K.shape[0]
-        Kd, Ld = dev.upload(K), dev.alloc(M, M, self.dtype)
-        dev.potrf_robust(Kd, Ld, M)                                       # elliptical.py:72,76,88,92
-        return dev.download(Ld)
+        Ld, M, _ = self.th_cholesky_dev(space, inputs, outputs, vector, params, prior=prior, noise=noise)
+        return self.device.download(Ld, M, M)
 
     def th_kernel_diag(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         values, _ = self._values(params)
@@ -328,4 +339,5 @@ class EllipticalProcess(StochasticProcess):
                 ('location', 'th_location'), ('kernel', 'th_kernel'), ('cholesky', 'th_cholesky'),
                 ('kernel_diag', 'th_kernel_diag'), ('kernel_sd', 'th_kernel_sd'),
                 ('cholesky_diag', 'th_cholesky_diag'), ('cross_mean', 'th_cross_mean'), ('freedom', 'th_freedom'),
-                ('error_l1', 'th_error_l1'), ('error_l2', 'th_error_l2'), ('error_mse', 'th_error_mse'))
+                ('error_l1', 'th_error_l1'), ('error_l2', 'th_error_l2'), ('error_mse', 'th_error_mse'),
+                ('_cholesky_dev', 'th_cholesky_dev'))

@@ -229,10 +229,9 @@ class GaussianProcess(EllipticalProcess):
         rand = np.asarray(rand, dtype=self.dtype)
         S = rand.shape[1]
         loc = self.location(params, space, inputs, outputs, prior=prior, noise=noise)
-        L = self.cholesky(params, space, inputs, outputs, prior=prior, noise=noise)
+        Ld, _, Mp = self._cholesky_dev(params, space, inputs, outputs, prior=prior, noise=noise)   # stays on the device
         dev = self.device
-        Mp, Sp = _lib.roundup(M, _lib.G3_RHS_PAD), _lib.roundup(S, 64)
-        Ld = dev.upload(L, pad_rows=Mp, pad_cols=Mp)
+        Sp = _lib.roundup(S, 64)
         Zt = dev.upload(np.ascontiguousarray(rand.T), pad_rows=Sp, pad_cols=Mp)
         out = dev.alloc(Sp, Mp, self.dtype)
         dev.gemm_nt(out, Zt, Ld, Sp, Mp, Mp)                      # (L Z)^T
