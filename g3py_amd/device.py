@@ -125,6 +125,14 @@ class Device:
         d.rows, d.cols = pr, pc
         return d
 
+    def copy_in(self, d, a):
+        """host array -> an existing device buffer of the same shape"""
+        a = np.ascontiguousarray(a, dtype=d.dtype)
+        if a.nbytes > d.nbytes:
+            raise G3Error('copy_in: %d bytes do not fit in a buffer of %d' % (a.nbytes, d.nbytes))
+        if a.nbytes:
+            _check(self, self.lib.g3_memcpy_h2d(self.ctx, d.ptr, a.ctypes.data, a.nbytes), 'g3_memcpy_h2d')
+
     def download(self, d, rows=None, cols=None):
         rows = d.rows if rows is None else rows
         cols = d.cols if cols is None else cols

@@ -32,6 +32,7 @@ class EllipticalProcess(StochasticProcess):
         else:
             self.f_kernel_noise = self.f_kernel
         self._cache = None
+        self._workspace = None
         kwargs['space'] = space
         super().__init__(*args, **kwargs)
 
@@ -70,6 +71,9 @@ class EllipticalProcess(StochasticProcess):
     def _values(self, params):
         """transformed-space params dict -> natural-space values by hyper name; also the
         log-Jacobian term of the FlatExp variables (hypers/__init__.py:199-200)."""
+        memo = getattr(self, '_values_memo', None)
+        if memo is not None and memo[0] is params:          # th_logp -> th_loglike -> ... share one params object
+            return memo[1], memo[2]
         values, logjac = {}, 0.0
         for v in self.model.vars:
             p = np.asarray(params[v.key], dtype=np.float64)
@@ -86,6 +90,7 @@ class EllipticalProcess(StochasticProcess):
                 logjac += c * -float(sum(np.sum(np.abs(values[h.name])) for h in sel))
             elif reg == 'L2':
                 logjac += c * -float(sum(np.sum(np.asarray(values[h.name]) ** 2) for h in sel))
+        self._values_memo = (params, values, logjac)
         return values, logjac
 
     def _x(self, a):
@@ -114,10 +119,17 @@ class EllipticalProcess(StochasticProcess):
         # tt_to_num(mapping.inv(outputs)) is what the posterior uses (elliptical.py:63)
         mapped_num = np.where(np.isnan(mapped), 0, np.where(np.isinf(mapped), self.dtype.type(np.float32(1e10)), mapped))
         Np = _lib.roundup(N)
-        Xd = dev.upload(X)
-        Kd = dev.alloc(Np + _lib.G3_RHS_PAD, Np, self.dtype)   # + the right-hand-side block that carries delta
-        ad = dev.alloc(1, Np, self.dtype)
-        Wd = dev.alloc_inverses(Np, self.dtype)
+        # device workspace: re-used while the observations stay the same (optimisers and samplers call
+        # logp / dlogp thousands of times on one data set -- hipMalloc and the upload of X would
+        # otherwise dominate small problems)
+        ws = self._workspace
+        if ws is None or ws['shape'] != X.shape or not np.array_equal(ws['X'], X):
+            ws = dict(shape=X.shape, X=X.copy(), Xd=dev.upload(X),
+                      Kd=dev.alloc(Np + _lib.G3_RHS_PAD, Np, self.dtype),   # + the right-hand-side block that carries delta
+                      ad=dev.alloc(1, Np, self.dtype), Wd=dev.alloc_inverses(Np, self.dtype),
+                      dvec=dev.alloc(1, N, self.dtype))
+            self._workspace = ws
+        Xd, Kd, ad, Wd = ws['Xd'], ws['Kd'], ws['ad'], ws['Wd']
         c = dict(key=key, X=X.copy(), y=y.copy(), N=N, d=d, Np=Np, Xd=Xd, Kd=Kd, Wd=Wd, ad=ad, mu=mu, det_m=det_m,
                  delta=delta, delta_post=mapped_num - mu, stats=None, which=None)
         c['same_delta'] = bool(np.array_equal(c['delta'], c['delta_post']))
@@ -131,7 +143,8 @@ class EllipticalProcess(StochasticProcess):
         dev = self.device
         dl = c['delta'] if which == 'logp' else c['delta_post']
         finite = np.all(np.isfinite(dl))
-        dvec = dev.upload(np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
+        dvec = self._workspace['dvec']
+        dev.copy_in(dvec, np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
         prog = self._prog(self.f_kernel_noise, values, c['d'])
         st = dev.gp_factor(prog, c['Xd'], c['N'], c['d'], dvec, c['Kd'], c['Wd'], c['ad'])
         st['delta_finite'] = bool(finite)
