@@ -37,6 +37,30 @@ def test_gemm_nt(dev, dt, m, n, k, lower):
     assert np.abs(got - ref).max() <= TOL[dt] * np.abs(ref).max() * max(1, k / 64)
 
 
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+@pytest.mark.parametrize('lower', [False, True])
+def test_gemm_unaligned_c_takes_the_scalar_epilogue(dev, dt, lower):
+    """C with an odd leading dimension / offset start is not 16-byte aligned row by row: the kernel
+    falls back from the vectorised LDS epilogue to element-wise stores; a sub-block of a wider C and
+    beta = 0 are covered on the way"""
+    m, n, k, ld = 192, 128, 64, 131
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((m, k)).astype(dt)
+    B = rng.standard_normal((n, k)).astype(dt)
+    C = rng.standard_normal((m, ld)).astype(dt)
+    Ad, Bd, Cd = dev.upload(A), dev.upload(B), dev.upload(C)
+    dev.gemm_nt(Cd, Ad, Bd, m, n, k, alpha=2.0, beta=-1.0, lower_only=lower, c_off=np.dtype(dt).itemsize)   # starts at column 1
+    got = dev.download(Cd)
+    ref = C.astype(np.float64)
+    upd = 2.0 * A.astype(np.float64) @ B.astype(np.float64).T - ref[:, 1:1 + n]
+    mask = np.tril(np.ones((m, n), bool)) if lower else np.ones((m, n), bool)
+    ref[:, 1:1 + n] = np.where(mask, upd, ref[:, 1:1 + n])
+    assert np.abs(got - ref).max() <= TOL[dt] * np.abs(ref).max() * 4
+    C0 = dev.upload(np.full((m, n), np.nan, dtype=dt))          # beta = 0 must not read C
+    dev.gemm_nt(C0, Ad, Bd, m, n, k, alpha=1.0, beta=0.0)
+    assert np.abs(dev.download(C0) - A.astype(np.float64) @ B.astype(np.float64).T).max() <= TOL[dt] * 50
+
+
 def test_gemm_identity_layout(dev):
     # A = I with asymmetric B catches a row<->col swap of the MFMA accumulator layout
     n = 128
