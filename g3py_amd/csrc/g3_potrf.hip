@@ -500,7 +500,10 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
       int64_t w = NB;
       if (taper) {
         const int64_t rem = n - r0;
-        while (w > 256 && rem <= (int64_t)taper * w) w /= 2;
+        static int wmin = -1;
+        if (wmin < 0) { const char* e = getenv("G3_NB_MIN"); wmin = e ? atoi(e) : 128; }
+        const int64_t wlo = ctx->batch > 1 && wmin < 256 ? 256 : wmin;   // batched sweeps: work per launch matters more
+        while (w > wlo && rem <= (int64_t)taper * w) w /= 2;
       }
       w = g3_roundup(w, LB);
       bnd.push_back(r0);
@@ -587,7 +590,9 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
     const char* e = getenv("G3_NB");
     // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
     // kernels that dominates small problems, wide panels give the bulk updates more K
-    NB = e ? atoll(e) : (n <= 8192 ? 256 : (n <= 20480 ? 512 : 1024));
+    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 8192 ? 256 : (n <= 20480 ? 512 : 1024)));
+    // a batched sweep is bound by work per launch, not by the chain: wider panels again
+    if (!e && ctx->batch > 1 && NB < 256) NB = 256;
   }
   NB = g3_roundup(NB < LB ? LB : NB, LB);
   if (n >= 3 * NB) {
