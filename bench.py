@@ -188,7 +188,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dev.prof_enable(not args.no_prof)
+    # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
+    dev.prof_enable(0 if args.no_prof else (3 if world > 1 else 1))
     dev.prof_reset()
     if world > 1:
         dist.barrier()
@@ -232,13 +233,20 @@ def main():
             out['cholesky_tflops'] = (N ** 3 / 3.0) / t_ph / 1e12
             out['factor_solve_tflops'] = prof['potrf']['work'] / prof['potrf']['count'] / t_ph / 1e12
         g = prof['gemm_bulk']
-        if g['count']:
+        kern = 'gemm_nt_kernel<%s,128,128,64,64>, launches with >= 1024 tiles ' % ('float' if args.f32 else 'double') + \
+               '(bulk panel updates of the blocked Cholesky and of the trsm)'
+        if world > 1:
+            # the row-block layout issues per-block updates (m = nb rows): a 1-in-16 sample of the MFMA GEMM launches of rank 0
+            g = {k: sum(prof[t][k] for t in ('gemm_bulk', 'gemm_mid', 'gemm_small')) for k in ('count', 'ms', 'work')}
+            kern = 'gemm_nt_kernel<%s,*>: 1-in-16 sample of the MFMA GEMM launches of rank 0 (trailing updates and panel solves of ' \
+                   'its row blocks)' % ('float' if args.f32 else 'double')
+        if g['count'] and g['ms'] > 0:
             ach = g['work'] / (g['ms'] * 1e-3) / 1e12
             peak = FP32_MATRIX_PEAK_TFLOPS if args.f32 else FP64_MATRIX_PEAK_TFLOPS
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                               'frac': ach / peak, 'traffic': _traffic() if (not args.f32 and N == 32768) else None,
-                               'kernel': 'gemm_nt_kernel<%s,128,128,64,64>, launches with >= 1024 tiles ' % ('float' if args.f32 else 'double') +
-                                         '(bulk panel updates of the blocked Cholesky and of the trsm)',
+                               'frac': ach / peak,
+                               'traffic': _traffic() if (world == 1 and not args.f32 and N == 32768) else None,
+                               'kernel': kern,
                                'launches_per_step': g['count'] / args.steps,
                                'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],
                                'note': 'HIP events per launch on the launching stream; launches on the two '

@@ -99,7 +99,11 @@ extern "C" int g3_prof_reset(g3_ctx* ctx) {
 int g3i_prof_begin(g3_ctx* ctx, int tag, double work) {
   if (!ctx->prof_on || ctx->prof_n + 2 > ctx->prof_cap) return -1;
   // level 1 (default): phases and the large GEMM launches only; level 2 adds every small launch
-  if (ctx->prof_level < 2 && (tag == G3_TAG_GEMM_SMALL || tag == G3_TAG_LEAF || tag == G3_TAG_GEMM_MID)) return -1;
+  const bool minor = tag == G3_TAG_GEMM_SMALL || tag == G3_TAG_LEAF || tag == G3_TAG_GEMM_MID;
+  if (ctx->prof_level < 2 && minor) return -1;
+  // level 3: like 2, but only every 16th of the small launches is timed (an unbiased sample that
+  // keeps the event traffic out of launch-bound loops such as the multi-GPU driver's)
+  if (ctx->prof_level == 3 && minor && (ctx->prof_skip++ & 15) != 0) return -1;
   const int r = ctx->prof_nrec++;
   ctx->prof_rec[r].e0 = ctx->prof_n++;
   ctx->prof_rec[r].e1 = ctx->prof_n++;

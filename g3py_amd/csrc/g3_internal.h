@@ -45,6 +45,7 @@ struct g3_ctx {
   // optional profiling: HIP-event pairs around tagged regions (g3_prof_*)
   bool prof_on;
   int prof_level;
+  unsigned prof_skip;      // sampling counter of level 3
   hipEvent_t* prof_ev;
   int prof_cap, prof_n;          // events allocated / used
   struct { int e0, e1, tag; double work; }* prof_rec;

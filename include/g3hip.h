@@ -309,7 +309,8 @@ int g3_gp_dlogp(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map,
  * algorithmic work (flops, or bytes for the Gram tags).  Tags: 0 MFMA GEMM, 128x128 tile,
  * launches with >= 1024 tiles (the bulk panel updates), 1 Gram, 2 potrf (whole factorisation),
  * 3 trsv (L^-1 delta), 4 cross Gram, 5 trsm (predict), 6 reductions; and with on = 2 also
- * 7 other 128x128-tile GEMM launches, 8 small-tile GEMM launches, 9 fused diagonal-block kernels. */
+ * 7 other 128x128-tile GEMM launches, 8 small-tile GEMM launches, 9 fused diagonal-block kernels;
+ * on = 3 times only every 16th of those small launches (a sample, for launch-bound callers). */
 #define G3_PROF_NTAGS 10
 int g3_prof_enable(g3_ctx* ctx, int on);
 int g3_prof_reset(g3_ctx* ctx);
