@@ -197,3 +197,30 @@ def test_potri_matches_lapack(dev, n, dtype):
     assert np.max(np.abs(Yh - Linv.T)) < tol * np.max(np.abs(Linv))
     Kinv = np.linalg.inv(K)
     assert np.max(np.abs(np.tril(Kih) - np.tril(Kinv))) < tol * np.max(np.abs(Kinv))
+
+
+def test_new_entry_points_reject_bad_arguments(dev):
+    """status codes (-i = bad argument i) of the gradient / batched / multi-GPU entry points"""
+    import ctypes as C
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    lib, ctx = dev.lib, dev.ctx
+    prog = compile_spec(('sum', ('SE', 1.0, np.ones(2), None), ('NOISE', 0.1)), 2)
+    gmap = dev.grad_layout(prog)
+    assert gmap.nslots == 4 and list(gmap.var[:2]) == [0, 3] and gmap.rate[0] == 1
+    a = dev.alloc(256, 256, np.float64, zero=True)
+    out = (C.c_double * 8)()
+    assert lib.g3_potri(ctx, a.ptr, 100, 256, None, 0, a.ptr, 256, a.ptr, 256) == -3            # n not a multiple of 128
+    assert lib.g3_potri(ctx, a.ptr, 256, 255, None, 0, a.ptr, 256, a.ptr, 256) == -4            # ld < n
+    assert lib.g3_gram_grad(ctx, C.byref(prog), C.byref(gmap), a.ptr, 10, 1, 2, 0, a.ptr, 256, a.ptr, out) == -6   # ldx < d
+    bad = _lib.GradMap()
+    bad.nslots = 2
+    bad.var[0] = 5
+    assert lib.g3_gram_grad(ctx, C.byref(prog), C.byref(bad), a.ptr, 10, 2, 2, 0, a.ptr, 256, a.ptr, out) == -3    # slot outside the output
+    progs = (_lib.KernelProg * 2)(prog, compile_spec(('SE', 1.0, np.ones(2), None), 2))
+    rc = lib.g3_gp_factor_batched(ctx, progs, 2, a.ptr, 100, 2, 2, a.ptr, 128, 0, a.ptr, 128, 256 * 128, a.ptr, a.ptr, out)
+    assert rc == -2                                                                               # members of different structure
+    assert lib.g3_gp_factor_batched(ctx, progs, 0, a.ptr, 100, 2, 2, a.ptr, 128, 0, a.ptr, 128, 256 * 128, a.ptr, a.ptr, out) == -3
+    assert lib.g3_gram_rows(ctx, C.byref(prog), a.ptr, 100, 2, 2, 0, 128, 0, a.ptr, 64, 0) == -11                  # ldk < row0 + nrows
+    assert lib.g3_gram_rows(ctx, C.byref(prog), a.ptr, 100, 2, 2, 0, 128, 0, a.ptr, 128, _lib.G3_GRAM_LOWER) == -12
+    assert lib.g3_potrf_nowait(ctx, a.ptr, 128, 256, 0, a.ptr, None) == -7
