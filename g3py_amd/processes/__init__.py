@@ -3,6 +3,7 @@ from .hypers.metrics import *
 from .hypers.kernels import *
 from .hypers.means import *
 from .hypers.mappings import *
+from .hypers.transports import Transport, TransportComposed, ID, TElemwise, TLocation, TMapping, TKernel
 from .stochastic import StochasticProcess, GraphicalModel
 from .elliptical import EllipticalProcess
 from .gaussian import GaussianProcess, WarpedGaussianProcess

@@ -747,6 +747,41 @@ class TP(GP):
                           self.freedom(prior=True), self.map)
 
 
+# --------------------------------------------------------------------------- transports
+class TKernelOracle:
+    """TKernel -- g3py/processes/hypers/transports.py:200-257, literally (the joint covariance is formed)."""
+
+    def __init__(self, kernel_f, noise_var=None, dtype=np.float64):
+        self.kf = kernel_f
+        self.kn = kernel_f if noise_var is None else ('sum', kernel_f, ('NOISE', noise_var))
+        self.dtype = dtype
+
+    def _cov(self, x, noise, x2=None):
+        return kernel_cov(self.kn if noise else self.kf, x, x2, self.dtype)
+
+    def __call__(self, inputs, outputs, noise=False):
+        return cholesky_robust(self._cov(inputs, noise)).dot(outputs)                        # :212-218
+
+    def diag(self, inputs, outputs, noise=False):
+        return np.sqrt(np.diag(self._cov(inputs, noise))) * outputs                          # :220-227
+
+    def inv(self, inputs, outputs, noise=False):
+        return sp.linalg.solve_triangular(cholesky_robust(self._cov(inputs, noise)), outputs, lower=True)   # :229-234
+
+    def logdet_dinv(self, inputs, outputs):
+        return -np.sum(np.log(np.diag(cholesky_robust(self._cov(inputs, True)))))            # :236-238
+
+    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True):
+        outputs_inv = self.inv(inputs, outputs, noise=noise_obs)                             # :240
+        cov_inputs = self._cov(inputs, noise_obs)
+        cov_space = self._cov(space, noise_pred)
+        cov_space_inputs = kernel_cov(self.kf, inputs, space, self.dtype)                    # :249
+        cov = np.concatenate([np.concatenate([cov_inputs, cov_space_inputs], axis=1),
+                              np.concatenate([cov_space_inputs.T, cov_space], axis=1)])      # :250-252
+        cho = cholesky_robust(cov)
+        return cho.dot(np.concatenate([outputs_inv, pred]))[len(inputs):]                    # :253-257
+
+
 # --------------------------------------------------------------------------- CPU baseline
 def cpu_hot_path(X, y, Xs, var=1.0, rate=1.0, noise=0.1):
     """One pass of the benchmark hot path on the CPU (bench.py `cpu_baseline`, kind "port"):

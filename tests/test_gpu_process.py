@@ -480,3 +480,47 @@ def test_fixed_chain_averages(golden_dir):
     np.testing.assert_allclose(gp.active.dict_to_array(d)[:4], sp)
     gp.active.fix_vars()
     assert gp.active.fixed_chain is None and gp.active.sampling_dims == list(range(5))
+
+
+# ------------------------------------------------------------------ transports (hypers/transports.py)
+def test_tkernel_transport_matches_oracle():
+    """TKernel on the device (block schedule: V a + chol(Kss - V V^T) z) against the literal joint-covariance
+    restatement, plus composition with a location and a warping"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(8)
+    X, Xs = rng.uniform(0, 3, (300, 2)), rng.uniform(0, 3, (40, 2))
+    y = np.sin(X.sum(1)) + 0.05 * rng.standard_normal(300)
+    r = np.array([0.8, 1.1])
+    with g3.Model('t') as model:
+        tk = g3.TKernel(g3.SE(X), noisy=True)
+        tl = g3.TLocation(g3.Bias(X))
+        tm = g3.TMapping(g3.ArcsinhLinear(y))
+        for t in (tk, tl, tm):
+            t.check_dims(X)
+            t.check_hypers('T_')
+    names = [v.name for v in model.vars]
+    assert names == ['T_SE_var', 'T_SE_rate', 'T_NoiseSE_var', 'T_Bias_Bias', 'T_ArcsinhLinear_shift', 'T_ArcsinhLinear_scale']
+    values = {'T_SE_var': 1.2, 'T_SE_rate': r, 'T_NoiseSE_var': 0.1, 'T_Bias_Bias': 0.3, 'T_ArcsinhLinear_shift': 0.1,
+              'T_ArcsinhLinear_scale': 0.9}
+    ref = orc.TKernelOracle(('SE', 1.2, r, None), 0.1)
+    z = rng.standard_normal(40)
+    v = rng.standard_normal(300)
+    np.testing.assert_allclose(tk(X, v, noise=True, values=values), ref(X, v, noise=True), atol=1e-9)
+    np.testing.assert_allclose(tk.inv(X, y, noise=True, values=values), ref.inv(X, y, noise=True), atol=1e-8)
+    np.testing.assert_allclose(tk.diag(X, v, noise=True, values=values), ref.diag(X, v, noise=True), atol=1e-12)
+    assert abs(tk.logdet_dinv(X, y, values=values) - ref.logdet_dinv(X, y)) <= 1e-9 * abs(ref.logdet_dinv(X, y))
+    for noise_pred in (False, True):
+        got = tk.posterior(Xs, z, X, y, noise_pred=noise_pred, noise_obs=True, values=values)
+        np.testing.assert_allclose(got, ref.posterior(Xs, z, X, y, noise_pred=noise_pred, noise_obs=True), atol=1e-8)
+    # composition: y = arcsinh-warp(bias + chol(K) x)
+    T = tm @ (tl @ tk)
+    yy = np.sinh((y - 0.1) / 0.9)
+    mp = orc.Mapping(('ArcsinhLinear', 0.1, 0.9))
+    x_ref = ref.inv(X, mp.inv(yy) - 0.3, noise=True)
+    np.testing.assert_allclose(T.inv(X, yy, noise=True, values=values), x_ref, atol=1e-8)
+    np.testing.assert_allclose(T(X, x_ref, noise=True, values=values), yy, atol=1e-8)
+    ld = T.logdet_dinv(X, yy, values=values)
+    assert abs(ld - (ref.logdet_dinv(X, y) + mp.logdet_dinv(yy))) <= 1e-9 * abs(ld)
+    want = mp(0.3 + ref.posterior(Xs, z, X, mp.inv(yy) - 0.3))
+    np.testing.assert_allclose(T.posterior(Xs, z, X, yy, values=values), want, atol=1e-8)

@@ -361,3 +361,19 @@ def test_student_t_dlogp_matches_finite_differences():
                    (kern[(1, 'var', None)], fd('noise')), (g['mean'][0][2], fd('bias')), (g['mapping'][0][1], fd('shift')),
                    (tp.dlogp_degree(X, y), fd('deg'))]:
         assert abs(val - f) <= 2e-6 * max(1.0, abs(val)), (val, f)
+
+
+def test_tkernel_oracle_posterior_is_the_gp_posterior():
+    """transports.py:239-257 with pred = 0 is the GP posterior mean; with pred = z a posterior draw"""
+    rng = np.random.default_rng(8)
+    X, Xs = rng.uniform(0, 3, (50, 2)), rng.uniform(0, 3, (7, 2))
+    y = np.sin(X.sum(1))
+    kf = ('SE', 1.2, np.array([0.8, 1.1]), None)
+    t = orc.TKernelOracle(kf, 0.1)
+    gp = orc.GP(kf, 0.1)
+    np.testing.assert_allclose(t.posterior(Xs, np.zeros(7), X, y), gp.mean(Xs, X, y), atol=1e-10)
+    z = rng.standard_normal(7)
+    Lp = np.linalg.cholesky(gp.kernel(Xs, X, noise=False))
+    np.testing.assert_allclose(t.posterior(Xs, z, X, y), gp.mean(Xs, X, y) + Lp.dot(z), atol=1e-8)
+    np.testing.assert_allclose(t.inv(X, t(X, y, noise=True), noise=True), y, atol=1e-10)
+    assert abs(t.logdet_dinv(X, y) + 0.5 * np.linalg.slogdet(orc.kernel_cov(t.kn, X))[1]) < 1e-10
