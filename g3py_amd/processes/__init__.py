@@ -8,9 +8,11 @@ from .stochastic import StochasticProcess, GraphicalModel
 from .elliptical import EllipticalProcess
 from .gaussian import GaussianProcess, WarpedGaussianProcess
 from .studentT import StudentTProcess, WarpedStudentTProcess
+from .transport import TransportProcess, TransportGaussianProcess
 
 # aliases of g3py/processes/__init__.py:9-16
 GP = GaussianProcess
 WGP = WarpedGaussianProcess
 TP = StudentTProcess
 WTP = WarpedStudentTProcess
+TGP = TransportGaussianProcess

@@ -17,8 +17,8 @@ reference in exact arithmetic whenever no jitter is needed (the reference applie
 schedule to the joint matrix, this module to the two blocks).
 
 Numeric API: every method takes the natural-space hyper values (`values`, name -> value) that a
-process would hand down; constants need none.  The `TransportProcess` front end of
-g3py/processes/transport.py is not built.
+process would hand down; constants need none.  `g3py_amd/processes/transport.py` is the
+process front end (`TransportProcess`, `TransportGaussianProcess`).
 """
 import numpy as np
 
@@ -44,7 +44,7 @@ class Transport(Hypers):
     def logdet_dinv(self, inputs, outputs, values=None):
         raise NotImplementedError
 
-    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True, values=None):
+    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True, diag=False, inv=False, values=None):
         """transports.py:27-33: push [T^-1(outputs); pred] through the transport of [inputs; space]"""
         outputs_inv = self.inv(inputs, outputs, noise=True, values=values)
         full = self(np.concatenate([inputs, space]), np.concatenate([outputs_inv, pred]), noise=True, values=values)
@@ -92,7 +92,7 @@ class TransportComposed(Transport):
         return (self.t2.logdet_dinv(inputs, self.t1.inv(inputs, outputs, noise=True, values=values), values=values)
                 + self.t1.logdet_dinv(inputs, outputs, values=values))
 
-    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True, values=None):
+    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True, diag=False, inv=False, values=None):
         inner = self.t2.posterior(space, pred, inputs, self.t1.inv(inputs, outputs, noise=noise_obs, values=values),
                                   noise_pred=noise_pred, noise_obs=noise_obs, values=values)
         return self.t1.posterior(space, inner, inputs, outputs, noise_pred=noise_pred, noise_obs=noise_obs, values=values)
@@ -110,7 +110,8 @@ class ID(Transport):
 
 
 class TElemwise(Transport):
-    def posterior(self, space, pred, inputs=None, outputs=None, noise_pred=False, noise_obs=True, values=None):
+    def posterior(self, space, pred, inputs=None, outputs=None, noise_pred=False, noise_obs=True, diag=False, inv=False,
+                  values=None):
         return self(space, pred, noise=noise_pred, values=values)
 
 
@@ -231,7 +232,7 @@ class TKernel(Transport):
     def logdet_dinv(self, inputs, outputs, values=None):
         return -self._factor(inputs, outputs, True, values)['st']['logdet']                   # :236-238
 
-    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True, values=None):
+    def posterior(self, space, pred, inputs, outputs, noise_pred=False, noise_obs=True, diag=False, inv=False, values=None):
         """rows N.. of chol(joint covariance) [L^-1 outputs; pred] without forming the joint matrix (:239-257)"""
         dev = self.device
         f = self._factor(inputs, outputs, noise_obs, values, space=space)
