@@ -467,12 +467,180 @@ grad_reduce_kernel(const double* __restrict__ partial, int nblocks, int width, d
   if (threadIdx.x == 0) out[s] = red[0];
 }
 
+// ---- fast path: prog == var * SE(all d columns in order) [+ noise on the diagonal], D compile-time.
+// Accumulators live in registers (var, noise, D rates); one exp per pair; the pass is bound by
+// reading the lower triangle of K^-1.  Slot order of the partial sums: [var, noise, rate_0..rate_{D-1}].
+template <int D>
+struct SeGradParams {
+  double w[D];      // 0.5 * rate^2
+  double rate[D];
+  double var;
+};
+
+template <typename T, int D>
+__global__ void __launch_bounds__(GG_THREADS)
+gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int64_t ldx, const T* __restrict__ G,
+                    int64_t ldg, const T* __restrict__ alpha, double* __restrict__ partial) {
+  __shared__ double xi_s[GG_T * (D | 1)], xj_s[GG_T * (D | 1)], ai_s[GG_T], aj_s[GG_T];
+  __shared__ double red[(D + 2) * (GG_THREADS / 64)];
+  constexpr int dp = D | 1;
+  const int tid = threadIdx.x;
+  double g_var = 0.0, g_noise = 0.0, g_rate[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) g_rate[k] = 0.0;
+  const int64_t nt = (N + GG_T - 1) / GG_T;
+  const int64_t ntiles = nt * (nt + 1) / 2;
+  for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    int64_t bi = (int64_t)((sqrt(1.0 + 8.0 * (double)id) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
+    while (bi * (bi + 1) / 2 > id) --bi;
+    const int64_t bj = id - bi * (bi + 1) / 2;
+    const int64_t i0 = bi * GG_T, j0 = bj * GG_T;
+    __syncthreads();
+    for (int e = tid; e < GG_T * D; e += GG_THREADS) {
+      const int r = e / D, c = e - r * D;
+      xi_s[r * dp + c] = i0 + r < N ? (double)X[(i0 + r) * ldx + c] : 0.0;
+      xj_s[r * dp + c] = j0 + r < N ? (double)X[(j0 + r) * ldx + c] : 0.0;
+    }
+    if (tid < GG_T) ai_s[tid] = i0 + tid < N ? (double)alpha[i0 + tid] : 0.0;
+    else if (tid < 2 * GG_T) aj_s[tid - GG_T] = j0 + tid - GG_T < N ? (double)alpha[j0 + tid - GG_T] : 0.0;
+    __syncthreads();
+    const int c = tid & (GG_T - 1);
+    const int64_t j = j0 + c;
+    double xj[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xj[k] = xj_s[c * dp + k];
+    const double aj = aj_s[c];
+#pragma unroll 4
+    for (int rr = tid >> 6; rr < GG_T; rr += GG_THREADS / GG_T) {
+      const int64_t i = i0 + rr;
+      if (i >= N || j > i) continue;
+      const bool diag = i == j;
+      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj - (double)G[i * ldg + j]);
+      double dx2[D], dd = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double dx = xi_s[rr * dp + k] - xj[k];
+        dx2[k] = dx * dx;
+        dd = fma(dx2[k], se.w[k], dd);
+      }
+      const double gk = g * exp(-dd);            // g * k_ij (unit variance)
+      g_var += gk;
+      if (diag) g_noise += g;
+      const double gv = -gk * se.var;
+#pragma unroll
+      for (int k = 0; k < D; ++k) g_rate[k] = fma(gv * se.rate[k], dx2[k], g_rate[k]);
+    }
+  }
+  // block reduction of the D + 2 sums
+  const int lane = tid & 63, wv = tid >> 6;
+  double vals[D + 2];
+  vals[0] = g_var; vals[1] = g_noise;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vals[2 + k] = g_rate[k];
+#pragma unroll
+  for (int s = 0; s < D + 2; ++s) {
+    double v = vals[s];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[s * (GG_THREADS / 64) + wv] = v;
+  }
+  __syncthreads();
+  if (tid < D + 2) {
+    double v = 0.0;
+    for (int q = 0; q < GG_THREADS / 64; ++q) v += red[tid * (GG_THREADS / 64) + q];
+    partial[(size_t)blockIdx.x * (D + 2) + tid] = v;
+  }
+}
+
+template <int D>
+static bool match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, int* leaf_se, int* leaf_noise) {
+  if (d != D || p->nprod < 1 || p->nprod > 2) return false;
+  int se = -1, noise = -1;
+  for (int q = 0; q < p->nprod; ++q) {
+    if (p->prod[q].nfac != 1 || p->prod[q].coef != 1.0) return false;
+    const int l = p->prod[q].fac[0];
+    if (p->leaf[l].kind == G3_K_SE && se < 0) se = l;
+    else if (p->leaf[l].kind == G3_K_NOISE && noise < 0) noise = l;
+    else return false;
+  }
+  if (se < 0) return false;
+  const g3_leaf& lf = p->leaf[se];
+  if (lf.ndims != D) return false;
+  for (int k = 0; k < D; ++k) {
+    if (lf.dims[k] != k) return false;
+    out->w[k] = 0.5 * lf.rate[k] * lf.rate[k];
+    out->rate[k] = lf.rate[k];
+  }
+  out->var = lf.var;
+  *leaf_se = se;
+  *leaf_noise = noise;
+  return true;
+}
+
+template <int D>
+static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N,
+                        int64_t ldx, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
+                        bool* handled) {
+  SeGradParams<D> se;
+  int lse = -1, lnoise = -1;
+  *handled = match_se_grad<D>(prog, D, &se, &lse, &lnoise);
+  if (!*handled) return G3_OK;
+  const int ns = D + 2;
+  const int64_t nt = (N + GG_T - 1) / GG_T;
+  const int64_t ntiles = nt * (nt + 1) / 2;
+  const int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
+  const size_t pbytes = (size_t)nblocks * ns * sizeof(double);
+  int rc = g3i_ensure_work(ctx, pbytes + 64 * sizeof(double));
+  if (rc) return rc;
+  double* partial = (double*)ctx->work;
+  double* dout = (double*)((char*)ctx->work + pbytes);
+  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * (N + 1) / 2 * g3_esize(dt));
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((gram_grad_se_kernel<double, D>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,
+                       (const double*)X, N, ldx, (const double*)G, ldg, (const double*)alpha, partial);
+  else
+    hipLaunchKernelGGL((gram_grad_se_kernel<float, D>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,
+                       (const float*)X, N, ldx, (const float*)G, ldg, (const float*)alpha, partial);
+  G3_LAUNCH_CHECK();
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(ns), dim3(256), 0, ctx->stream, partial, nblocks, ns, dout);
+  G3_LAUNCH_CHECK();
+  g3i_prof_end(ctx, rec);
+  double h[64];
+  G3_HIP(hipMemcpyAsync(h, dout, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < map->nslots; ++s) out_host[s] = 0.0;
+  if (map->var[lse] >= 0) out_host[map->var[lse]] = h[0];
+  if (lnoise >= 0 && map->var[lnoise] >= 0) out_host[map->var[lnoise]] = h[1];
+  if (map->rate[lse] >= 0)
+    for (int k = 0; k < D; ++k) out_host[map->rate[lse] + k] = h[2 + k];
+  return G3_OK;
+}
+
 int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N,
                   int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host) {
   const int nslots = map->nslots;
   if (nslots == 0 || N == 0) {
     for (int s = 0; s < nslots; ++s) out_host[s] = 0.0;
     return G3_OK;
+  }
+  static int generic_only = -1;   // G3_GRAD_GENERIC=1: development switch, always the sum-of-products kernel
+  if (generic_only < 0) {
+    const char* e = getenv("G3_GRAD_GENERIC");
+    generic_only = (e && atoi(e)) ? 1 : 0;
+  }
+  if (!generic_only) {   // var * SE(+ noise) on all columns: register fast path
+    bool done = false;
+    int r = G3_OK;
+    switch (d) {
+      case 1: r = gram_grad_se<1>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      case 2: r = gram_grad_se<2>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      case 3: r = gram_grad_se<3>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      case 4: r = gram_grad_se<4>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      case 8: r = gram_grad_se<8>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      case 16: r = gram_grad_se<16>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      default: break;
+    }
+    if (r || done) return r;
   }
   const g3_kernel_prog* dprog = nullptr;
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
