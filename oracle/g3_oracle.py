@@ -13,12 +13,14 @@ Pinning status (see DESIGN.md "Oracle"):
   * PINNED against the reference's own executable NumPy prototype `sandbox/gpmm.py`
     (imported in the build container by `oracle/gen_golden.py`; outputs committed under
     `tests/golden/gpmm_*.npz`): SE(+noise) and OU(+noise) Gram, Cholesky factor,
-    log marginal likelihood, posterior mean / variance / covariance.
+    log marginal likelihood, posterior mean / variance / covariance, and the gradient of logp
+    (finite differences of gpmm's own NLL).
   * The main Theano/PyMC3 path cannot be imported here (ModuleNotFoundError: theano,
     pymc3 -- an ordinary error, not a permission denial) and the reference ships no
     tests or golden vectors, so for everything else (MAT32/MAT52/RQ/periodic kernels,
-    warped GP, Gauss-Hermite, jitter schedule) the restatement is "parity unpinned" by
-    the reference and is pinned by analytic known-answer tests in tests/test_oracle.py.
+    warped GP, Gauss-Hermite, jitter schedule, Student-t process, transports) the restatement
+    is "parity unpinned" by the reference and is pinned by analytic known-answer tests in
+    tests/test_oracle.py (closed forms, limits, finite differences of logp for dlogp).
 
 dtype: the reference graph is hard-wired float32 (g3py/config.py:4,9) with the Cholesky
 done in float64 and cast back (g3py/libs/tensors.py:198,219).  `dtype=np.float64`
