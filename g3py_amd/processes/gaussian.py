@@ -106,16 +106,17 @@ class GaussianProcess(EllipticalProcess):
         if c.get('grad') is None:
             prog = self._prog(self.f_kernel_noise, values, d)
             gmap = dev.grad_layout(prog)
-            Y = dev.alloc(Np, Np, self.dtype)
-            Kinv = dev.alloc(Np, Np, self.dtype)
-            alpha = dev.alloc(1, Np, self.dtype)
+            ws = self._workspace                 # K^-1 workspaces live with the factor workspace (same data set)
+            if 'Y' not in ws:
+                ws['Y'], ws['Kinv'] = dev.alloc(Np, Np, self.dtype), dev.alloc(Np, Np, self.dtype)
+                ws['alpha'] = dev.alloc(1, Np, self.dtype)
+            Y, Kinv, alpha = ws['Y'], ws['Kinv'], ws['alpha']
             ad = c['ad']
             if s != 1.0:      # G = s alpha alpha^T - K^-1: hand the device sqrt(s) a, it returns sqrt(s) alpha
                 ad = dev.upload((dev.download(c['ad']) * np.sqrt(s)).astype(self.dtype))
             slots = dev.gp_dlogp(prog, gmap, c['Xd'], N, d, c['Kd'], c['Wd'], ad, Y, Kinv, alpha)
             c['grad'] = dict(prog=prog, gmap=gmap, slots=slots,
                              alpha=np.sqrt(s) * dev.download(alpha, 1, N)[0].astype(np.float64))
-            del Y, Kinv                                   # 2 N^2 of HBM: released as soon as the sums exist
         g = c['grad']
         prog, gmap, slots, alpha = g['prog'], g['gmap'], g['slots'], g['alpha']   # alpha = s K^-1 delta
         # kernel hypers: leaf parameter slots -> the HyperVars that fed them
