@@ -46,6 +46,18 @@ def _traffic():
         return None
 
 
+def _golden_logp(N, d, M, seed, kernel):
+    """logp of the CPU oracle at a full benchmark configuration, or None when it was never generated"""
+    try:
+        gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fullsize.json')))
+    except Exception:
+        return None
+    for g in gold.values():
+        if (g['N'], g['d'], g['M'], g['seed'], g['kernel']) == (N, d, M, seed, kernel):
+            return float(g['logp'])
+    return None
+
+
 def synth(N, d, M, seed):
     """SURVEY.md section 8(d)"""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -102,33 +114,56 @@ def main():
     ap.add_argument('--panel', dest='nb', type=int, default=0, help='row-block height of the multi-GPU distribution (0 = 1024 up to 4 GPUs, 512 beyond)')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` typed directly: start one FRESH child process per GPU through
+        # torch.distributed.run and exit with its status.  Nothing in this process has touched the GPU
+        # yet (torch is not even imported), and nothing is exec'ed: the ranks are ordinary children.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:      # checked before anything initialises the GPU
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torchrun --nproc-per-node %d, or '
+                         'run `python bench.py --gpus %d` and let it start the ranks)' % (args.gpus, world, args.gpus, args.gpus))
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     # one rank per GPU; G3_DIST_BACKEND=gloo (rehearsal of N>1 on a one-GPU box) lets ranks share a device
     backend = os.environ.get('G3_DIST_BACKEND', 'nccl')
-    local_rank = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if world > 1 and backend == 'nccl' and ndev < world:
+        raise SystemExit('bench.py: %d ranks over RCCL need %d GPUs, %d visible (G3_DIST_BACKEND=gloo rehearses '
+                         'several ranks on one GPU)' % (world, world, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
 
     tdev0 = torch.device('cuda', local_rank)
     import g3py_amd as g3
     from g3py_amd import _lib
     from g3py_amd.device import compile_spec
 
-    N, d, M, seed = args.n, args.d, args.m, 1004
+    # seed = 1000 + BASELINE config index (config 2: N=8192 SE, 3: MAT52+COS, 4: N=32768 SE, 5: fp32)
+    seed = 1005 if args.f32 else (1003 if args.kernel == 'mat52cos' else (1002 if args.n == 8192 else 1004))
+    N, d, M = args.n, args.d, args.m
     X, y, Xs = synth(N, d, M, seed)
     delta = y.copy()                      # Zero mean, identity mapping: delta = y
     if args.kernel == 'se':
@@ -272,9 +307,20 @@ def main():
         if world == 1 and args.cpu_n > 0:
             cb, lp_cpu = cpu_baseline(N, d, M, seed, min(args.cpu_n, N))
             out['cpu_baseline'] = cb
+        # full-size pin: the CPU oracle's logp at this exact configuration (tests/golden/fullsize.json,
+        # written once by oracle/gen_fullsize.py in the build container; data, not code)
+        ref = _golden_logp(N, d, M, seed, args.kernel) if not args.f32 else None
+        if ref is not None:
+            out['logp_ref'] = ref
+            out['logp_rel_err'] = abs(out['logp'] - ref) / abs(ref)
         print(json.dumps(out))
+        if ref is not None and not out['logp_rel_err'] <= 1e-8:
+            raise SystemExit('bench.py: logp %.12f differs from the oracle pin %.12f by more than 1e-8 relative'
+                             % (out['logp'], ref))
     if world > 1:
         dist.destroy_process_group()
+    # explicit teardown while the HIP runtime is alive (streams, events, pinned buffers, workspaces)
+    g3.Device.close_all()
 
 
 if __name__ == '__main__':

@@ -41,6 +41,7 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
 
 extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_info) (void)hipFree(ctx->d_info);
@@ -69,6 +70,7 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
 
 extern "C" int g3_ctx_set_stream(g3_ctx* ctx, void* s) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   G3_HIP(hipStreamSynchronize(ctx->stream));
   ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
   ctx->adopted = (s != nullptr);
@@ -78,6 +80,7 @@ extern "C" int g3_ctx_set_stream(g3_ctx* ctx, void* s) {
 // ----------------------------------------------------------------------------- profiling
 extern "C" int g3_prof_enable(g3_ctx* ctx, int on) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (on && !ctx->prof_ev) {
     ctx->prof_cap = 16384;
     ctx->prof_ev = (hipEvent_t*)calloc(ctx->prof_cap, sizeof(hipEvent_t));
@@ -91,6 +94,7 @@ extern "C" int g3_prof_enable(g3_ctx* ctx, int on) {
 }
 extern "C" int g3_prof_reset(g3_ctx* ctx) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   G3_HIP(hipStreamSynchronize(ctx->stream));
   ctx->prof_n = 0;
   ctx->prof_nrec = 0;
@@ -118,6 +122,7 @@ void g3i_prof_end(g3_ctx* ctx, int rec) {
 }
 extern "C" int g3_prof_collect(g3_ctx* ctx, double* out) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!out) return -2;
   G3_HIP(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 3 * G3_PROF_NTAGS; ++i) out[i] = 0.0;
@@ -134,6 +139,7 @@ extern "C" int g3_prof_collect(g3_ctx* ctx, double* out) {
 
 extern "C" int g3_ctx_sync(g3_ctx* ctx) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   G3_HIP(hipStreamSynchronize(ctx->stream));
   return G3_OK;
 }
@@ -142,6 +148,7 @@ extern "C" const char* g3_last_error(g3_ctx* ctx) { return ctx ? ctx->err : "nul
 
 extern "C" int g3_malloc(g3_ctx* ctx, size_t bytes, void** dev) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!dev) return -3;
   *dev = nullptr;
   if (bytes == 0) return G3_OK;
@@ -151,6 +158,7 @@ extern "C" int g3_malloc(g3_ctx* ctx, size_t bytes, void** dev) {
 }
 extern "C" int g3_free(g3_ctx* ctx, void* dev) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!dev) return G3_OK;
   G3_HIP(hipStreamSynchronize(ctx->stream));
   G3_HIP(hipFree(dev));
@@ -158,6 +166,7 @@ extern "C" int g3_free(g3_ctx* ctx, void* dev) {
 }
 extern "C" int g3_memcpy_h2d(g3_ctx* ctx, void* dev, const void* host, size_t bytes) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (bytes == 0) return G3_OK;
   if (!dev) return -2;
   if (!host) return -3;
@@ -167,6 +176,7 @@ extern "C" int g3_memcpy_h2d(g3_ctx* ctx, void* dev, const void* host, size_t by
 }
 extern "C" int g3_memcpy_d2h(g3_ctx* ctx, void* host, const void* dev, size_t bytes) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (bytes == 0) return G3_OK;
   if (!host) return -2;
   if (!dev) return -3;
@@ -176,6 +186,7 @@ extern "C" int g3_memcpy_d2h(g3_ctx* ctx, void* host, const void* dev, size_t by
 }
 extern "C" int g3_memcpy_d2d(g3_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (bytes == 0) return G3_OK;
   if (!dst) return -2;
   if (!src) return -3;
@@ -184,6 +195,7 @@ extern "C" int g3_memcpy_d2d(g3_ctx* ctx, void* dst, const void* src, size_t byt
 }
 extern "C" int g3_memset(g3_ctx* ctx, void* dev, int byte, size_t bytes) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (bytes == 0) return G3_OK;
   if (!dev) return -2;
   G3_HIP(hipMemsetAsync(dev, byte, bytes, ctx->stream));
@@ -192,6 +204,7 @@ extern "C" int g3_memset(g3_ctx* ctx, void* dev, int byte, size_t bytes) {
 extern "C" int g3_copy2d(g3_ctx* ctx, void* dst, int64_t ldd, const void* src, int64_t lds,
                          int64_t rows, int64_t cols, g3_dtype dt) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (rows == 0 || cols == 0) return G3_OK;
   if (!dst) return -2;
   if (!src) return -4;
@@ -357,6 +370,7 @@ static int diag_stats_launch(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dty
 
 extern "C" int g3_cov_lift(g3_ctx* ctx, void* K, int64_t n, int64_t ld, g3_dtype dt) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!K) return -2;
   if (n < 0) return -3;
   if (ld < n) return -4;
@@ -366,6 +380,7 @@ extern "C" int g3_cov_lift(g3_ctx* ctx, void* K, int64_t n, int64_t ld, g3_dtype
 
 extern "C" int g3_diag_stats(g3_ctx* ctx, const void* A, int64_t n, int64_t ld, g3_dtype dt, double out[3]) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!A) return -2;
   if (n <= 0) return -3;
   if (ld < n) return -4;
@@ -380,6 +395,7 @@ extern "C" int g3_diag_stats(g3_ctx* ctx, const void* A, int64_t n, int64_t ld, 
 
 extern "C" int g3_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!A) return -2;
   if (n < 0) return -3;
   if (ld < n) return -4;
@@ -395,6 +411,7 @@ extern "C" int g3_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype
 
 extern "C" int g3_scrub(g3_ctx* ctx, void* A, int64_t n1, int64_t n2, int64_t ld, g3_dtype dt) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!A) return -2;
   if (n1 < 0) return -3;
   if (n2 < 0) return -4;
@@ -423,6 +440,7 @@ static int logp_terms_launch(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, 
 extern "C" int g3_logp_terms(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const void* a,
                              g3_dtype dt, double out[4]) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!L) return -2;
   if (n <= 0) return -3;
   if (ld < n) return -4;
@@ -448,6 +466,7 @@ static int rows_dot_ss_launch(g3_ctx* ctx, const void* V, int64_t m, int64_t n, 
 extern "C" int g3_rows_dot_ss(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld,
                               const void* a, g3_dtype dt, void* dot, void* ss) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!V) return -2;
   if (m < 0) return -3;
   if (n < 0) return -4;
@@ -633,6 +652,7 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
                                     int64_t ldx, int d, const void* delta, int64_t ldd, g3_dtype dt, void* K,
                                     int64_t ldk, int64_t kstride, void* invd, void* a, double* out) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!progs) return -2;
   if (batch < 1 || batch > G3_MAX_BATCH) return -3;
   if (!X) return -4;
@@ -744,6 +764,7 @@ extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
                             int64_t ldx, int d, const void* delta, g3_dtype dt, void* K, int64_t ldk,
                             void* invd, void* a, double out[6]) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog) return -2;
   if (!X) return -3;
   if (N <= 0) return -4;
@@ -763,6 +784,7 @@ extern "C" int g3_gp_factor_predict(g3_ctx* ctx, const g3_kernel_prog* prog, con
                                     const void* Xs, int64_t M, int64_t ldxs, g3_dtype dt, void* K, int64_t ldk,
                                     void* invd, void* a, void* mu, void* ss, double out[6]) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog) return -2;
   if (!prog_cross) return -3;
   if (!X) return -4;
@@ -784,6 +806,7 @@ extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* 
                            int64_t ldl, const void* invd, const void* a, g3_dtype dt, void* V, int64_t ldv,
                            void* mu, void* ss) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog) return -2;
   if (!Xs) return -3;
   if (M <= 0) return -4;

@@ -26,11 +26,31 @@
 constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
 constexpr int GROUP_M = 4; // row-blocks per raster group
 
+// ---- tile raster.  The host describes the ACTIVE tiles of a launch as a list of row groups (a few
+// consecutive row tiles each) with a column-tile count per group; the table travels by value in the
+// kernel arguments.  This one mechanism covers dense products, lower-triangular / trapezoidal
+// updates of the factorisation (column count grows with the row, `diag_off` masks the elements above
+// the shifted diagonal) and the multi-GPU "staircase" (a rank's row blocks, each with its own
+// width, updated by ONE launch).  Tiles that are not wanted are never launched.
+constexpr int G3_RASTER_MAX = 160;
+constexpr int G3_DENSE_OFF = 1 << 30;
+struct RasterTab {
+  int ngroups;
+  int diag_off;                             // element (row, col) is wanted iff col <= row + diag_off
+  int prefix[G3_RASTER_MAX + 1];            // first virtual tile id of group g; prefix[ngroups] = grid size
+  unsigned short row0[G3_RASTER_MAX];       // first row tile of group g
+  unsigned char nrows[G3_RASTER_MAX];       // row tiles in group g (its tiles are ordered column-major)
+  // optional row-block permutation of B: logical block s (b_nb rows) lives at physical block
+  // b_blk[s] -- the gathered panel of the multi-GPU sweep arrives rank-major, not in global order
+  int b_nb;                                 // 0: B is in logical order
+  unsigned short b_blk[G3_RASTER_MAX];
+};
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
 gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
-               int K, T alpha, T beta, int lower_only, const int* __restrict__ info, int tiles_m, int tiles_n,
-               int64_t bsC, int64_t bsA, int64_t bsB) {
+               int K, T alpha, T beta, const int* __restrict__ info,
+               int64_t bsC, int64_t bsA, int64_t bsB, const RasterTab tab) {
   using M = MfmaT<T>;
   // batch member (grid.y); strides are 0 for a single product
   C += (int64_t)blockIdx.y * bsC;
@@ -48,53 +68,28 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   // ---- tile assignment: XCD-aware, grouped raster over the ACTIVE tiles only.
   // Workgroups are dealt round-robin over the 8 XCDs, so ids {x, x+8, ...} share an L2;
   // remap so that each XCD walks a contiguous range of "virtual" ids, and order virtual
-  // ids in groups of GROUP_M row-blocks, column-major inside a group: the ~32 tiles an XCD
-  // works on at any time then form a GROUP_M x 8 patch that shares 4 A panels and 8 B
-  // panels through its L2 instead of streaming 32 distinct B panels from HBM.
+  // ids group by group, column-major inside a group: the ~32 tiles an XCD works on at any
+  // time then form a (group height) x 8 patch that shares 4 A panels and 8 B panels through
+  // its L2 instead of streaming 32 distinct B panels from HBM.
   int bm, bn;
   {
     const int nwg = gridDim.x, id = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    // groups of GROUP_M row-blocks; group g has nc(g) active column-blocks
-    int g = 0, base = 0;
-    if (!lower_only) {
-      const int per = GROUP_M * tiles_n;
-      g = v / per;
-      base = g * per;
-    } else {
-      // nc(g) = min(tiles_n, RATIO * GROUP_M * (g + 1)), RATIO = BM / BN column tiles per row tile;
-      // quadratic prefix until saturation at g_sat, linear after
-      constexpr int RATIO = (BM >= BN) ? BM / BN : 1;
-      const int step = RATIO * GROUP_M;                       // nc grows by `step` per group
-      const int g_sat = (tiles_n + step - 1) / step - 1;      // first group with nc == tiles_n (maybe)
-      // prefix(g) = GROUP_M * step * g (g + 1) / 2 for g <= g_sat
-      const long long pre_sat = (long long)GROUP_M * step * g_sat * (g_sat + 1) / 2;
-      if (v < pre_sat) {
-        // solve GROUP_M*step*g(g+1)/2 <= v
-        const double a = 0.5 * GROUP_M * step;
-        g = (int)((-a + sqrt(a * a + 4.0 * a * (double)v)) / (2.0 * a));
-        while ((long long)GROUP_M * step * (g + 1) * (g + 2) / 2 <= v) ++g;
-        while ((long long)GROUP_M * step * g * (g + 1) / 2 > v) --g;
-        base = (int)((long long)GROUP_M * step * g * (g + 1) / 2);
-      } else {
-        const int per = GROUP_M * tiles_n;
-        g = g_sat + (int)((v - pre_sat) / per);
-        base = (int)(pre_sat + (long long)(g - g_sat) * per);
-      }
+    int lo = 0, hi = tab.ngroups;            // largest g with prefix[g] <= v  (prefix[0] = 0, v < prefix[ngroups])
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tab.prefix[mid] <= v) lo = mid; else hi = mid;
     }
-    const int w = v - base;                 // index inside the group, column-major
-    const int rows_in_group = min(GROUP_M, tiles_m - g * GROUP_M);
-    bn = w / GROUP_M;
-    bm = g * GROUP_M + (w - bn * GROUP_M);
-    if (rows_in_group < GROUP_M) {          // ragged last group: re-derive with its own height
-      bn = w / rows_in_group;
-      bm = g * GROUP_M + (w - bn * rows_in_group);
-    }
-    if (bm >= tiles_m || bn >= tiles_n) return;
+    const int w = v - tab.prefix[lo];
+    const int rows = (int)tab.nrows[lo];
+    bn = w / rows;
+    bm = (int)tab.row0[lo] + (w - bn * rows);
   }
+  const int doff = tab.diag_off;
+  const bool lower_only = doff < G3_DENSE_OFF;
   const int m0 = bm * BM, n0 = bn * BN;
-  if (lower_only && n0 >= m0 + BM) return;
+  if (lower_only && n0 > m0 + BM - 1 + doff) return;    // a tile of a group above its own row's limit
   if (info != nullptr && *info != 0) return;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +113,12 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   constexpr int NW = NT / 64;
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "rows per wave-instruction");
   const T* gA = A + (int64_t)m0 * lda;
-  const T* gB = B + (int64_t)n0 * ldb;
+  int64_t brow = n0;
+  if (tab.b_nb > 0) {
+    const int sblk = n0 / tab.b_nb;
+    brow = (int64_t)tab.b_blk[sblk] * tab.b_nb + (n0 - sblk * tab.b_nb);
+  }
+  const T* gB = B + brow * ldb;
   const int sr = lane >> 3, sc = lane & 7;
   auto stage = [&](int buf, int k0) {
     char* a = sA + buf * BM * ROWB;
@@ -186,7 +186,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     for (int p = 0; p < NPASS; ++p) {
       const int row = m0 + c * RC + p * RPP + vrow, col = n0 + vcol;
       cnext[p] = chunk_t{};
-      if (!(lower_only && col > row)) cnext[p] = *reinterpret_cast<const chunk_t*>(C + (int64_t)row * ldc + col);
+      if (!(lower_only && col > row + doff)) cnext[p] = *reinterpret_cast<const chunk_t*>(C + (int64_t)row * ldc + col);
     }
   };
   for (int kt = 0; kt < KT; ++kt) {
@@ -232,17 +232,17 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
       for (int p = 0; p < NPASS; ++p) {
         const int rl = p * RPP + vrow;
         const int row = m0 + c * RC + rl, col = n0 + vcol;
-        if (lower_only && col > row) continue;
+        if (lower_only && col > row + doff) continue;
         chunk_t v = *reinterpret_cast<const chunk_t*>(smem + rl * PITCH + vcol * (int)sizeof(T));
         v = v * alpha;
         if (rmw) v = v + cold[p] * beta;
         T* dst = C + (int64_t)row * ldc + col;
-        if (!lower_only || col + EPC - 1 <= row) {
+        if (!lower_only || col + EPC - 1 <= row + doff) {
           *reinterpret_cast<chunk_t*>(dst) = v;
         } else {                                           // the vector straddles the diagonal
 #pragma unroll
           for (int e = 0; e < EPC; ++e)
-            if (col + e <= row) dst[e] = v[e];
+            if (col + e <= row + doff) dst[e] = v[e];
         }
       }
       __syncthreads();
@@ -259,7 +259,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm + i * 16 + M::row(lane, r);
-        if (lower_only && col > row) continue;
+        if (lower_only && col > row + doff) continue;
         T* p = C + (int64_t)row * ldc + col;
         T v = alpha * acc[i][j][r];
         if (beta != T(0)) v += beta * (*p);
@@ -268,99 +268,195 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     }
 }
 
+// ---- host side: which elements of C a launch produces
+struct GemmShape {
+  int kind;                 // 0 dense, 1 trapezoid (col <= row + off), 2 staircase (row segments with own widths)
+  int64_t m, n;             // extent of C in elements (staircase: m = sum of segment rows, n = widest segment)
+  int64_t off;              // trapezoid: diagonal offset in elements
+  int nseg;                 // staircase
+  const int64_t* seg_rows;
+  const int64_t* seg_cols;
+  int64_t b_nb;             // rows per permuted block of B (0: none)
+  const int32_t* b_perm;    // physical block of logical block s
+  int nperm;
+};
+
+static double shape_elems(const GemmShape& sh) {
+  if (sh.kind == 0) return (double)sh.m * (double)sh.n;
+  if (sh.kind == 2) {
+    double e = 0;
+    for (int s = 0; s < sh.nseg; ++s) e += (double)sh.seg_rows[s] * (double)sh.seg_cols[s];
+    return e;
+  }
+  // sum_{i < m} clamp(i + off + 1, 0, n)
+  int64_t i0 = sh.off < 0 ? -sh.off : 0;           // first row with a wanted element: i + off + 1 >= 1
+  if (i0 > sh.m) i0 = sh.m;
+  int64_t i1 = sh.n - 1 - sh.off;                  // first row that is full width
+  if (i1 < i0) i1 = i0;
+  if (i1 > sh.m) i1 = sh.m;
+  const double cnt = (double)(i1 - i0);
+  const double tri = cnt * ((double)i0 + (double)sh.off + 1.0) + 0.5 * cnt * (cnt - 1.0);
+  return tri + (double)(sh.m - i1) * (double)sh.n;
+}
+
+// Build the raster table for BM x BN tiles.  Returns the grid size, or -1 when the launch needs more
+// than G3_RASTER_MAX groups (staircases with very many segments: the caller splits the launch).
+template <int BM, int BN>
+static long long build_raster(const GemmShape& sh, RasterTab* tab) {
+  const int64_t tiles_m = sh.m / BM;
+  tab->diag_off = sh.kind == 1 ? (int)sh.off : G3_DENSE_OFF;
+  int ng = 0;
+  long long total = 0;
+  auto push = [&](int64_t row_tile0, int64_t rows, int64_t nc) -> bool {
+    if (rows <= 0 || nc <= 0) return true;
+    if (ng >= G3_RASTER_MAX) return false;
+    tab->prefix[ng] = (int)total;
+    tab->row0[ng] = (unsigned short)row_tile0;
+    tab->nrows[ng] = (unsigned char)rows;
+    total += rows * nc;
+    ++ng;
+    return true;
+  };
+  if (sh.kind == 2) {
+    int64_t rt = 0;
+    // group height: GROUP_M row tiles unless that needs too many groups
+    int64_t ngroups_min = 0;
+    for (int s = 0; s < sh.nseg; ++s) ngroups_min += (sh.seg_rows[s] / BM + GROUP_M - 1) / GROUP_M;
+    const int64_t gh = ngroups_min <= G3_RASTER_MAX ? GROUP_M : GROUP_M * ((ngroups_min + G3_RASTER_MAX - 1) / G3_RASTER_MAX + 1);
+    for (int s = 0; s < sh.nseg; ++s) {
+      const int64_t st = sh.seg_rows[s] / BM, nc = sh.seg_cols[s] / BN;
+      for (int64_t t = 0; t < st; t += gh) {
+        // groups never span segments; a group's row tiles are consecutive, so an empty segment in
+        // between simply starts a new group
+        if (!push(rt + t, (st - t < gh ? st - t : gh), nc)) return -1;
+      }
+      rt += st;
+    }
+  } else {
+    const int64_t tiles_n = sh.n / BN;
+    int64_t gh = GROUP_M;
+    if ((tiles_m + gh - 1) / gh > G3_RASTER_MAX) gh = (tiles_m + G3_RASTER_MAX - 1) / G3_RASTER_MAX;
+    if (gh > 255) return -1;
+    for (int64_t t = 0; t < tiles_m; t += gh) {
+      const int64_t rows = tiles_m - t < gh ? tiles_m - t : gh;
+      int64_t nc = tiles_n;
+      if (sh.kind == 1) {
+        const int64_t lim = (t + rows) * BM - 1 + sh.off;   // last wanted column of the group's last row
+        nc = lim < 0 ? 0 : lim / BN + 1;
+        if (nc > tiles_n) nc = tiles_n;
+      }
+      if (!push(t, rows, nc)) return -1;
+    }
+  }
+  tab->ngroups = ng;
+  tab->prefix[ng] = (int)total;
+  tab->b_nb = 0;
+  if (sh.b_nb > 0 && sh.b_perm) {
+    if (sh.nperm > G3_RASTER_MAX || sh.b_nb % BN) return -1;
+    tab->b_nb = (int)sh.b_nb;
+    for (int i = 0; i < sh.nperm; ++i) tab->b_blk[i] = (unsigned short)sh.b_perm[i];
+  }
+  return total;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
-                      int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
-                      int lower_only) {
+                      int64_t ldb, int64_t k, double alpha, double beta, const GemmShape& sh) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int LDS = 2 * (BM + BN) * ROWB;
   auto kern = gemm_nt_kernel<T, BM, BN, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute belongs to the (function, device) pair: cached per device.  Setting it twice from
+  // two threads is harmless (same value), so the flag needs no lock.
+  static bool attr_set[G3_MAX_DEVICES] = {};
+  const int dev_slot = ctx->device & (G3_MAX_DEVICES - 1);
+  if (!attr_set[dev_slot]) {
     G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
+    attr_set[dev_slot] = true;
   }
-  // number of virtual tile ids (see the kernel's raster): groups of GROUP_M row-blocks, each
-  // with nc(g) column-blocks; the last group may be ragged
-  const int tiles_m = (int)(m / BM), tiles_n = (int)(n / BN);
-  long long nv = 0;
-  {
-    constexpr int RATIO = (BM >= BN) ? BM / BN : 1;
-    const int ngroups = (tiles_m + GROUP_M - 1) / GROUP_M;
-    for (int g = 0; g < ngroups; ++g) {
-      const int rows = (g == ngroups - 1) ? tiles_m - g * GROUP_M : GROUP_M;
-      long long nc = tiles_n;
-      if (lower_only) {
-        const long long lim = (long long)RATIO * GROUP_M * (g + 1);
-        if (lim < nc) nc = lim;
-      }
-      // the kernel's prefix formula assumes full groups except the last one
-      nv += (g == ngroups - 1) ? (long long)rows * nc : (long long)GROUP_M * nc;
-    }
+  RasterTab tab;
+  const long long nv = build_raster<BM, BN>(sh, &tab);
+  if (nv < 0) {
+    snprintf(ctx->err, sizeof(ctx->err), "GEMM raster needs more than %d row groups", G3_RASTER_MAX);
+    return G3_ERR_HIP;
   }
+  if (nv == 0) return G3_OK;
   dim3 grid((unsigned)nv, (unsigned)g3_nbatch(ctx));
   // algorithmic flops: 2 k per output element that is wanted.  Profiling
   // tag: launches of the 128 x 128 tile with >= 1024 tiles are the bulk panel updates
   const int tag = (BM == 128 && BN == 128) ? (nv >= 1024 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
-  // lower-only: 2k flops for every element on or below the diagonal (m >= n: m n - n(n-1)/2 of them)
-  const double elems = lower_only ? ((double)m * n - 0.5 * (double)n * (n - 1) - (m < n ? 0.5 * (double)(n - m) * (n - m + 1) : 0.0))
-                                  : (double)m * n;
-  const int pr = g3i_prof_begin(ctx, tag, 2.0 * elems * (double)k);
+  const int pr = g3i_prof_begin(ctx, tag, 2.0 * shape_elems(sh) * (double)k);
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, ctx->stream, (T*)C, ldc, (const T*)A, lda,
-                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, lower_only, ctx->d_info, tiles_m, tiles_n,
-                     g3_bstride_of(ctx, C), g3_bstride_of(ctx, A), g3_bstride_of(ctx, B));
+                     (const T*)B, ldb, (int)k, (T)alpha, (T)beta, ctx->d_info,
+                     g3_bstride_of(ctx, C), g3_bstride_of(ctx, A), g3_bstride_of(ctx, B), tab);
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
 
+// smallest number of 128 x 128 tiles for which the big tile is chosen (G3_GEMM_BIG_MIN overrides)
+static int64_t big_tile_min() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("G3_GEMM_BIG_MIN");
+    v = e ? atoll(e) : 4096;
+  }
+  return v;
+}
+
 template <typename T>
 static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
-                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
-                    int lower_only, int wide) {
+                    int64_t ldb, int64_t k, double alpha, double beta, const GemmShape& sh, int wide) {
   // tile choice: big tiles when they still fill the chip, small tiles for the narrow
   // panel / leaf operations on the critical path of the factorisation
-  const int64_t blocks128 = (m / 128) * (n / 128) / (lower_only ? 2 : 1) * g3_nbatch(ctx);
+  const int64_t blocks128 = (int64_t)(shape_elems(sh) / (128.0 * 128.0)) * g3_nbatch(ctx);
+  bool all128 = sh.m % 128 == 0 && sh.n % 128 == 0;
+  if (sh.kind == 2)
+    for (int s = 0; s < sh.nseg; ++s) all128 = all128 && sh.seg_rows[s] % 128 == 0 && sh.seg_cols[s] % 128 == 0;
   static int forced = -1;   // G3_GEMM_CFG: development override of the tile choice
   if (forced < 0) {
     const char* e = getenv("G3_GEMM_CFG");
     forced = e ? atoi(e) : 0;
   }
-  if (forced == 1 && m % 256 == 0 && n % 128 == 0)
-    return launch_cfg<T, 256, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  if (forced == 2 && m % 128 == 0 && n % 128 == 0)
-    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  if (forced == 4 && n % 128 == 0)
-    return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (forced == 1 && sh.kind != 2 && sh.m % 256 == 0 && sh.n % 128 == 0)
+    return launch_cfg<T, 256, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 2 && all128)
+    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 4 && sh.kind != 2 && sh.n % 128 == 0)
+    return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   // Tile choice (measured on MI355X, scripts/gemm_bench.py):
   //  * in-place panel solves (`wide`, C aliases A, n = 128): thin 32 x 128 tiles always -- one
   //    tile must span the 128 output columns, and 4x more workgroups beat 128 x 128 tiles from
   //    m = 1024 (13 vs 32 us) to m = 31744 (34 vs 45 us);
-  //  * >= 4096 tiles of 128 x 128: the big tile (two blocks per CU, 65-68 TFLOP/s);
+  //  * >= big_tile_min() tiles of 128 x 128: the big tile (two blocks per CU, 65-68 TFLOP/s);
   //  * everything in between: 64 x 64 tiles -- finer work quanta balance better over the 256 CUs
   //    (lower SYRK 4096^2 x 1024: 51 vs 40 TFLOP/s; 2048 x 1024 x 1024: 50 vs 27).
   // (a 256 x 128 tile, one block per CU, was 4-5 % slower than 128 x 128 everywhere.)
   if (wide) {
-    if (n % 128 == 0 && m % 32 == 0)
-      return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+    if (sh.kind == 0 && sh.n % 128 == 0 && sh.m % 32 == 0)
+      return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
     snprintf(ctx->err, sizeof(ctx->err), "in-place panel GEMM needs n %% 128 == 0 and m %% 32 == 0 (m=%lld n=%lld)",
-             (long long)m, (long long)n);
+             (long long)sh.m, (long long)sh.n);
     return G3_ERR_HIP;
   }
-  if (m % 128 == 0 && n % 128 == 0 && blocks128 >= 4096)
-    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
-  return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only);
+  if (all128 && blocks128 >= big_tile_min())
+    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+}
+
+static int launch_dt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                     int64_t ldb, int64_t k, double alpha, double beta, g3_dtype dt, const GemmShape& sh, int wide) {
+  if (dt == G3_F64) return launch_t<double>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh, wide);
+  return launch_t<float>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh, wide);
 }
 
 int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                    g3_dtype dt, int lower_only, int wide) {
   if (m == 0 || n == 0) return G3_OK;
-  if (dt == G3_F64)
-    return launch_t<double>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only, wide);
-  return launch_t<float>(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, lower_only, wide);
+  const GemmShape sh{lower_only ? 1 : 0, m, n, 0, 0, nullptr, nullptr, 0, nullptr, 0};
+  return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, wide);
 }
 
 int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
@@ -369,10 +465,35 @@ int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, c
   return g3i_gemm_nt_ex(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, dt, lower_only, 0);
 }
 
+// trapezoid: only elements with col <= row + diag_off are produced (diag_off = 0: lower triangle
+// of a C whose top-left corner lies on the diagonal; > 0: C starts diag_off columns left of it)
+int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                     int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                     g3_dtype dt, int64_t diag_off) {
+  if (m == 0 || n == 0) return G3_OK;
+  const GemmShape sh{1, m, n, diag_off, 0, nullptr, nullptr, 0, nullptr, 0};
+  return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
+}
+
+// staircase: row segment s (seg_rows[s] rows, stacked) gets its first seg_cols[s] columns
+int g3i_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                      int64_t ldb, int64_t k, const int64_t* seg_rows, const int64_t* seg_cols, int nseg,
+                      double alpha, double beta, g3_dtype dt, int64_t b_nb, const int32_t* b_perm, int nperm) {
+  int64_t m = 0, n = 0;
+  for (int s = 0; s < nseg; ++s) {
+    m += seg_rows[s];
+    if (seg_cols[s] > n) n = seg_cols[s];
+  }
+  if (m == 0 || n == 0) return G3_OK;
+  const GemmShape sh{2, m, n, 0, nseg, seg_rows, seg_cols, b_nb, b_perm, nperm};
+  return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
+}
+
 extern "C" int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
                           const void* B, int64_t ldb, int64_t m, int64_t n, int64_t k,
                           double alpha, double beta, g3_dtype dt, int lower_only) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!C) return -2;
   if (!A) return -4;
   if (!B) return -6;
@@ -392,4 +513,43 @@ extern "C" int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int6
   int rc = g3i_reset_info(ctx);
   if (rc) return rc;
   return g3i_gemm_nt(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, dt, lower_only);
+}
+
+extern "C" int g3_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
+                                const void* B, int64_t ldb, int64_t k, const int64_t* seg_rows,
+                                const int64_t* seg_cols, int nseg, double alpha, double beta, g3_dtype dt,
+                                int64_t b_block_rows, const int32_t* b_perm, int nperm) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!C) return -2;
+  if (!A) return -4;
+  if (!B) return -6;
+  if (!seg_rows) return -9;
+  if (!seg_cols) return -10;
+  if (nseg < 0 || nseg > 4096) return -11;
+  const int64_t bk = ROWB / (int64_t)g3_esize(dt);
+  if (k <= 0 || k % bk) return -8;
+  const int64_t al = 16 / (int64_t)g3_esize(dt);
+  int64_t m = 0, n = 0;
+  for (int s = 0; s < nseg; ++s) {
+    if (seg_rows[s] < 0 || seg_rows[s] % 128) return -9;
+    if (seg_cols[s] < 0 || seg_cols[s] % 128) return -10;
+    m += seg_rows[s];
+    if (seg_cols[s] > n) n = seg_cols[s];
+  }
+  if (m >= 65535 * 64) return -9;
+  if (b_perm) {
+    if (b_block_rows <= 0 || b_block_rows % 128) return -15;
+    if (nperm * b_block_rows < n || nperm > G3_RASTER_MAX) return -17;
+    for (int i = 0; i < nperm; ++i)
+      if (b_perm[i] < 0 || b_perm[i] > 65535) return -16;
+  }
+  if (ldc < n) return -3;
+  if (lda < k || lda % al) return -5;
+  if (ldb < k || ldb % al) return -7;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return -4;
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  return g3i_gemm_nt_stair(ctx, C, ldc, A, lda, B, ldb, k, seg_rows, seg_cols, nseg, alpha, beta, dt,
+                           b_perm ? b_block_rows : 0, b_perm, b_perm ? nperm : 0);
 }

@@ -125,6 +125,7 @@ int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* in
 extern "C" int g3_potri(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, const void* invd_dev, g3_dtype dt,
                         void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!L_dev) return -2;
   if (n < 0 || n % G3_LB) return -3;
   const int64_t al = 16 / (int64_t)g3_esize(dt);
@@ -701,6 +702,7 @@ extern "C" int g3_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_gr
                             int64_t N, int64_t ldx, int d, g3_dtype dt, const void* G_dev, int64_t ldg,
                             const void* alpha_dev, double* out_host) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog || prog->nleaf < 0 || prog->nleaf > G3_MAXLEAF || prog->nprod < 0 || prog->nprod > G3_MAXPROD) return -2;
   if (!map || check_map(prog, map)) return -3;
   if (!X_dev && N > 0) return -4;
@@ -720,6 +722,7 @@ extern "C" int g3_gp_dlogp(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_gra
                            const void* a_dev, g3_dtype dt, void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc,
                            void* alpha_dev, double* out_host) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog || prog->nleaf < 0 || prog->nleaf > G3_MAXLEAF || prog->nprod < 0 || prog->nprod > G3_MAXPROD) return -2;
   if (!map || check_map(prog, map)) return -3;
   if (!X_dev) return -4;

@@ -464,6 +464,7 @@ extern "C" int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X1, 
                        const void* X2, int64_t n2, int64_t ldx2, int d, g3_dtype dt, void* K, int64_t ldk,
                        int64_t n1pad, int64_t n2pad, unsigned flags) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog) return -2;
   if (!X1) return -3;
   if (n1 < 0) return -4;
@@ -493,6 +494,7 @@ extern "C" int g3_gram(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X1, 
 extern "C" int g3_gram_rows(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N, int64_t ldx, int d,
                             int64_t row0, int64_t nrows, g3_dtype dt, void* K, int64_t ldk, unsigned flags) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog) return -2;
   if (!X) return -3;
   if (N < 0) return -4;
@@ -524,6 +526,7 @@ extern "C" int g3_gram_rows(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
 extern "C" int g3_gram_diag(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t n, int64_t ldx,
                             int d, g3_dtype dt, void* diag) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!prog) return -2;
   if (!X) return -3;
   if (n < 0) return -4;

@@ -80,6 +80,23 @@ void g3i_prof_end(g3_ctx* ctx, int rec);
     }                                                                                         \
   } while (0)
 
+// Every extern "C" entry runs with the context's device current and restores the caller's device
+// on return, so contexts on different GPUs can be used from one process (one thread per context).
+struct g3_dev_guard {
+  int prev = -1;
+  bool switched = false;
+  explicit g3_dev_guard(const g3_ctx* ctx) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != ctx->device) switched = (hipSetDevice(ctx->device) == hipSuccess);
+  }
+  ~g3_dev_guard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  g3_dev_guard(const g3_dev_guard&) = delete;
+  g3_dev_guard& operator=(const g3_dev_guard&) = delete;
+};
+#define G3_MAX_DEVICES 64   // per-device caches of function attributes
+
 #define G3_MAX_BATCH 4096
 static inline int g3_nbatch(const g3_ctx* ctx) { return ctx->batch > 1 ? ctx->batch : 1; }
 // element stride between batch members for an operand at p (0 outside batch mode)
@@ -100,6 +117,14 @@ int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, c
 int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                    g3_dtype dt, int lower_only, int wide);
+// only elements with col <= row + diag_off (trapezoid; 0 = lower triangle of a diagonal-anchored C)
+int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                     int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                     g3_dtype dt, int64_t diag_off);
+// staircase: stacked row segments, segment s updates its first seg_cols[s] columns (one launch)
+int g3i_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
+                      int64_t ldb, int64_t k, const int64_t* seg_rows, const int64_t* seg_cols, int nseg,
+                      double alpha, double beta, g3_dtype dt, int64_t b_nb, const int32_t* b_perm, int nperm);
 int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd);
 int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd, int64_t E);
 int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,

@@ -640,6 +640,7 @@ static int read_info(g3_ctx* ctx, int* info_host) {
 extern "C" int g3_potrf(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt,
                         void* invd_dev, int* info_host) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!A_dev) return -2;
   if (n < 0 || n % G3_LB) return -3;
   if (ld < n || ld % (16 / (int64_t)g3_esize(dt))) return -4;
@@ -664,6 +665,7 @@ __global__ void info_merge_kernel(const int* info, int* accum) {
 extern "C" int g3_potrf_nowait(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, g3_dtype dt, void* invd_dev,
                                int* info_accum_dev) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!A_dev) return -2;
   if (n < 0 || n % G3_LB) return -3;
   if (ld < n || ld % (16 / (int64_t)g3_esize(dt))) return -4;
@@ -679,6 +681,7 @@ extern "C" int g3_potrf_nowait(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, 
 extern "C" int g3_trsm_rlt(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, void* B_dev,
                            int64_t m, int64_t ldb, g3_dtype dt, const void* invd_dev) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!L_dev) return -2;
   if (n < 0 || n % G3_LB) return -3;
   const int64_t al = 16 / (int64_t)g3_esize(dt);
@@ -818,6 +821,7 @@ extern "C" int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void
                                int64_t n, g3_dtype dt, int maxtries, int* tries_host,
                                int* fallback_host, double* jitter_host) {
   if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
   if (!K_dev) return -2;
   if (ldk < n) return -3;
   if (!L_dev) return -4;

@@ -2,7 +2,10 @@
 
 Nothing here computes on the CPU: every numerical routine is a call into libg3hip.so.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import numpy as np
 
@@ -26,6 +29,8 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.owned = owned
         self._keep = keep
+        if owned and self.ptr:
+            dev._owned.add(self)
 
     @property
     def nbytes(self):
@@ -35,11 +40,17 @@ class DeviceArray:
         return self.ptr + (row * self.ld + col) * self.dtype.itemsize
 
     def free(self):
-        if self.owned and self.ptr:
+        """hipFree an owned buffer; a no-op once the context is closed (Device.close() has already
+        released everything the context owned, and nothing may call into HIP after that)"""
+        if self.owned and self.ptr and self.dev.ctx:
             self.dev.lib.g3_free(self.dev.ctx, self.ptr)
         self.ptr = 0
 
     def __del__(self):
+        # never call into the HIP runtime from interpreter finalisation: by then the runtime (or a
+        # profiler tool library layered over it) may already be shutting down
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.free()
         except Exception:
@@ -49,8 +60,11 @@ class DeviceArray:
 class Device:
     """One g3_ctx on one GPU.  Raises if the library or the GPU is missing."""
     _default = {}
+    _live = weakref.WeakSet()      # every open context, closed by the atexit hook below
 
     def __init__(self, index=0):
+        self.ctx = None
+        self._owned = weakref.WeakSet()
         self.lib = _lib.load()
         h = C.c_void_p()
         rc = self.lib.g3_ctx_create(int(index), C.byref(h))
@@ -59,6 +73,7 @@ class Device:
                           'g3py_amd has no CPU fallback' % (index, rc))
         self.ctx = h
         self.index = index
+        Device._live.add(self)
 
     @classmethod
     def default(cls, index=0):
@@ -67,9 +82,44 @@ class Device:
         return cls._default[index]
 
     def close(self):
-        if self.ctx:
-            self.lib.g3_ctx_destroy(self.ctx)
-            self.ctx = None
+        """Release everything the context owns -- device buffers handed out by alloc()/upload(), the
+        library's streams, events, pinned mirrors and workspaces -- while the HIP runtime is alive.
+        Idempotent; afterwards DeviceArray.free() is a no-op and any other call raises."""
+        if not self.ctx:
+            return
+        try:
+            self.lib.g3_ctx_sync(self.ctx)
+        except Exception:
+            pass
+        for a in list(self._owned):
+            try:
+                a.free()
+            except Exception:
+                pass
+        self.lib.g3_ctx_destroy(self.ctx)
+        self.ctx = None
+        Device._live.discard(self)
+        for k in [k for k, v in Device._default.items() if v is self]:
+            del Device._default[k]
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def close_all(cls):
+        """explicit teardown of every live context (registered with atexit: Python's exit hooks run
+        before the C runtime's static destructors, i.e. while HIP and any profiler tool are intact)"""
+        for d in list(cls._live):
+            try:
+                d.close()
+            except Exception:
+                pass
+        cls._default.clear()
 
     def set_stream(self, stream_handle):
         _check(self, self.lib.g3_ctx_set_stream(self.ctx, stream_handle), 'g3_ctx_set_stream')
@@ -164,6 +214,21 @@ class Device:
         rc = self.lib.g3_gemm_nt(self.ctx, Cm.ptr + c_off, Cm.ld, A.ptr + a_off, A.ld, B.ptr + b_off, B.ld,
                                  m, n, k, alpha, beta, _lib.dtype_code(Cm.dtype), int(lower_only))
         _check(self, rc, 'g3_gemm_nt')
+
+    def gemm_nt_stair(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, k, seg_rows, seg_cols, dtype, alpha=1.0, beta=0.0,
+                      b_block_rows=0, b_perm=None):
+        """one launch over stacked row segments: segment s gets its first seg_cols[s] columns;
+        b_perm[s] = physical position of logical row block s of B (blocks of b_block_rows rows)"""
+        n = len(seg_rows)
+        rows = (C.c_int64 * n)(*[int(v) for v in seg_rows])
+        cols = (C.c_int64 * n)(*[int(v) for v in seg_cols])
+        perm, nperm = None, 0
+        if b_perm is not None:
+            nperm = len(b_perm)
+            perm = (C.c_int32 * nperm)(*[int(v) for v in b_perm])
+        rc = self.lib.g3_gemm_nt_stair(self.ctx, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, k, rows, cols, n, alpha, beta,
+                                       _lib.dtype_code(dtype), int(b_block_rows), perm, nperm)
+        _check(self, rc, 'g3_gemm_nt_stair')
 
     def potrf(self, A, n):
         info = C.c_int(0)
@@ -263,6 +328,9 @@ class Device:
                                   a.ptr, _lib.dtype_code(L.dtype), Y.ptr, Y.ld, Kinv.ptr, Kinv.ld, alpha.ptr, out)
         _check(self, rc, 'g3_gp_dlogp')
         return np.array(out[:gmap.nslots])
+
+
+atexit.register(Device.close_all)
 
 
 # --------------------------------------------------------------------------- kernel programs

@@ -23,7 +23,10 @@ once.  Per step k:
   3. look-ahead: the owner of block k+1 already has the rows it needs -- it updates its diagonal
      block with its own panel rows, factors it and broadcasts the nb x nb factor (+ the inverses of
      its 128 x 128 diagonal blocks) while the all-gather is in flight
-  4. every rank: trailing update of its own row blocks with the gathered panel (MFMA GEMMs)
+  4. every rank: trailing update of ALL its row blocks and right-hand-side rows with the gathered
+     panel in ONE staircase MFMA-GEMM launch (g3_gemm_nt_stair: each row block has its own width,
+     and the rank-major order of the gathered panel is a block table of the B operand -- no
+     re-ordering copy)
 
 Gram: every rank builds exactly its own rows from the replicated N x d input: no communication.
 Scalars (log det, a^T a, posterior mean / variance pieces): one broadcast of a = L^-1 delta and
@@ -157,6 +160,45 @@ class HipPanelOps:
             self.dev.gemm_nt(self._w(C_, m, n), self._w(A, m, k), self._w(B, n, k), m, n, k, alpha=-1.0, beta=1.0,
                              lower_only=lower_only)
 
+    def gemm_sub_stair(self, C_, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None):
+        """stacked row segments of C: C[rows_s, :seg_cols[s]] -= A[rows_s, :k] B[:seg_cols[s], :k]^T in one launch;
+        logical row block s of B (b_block_rows rows) is stored at block b_perm[s]"""
+        if sum(seg_rows) > 0 and max(seg_cols) > 0:
+            self.dev.gemm_nt_stair(C_.data_ptr(), C_.stride(0), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), k,
+                                   seg_rows, seg_cols, self.dtype, alpha=-1.0, beta=1.0,
+                                   b_block_rows=b_block_rows, b_perm=b_perm)
+
+    def fill_zero(self, t):
+        t.zero_()
+
+    def scale_cols(self, t, n, factor):
+        """t[:, :n] *= factor (the 1e-10 * I fallback solves its right-hand sides by a division)"""
+        t[:, :n].mul_(factor)
+
+    def gram_block(self, out, Xa, ma, Xb, mb, spec, scrub=True):
+        """out[ma x >= mb] <- tt_to_num(K(Xa[:ma], Xb[:mb])) (cross semantics: no noise term)"""
+        d = Xa.shape[1]
+        prog = self._compile(spec, d)
+        xa = self.dev.wrap(Xa.data_ptr(), ma, d, Xa.stride(0), self.dtype, keep=Xa)
+        xb = self.dev.wrap(Xb.data_ptr(), mb, d, Xb.stride(0), self.dtype, keep=Xb)
+        self.dev.gram(prog, xa, xb, d, self._w(out), ma, mb, self._lib.G3_GRAM_SCRUB if scrub else 0)
+
+    def chol_draws(self, cov, M, loc, Z):
+        """cholesky_robust of the M x M covariance (tensors.py:197-222) and loc + L Z  (gaussian.py:92-95);
+        cov is a padded device matrix, Z an M x S host array; returns (draws M x S, tries, fallback)"""
+        torch = self.torch
+        Mp = cov.shape[0]
+        S = Z.shape[1]
+        Sp = (S + 63) // 64 * 64
+        L = self.zeros(Mp, Mp)
+        tries, fb, _ = self.dev.potrf_robust(self._w(cov, M, M), self._w(L, M, M), M)
+        Zt = self.zeros(Sp, Mp)
+        Zt[:S, :M] = torch.from_numpy(np.ascontiguousarray(np.asarray(Z, dtype=self.dtype).T)).to(self.device)
+        out = self.zeros(Mp, Sp)
+        self.dev.gemm_nt(self._w(out), self._w(L), self._w(Zt), Mp, Sp, Mp)
+        d = out[:M, :S].double().cpu().numpy()
+        return np.asarray(loc, dtype=np.float64)[:, None] + d, tries, fb
+
     def logdet_block(self, D, nv):
         """sum of log of the first nv diagonal entries"""
         if nv <= 0:
@@ -213,8 +255,8 @@ class DistributedGP:
         return r if r < P else 2 * P - 1 - r
 
     def _perm(self, k):
-        """index tensor that puts the all-gathered panel blocks of step k into global block order:
-        entry s (global block k + 1 + s) = position of that block in the rank-major gather buffer"""
+        """(blocks per rank in the padded gather of step k, block table): entry s of the table (global
+        block k + 1 + s) = position of that block in the rank-major gather buffer"""
         if k not in self._perms:
             P = self.world
             nbelow = self.nblk - 1 - k
@@ -226,8 +268,7 @@ class DistributedGP:
                 q = self.owner(I)
                 idx.append(q * cnt + seen[q])
                 seen[q] += 1
-            t = self.torch.tensor(idx, dtype=self.torch.int64)
-            self._perms[k] = (cnt, t.to(self.A.device) if self.A.is_cuda else t)
+            self._perms[k] = (cnt, idx)
         return self._perms[k]
 
     def _LW(self, k):
@@ -345,19 +386,18 @@ class DistributedGP:
                         work_b = self._bcast(self.dbuf[(k + 1) % 2], self.owner(k + 1), async_op=True)
                 else:
                     work_b = self._bcast(self.dbuf[(k + 1) % 2], self.owner(k + 1), async_op=True)
-            # 4. trailing update with the gathered panel in global block order
+            # 4. trailing update: ONE staircase launch over every row block this rank owns below block
+            #    k + 1 (block I is (I - k) nb wide) and its right-hand-side rows (full width); the
+            #    gathered panel stays rank-major, `perm` tells the GEMM where logical block s lives
             if nbelow > 0:
                 self._wait(work_g)
-                G = self.gath[:P * cnt * nb].view(P * cnt, nb * nb)
-                G = G.index_select(0, perm).view(nbelow * nb, nb)   # block s <-> global block k + 1 + s
-                for I in self.my_blocks:
-                    if I >= k + 2:
-                        lo = self.loff[I]
-                        n = (I - k) * nb
-                        o.gemm_sub(A[lo:lo + nb, c1:c1 + n], A[lo:lo + nb, c0:c1], G, nb, n, nb)
-                if self.rows_rhs > 0:
-                    n = nbelow * nb
-                    o.gemm_sub(A[self.rows_mat:, c1:c1 + n], A[self.rows_mat:, c0:c1], G, self.rows_rhs, n, nb)
+                G = self.gath[:P * cnt * nb]
+                mine = [I for I in self.my_blocks if I >= k + 2]
+                seg_rows = [nb] * len(mine) + ([self.rows_rhs] if self.rows_rhs > 0 else [])
+                seg_cols = [(I - k) * nb for I in mine] + ([nbelow * nb] if self.rows_rhs > 0 else [])
+                if seg_rows:
+                    lo = self.loff[mine[0]] if mine else self.rows_mat
+                    o.gemm_sub_stair(A[lo:, c1:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm)
         o.join_lookahead()
         t = self._allreduce(self.torch.tensor([float(o.read_info())], dtype=self.torch.float64), 'max')
         return int(t[0])
@@ -390,8 +430,24 @@ class DistributedGP:
                     break
                 dK *= c10
             if not ok:
-                raise RuntimeError('distributed Cholesky: jitter schedule exhausted (the 1e-10*I fallback of the '
-                                   'reference is a single-GPU path)')
+                # CholeskyRobust.perform never raises: the factor becomes 1e-10 * I (tensors.py:215-222),
+                # identity on the padding; the right-hand-side rows are rebuilt and solved against it
+                fallback = True
+                c = float(np.float32(1e-10))
+                o, nb = self.ops, self.nb
+                o.fill_zero(self.A[:self.rows_mat])
+                for I in self.my_blocks:
+                    nv = max(min(nb, self.N - I * nb), 0)
+                    D = self._diag(I)
+                    if nv > 0:
+                        o.diag_add(D, nv, c)
+                    if nv < nb:
+                        o.diag_add(D[nv:, nv:], nb - nv, 1.0)
+                for t, ch in enumerate(self.my_chunks):
+                    o.rhs_rows(self.A[self.rows_mat + t * 128:self.rows_mat + (t + 1) * 128], ch, Xs, self.M, X, self.N,
+                               spec_cross, delta)
+                if self.rows_rhs > 0:
+                    o.scale_cols(self.A[self.rows_mat:], self.N, 1.0 / c)
         self.last.update(info=info, tries=tries, fallback=fallback)
         return info
 
@@ -421,13 +477,64 @@ class DistributedGP:
         t = self._allreduce(self.torch.from_numpy(acc), 'sum').numpy()
         return float(t[0]), float(t[1]), t[2:2 + M], t[2 + M:]
 
-    def step(self, spec_noise, spec_f, X, Xs, delta):
-        """one pass of the hot path; returns logp (mean / variance pieces in self.last)"""
+    # ---------------------------------------------------------------- posterior covariance and draws
+    def posterior_draws(self, spec_pred, Xs, loc, Z):
+        """Posterior covariance K(Xs, Xs) - V V^T (elliptical.py:86-91), its robust Cholesky
+        (elliptical.py:88,92; tensors.py:197-222) and the draws loc + L_post Z (gaussian.py:75-97,
+        before the mapping) -- BASELINE config 5's extra work.
+
+        V = K(Xs, X) L^-T sits in the right-hand-side chunks of the factored local matrices, full rows
+        per chunk.  All-gather V (M x N: 1 GiB at config 5), every rank forms the covariance rows of
+        ITS chunks with one MFMA GEMM against the gathered V (rank-major: block table again), the
+        M x M covariance is all-gathered (64 MiB) and factored redundantly on every rank -- M^3/3
+        flops, nothing to exchange -- so all ranks hold the same draws.  spec_pred is the kernel of
+        the latent process f (posterior_kernel_f_space, elliptical.py:90-92: the prior part is the
+        plain f_kernel.cov, not scrubbed), loc the posterior location."""
+        o, P, M, Np, pad = self.ops, self.world, self.M, self.Np, 128
+        nch = self.Mp // pad                                       # chunks of Xs rows (right-hand-side chunks 1..nch)
+        owner = [(c + 1) % P for c in range(nch)]
+        cmax = max(max(sum(1 for c in range(nch) if owner[c] == q) for q in range(P)), 1)
+        mine = [c for c in range(nch) if owner[c] == self.rank]
+        # my V chunks, in chunk order (chunk c of Xs = right-hand-side chunk c + 1)
+        send = o.zeros(cmax * pad, Np)
+        for i, c in enumerate(mine):
+            t = self.my_chunks.index(c + 1)
+            send[i * pad:(i + 1) * pad].copy_(self.A[self.rows_mat + t * pad:self.rows_mat + (t + 1) * pad])
+        Vall = o.zeros(P * cmax * pad, Np)
+        self._wait(self._allgather(Vall, send))
+        seen, perm = [0] * P, []
+        for c in range(nch):
+            perm.append(owner[c] * cmax + seen[owner[c]])
+            seen[owner[c]] += 1
+        # covariance rows of my chunks: K(Xs_c, Xs) - V_c Vall^T
+        rows = o.zeros(cmax * pad, self.Mp)
+        for i, c in enumerate(mine):
+            m = max(min(pad, M - c * pad), 0)
+            if m > 0:
+                o.gram_block(rows[i * pad:(i + 1) * pad], Xs[c * pad:], m, Xs, M, spec_pred, scrub=False)
+        if mine:
+            o.gemm_sub_stair(rows, send, Vall, Np, [len(mine) * pad], [self.Mp], pad, perm)
+        call = o.zeros(P * cmax * pad, self.Mp)
+        self._wait(self._allgather(call, rows))
+        cov = o.zeros(self.Mp, self.Mp)
+        for c in range(nch):
+            cov[c * pad:(c + 1) * pad].copy_(call[perm[c] * pad:(perm[c] + 1) * pad])
+        draws, tries, fb = o.chol_draws(cov, M, loc, Z)
+        self.last.update(cov_tries=tries, cov_fallback=fb)
+        return draws
+
+    def step(self, spec_noise, spec_f, X, Xs, delta, Z=None, loc_prior=None):
+        """one pass of the hot path; returns logp (mean / variance pieces in self.last).  With Z (M x S
+        standard normals, gaussian.py:91) also the posterior covariance, its Cholesky and the latent
+        draws loc + L_post Z (self.last['draws']; the caller applies the mapping)"""
         Xt = X._keep if hasattr(X, '_keep') and X._keep is not None else X
         Xst = Xs._keep if hasattr(Xs, '_keep') and Xs._keep is not None else Xs
         dt = delta._keep if hasattr(delta, '_keep') and delta._keep is not None else delta
         self.factor_robust(spec_noise, spec_f, Xt, Xst, dt.reshape(-1))
         logdet, quad, mean, ss = self.stats()
+        if Z is not None:
+            loc = mean if loc_prior is None else np.asarray(loc_prior, dtype=np.float64) + mean
+            self.last['draws'] = self.posterior_draws(spec_f, Xst, loc, Z)
         self.ops.sync()
         logp = -0.5 * self.N * np.log(2 * np.pi) - 0.5 * quad - logdet
         self.last.update(logdet=logdet, quad=quad, mean=mean, ss=ss, logp=logp)

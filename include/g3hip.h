@@ -148,6 +148,19 @@ int g3_scrub(g3_ctx* ctx, void* A_dev, int64_t n1, int64_t n2, int64_t ld, g3_dt
 int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
                const void* B, int64_t ldb, int64_t m, int64_t n, int64_t k,
                double alpha, double beta, g3_dtype dt, int lower_only);
+/* Staircase product in ONE launch: C is a stack of nseg row segments (seg_rows[s] rows each, in
+ * order); segment s gets its first seg_cols[s] columns:
+ *   C[rows_s, 0:seg_cols[s]) = alpha * A[rows_s, 0:k) * B[0:seg_cols[s], 0:k)^T + beta * C.
+ * seg_rows / seg_cols are HOST arrays (borrowed for the call), entries multiples of 128 (0 allowed).
+ * b_perm (HOST, may be NULL): B is stored as blocks of b_block_rows rows (a multiple of 128) and
+ * logical block s -- the rows that multiply columns [s, s+1) * b_block_rows of C -- is physical
+ * block b_perm[s]; nperm entries.  This is the trailing update of one rank of the multi-GPU
+ * factorisation: its row blocks of the lower triangle have different widths and the all-gathered
+ * panel arrives rank-major (g3py/libs/tensors.py:198 is one dpotrf on one host). */
+int g3_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
+                     const void* B, int64_t ldb, int64_t k, const int64_t* seg_rows,
+                     const int64_t* seg_cols, int nseg, double alpha, double beta, g3_dtype dt,
+                     int64_t b_block_rows, const int32_t* b_perm, int nperm);
 
 /* In-place lower Cholesky of the lower triangle of A (n x n, n a multiple of 128; the
  * strict upper triangle is neither read nor written).  Replaces the dpotrf call at

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Full-size CPU oracle runs for BASELINE.json configs 2, 3 and 4 (TEST INFRASTRUCTURE, build container only).
+
+Runs the NumPy/SciPy restatement (oracle/g3_oracle.py: kernel_cov -> tt_to_cov -> dpotrf ->
+solve_triangular, i.e. g3py/processes/hypers/kernels.py:96-110,360-487, g3py/libs/tensors.py:90-98,
+197-222, g3py/processes/gaussian.py:208-241, g3py/processes/elliptical.py:60-107) ONCE at the full
+benchmark sizes with the SURVEY.md section 8(d) inputs and stores scalars only -- logp, 16 posterior
+means, 16 posterior variances -- in tests/golden/fullsize.json.  The covariance is assembled in row
+tiles (the reference's N x N x d broadcast would need 17 GB at config 3); everything else is the
+oracle's own code.  Config 4 needs ~9 GB of RAM and ~5 minutes on 8 cores.
+
+    python oracle/gen_fullsize.py [c2 c3 c4 ...]
+
+"parity unpinned by the reference" applies to these numbers exactly as to the oracle itself
+(DESIGN.md section 2): they extend the oracle to the benchmark sizes, they do not come from Theano.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy as sp
+import scipy.linalg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import g3_oracle as orc  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden', 'fullsize.json')
+NQ = 16          # posterior mean / variance at the first NQ query points
+
+
+def synth(N, d, M, seed):
+    """SURVEY.md section 8(d) -- identical to bench.py::synth"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Lbox = N ** (1.0 / d)
+    X = rng.uniform(0, Lbox, (N, d))
+    Xs = rng.uniform(0, Lbox, (M, d))
+    y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.standard_normal(N)
+    return X, y, Xs
+
+
+CONFIGS = {
+    # name: (N, d, M, seed, kernel)
+    'c2': (8192, 4, 1024, 1002, 'se'),
+    'c3': (16384, 8, 1024, 1003, 'mat52cos'),
+    'c4': (32768, 4, 1024, 1004, 'se'),
+}
+
+
+def spec_of(kind, d):
+    if kind == 'se':
+        return ('SE', 1.0, np.ones(d), None)
+    return ('sum', ('MAT52', 1.0, np.ones(d), None), ('COS', 0.5, np.full(d, 0.125), None))
+
+
+def prior_var(kind):
+    return 1.0 if kind == 'se' else 1.5
+
+
+def run(name):
+    N, d, M, seed, kind = CONFIGS[name]
+    X, y, Xs = synth(N, d, M, seed)
+    spec_f, noise = spec_of(kind, d), 0.1
+    t0 = time.perf_counter()
+    K = np.empty((N, N))
+    tile = max(64, min(1024, (1 << 27) // (N * d)))       # the periodic leaves form tile x N x d
+    for r0 in range(0, N, tile):
+        r1 = min(N, r0 + tile)
+        K[r0:r1] = orc.tt_to_num(orc.kernel_cov(spec_f, X[r0:r1], X))
+    K[np.diag_indices(N)] += noise                         # KernelNoise, square case (kernels.py:367-369)
+    assert K.diagonal().min() > 0                          # tt_to_cov is the identity here (tensors.py:95-98)
+    t1 = time.perf_counter()
+    # K is symmetric: its F-ordered view shares the buffer, so dpotrf works in place (no 2nd copy)
+    L, info = sp.linalg.lapack.dpotrf(K.T, lower=True, overwrite_a=True)
+    assert info == 0, info
+    t2 = time.perf_counter()
+    a = sp.linalg.solve_triangular(L, y, lower=True, check_finite=False)
+    logdet = float(np.sum(np.log(np.diagonal(L))))
+    quad = float(a.dot(a))
+    logp = -0.5 * N * np.log(2 * np.pi) - 0.5 * quad - logdet
+    Ks = orc.kernel_cov(spec_f, Xs[:NQ], X)
+    V = sp.linalg.solve_triangular(L, Ks.T, lower=True, check_finite=False)
+    mean = V.T.dot(a)
+    var = np.maximum(prior_var(kind) - (V ** 2).sum(0), 0.0)
+    t3 = time.perf_counter()
+    try:
+        import threadpoolctl
+        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return dict(N=N, d=d, M=M, seed=seed, kernel=kind, noise=noise, logp=logp, logdet=logdet, quad=quad,
+                mean=[float(v) for v in mean], variance=[float(v) for v in var],
+                cpu_seconds=dict(gram=t1 - t0, potrf=t2 - t1, solves=t3 - t2, total=t3 - t0),
+                cpu_threads=int(threads), potrf_gflops=(N ** 3 / 3.0) / (t2 - t1) / 1e9)
+
+
+def main():
+    names = sys.argv[1:] or ['c2', 'c3', 'c4']
+    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for n in names:
+        res[n] = run(n)
+        print(n, 'logp = %.12f' % res[n]['logp'], res[n]['cpu_seconds'], flush=True)
+        with open(OUT, 'w') as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

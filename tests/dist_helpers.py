@@ -59,6 +59,8 @@ class NumpyPanelOps:
         p[np.arange(n), np.arange(n)] += value
 
     def potrf_block(self, L, nb, W):
+        if getattr(self, '_info', 0):
+            return
         p = L.numpy()
         A = np.tril(p[:nb, :nb])
         A = A + np.tril(A, -1).T
@@ -83,17 +85,47 @@ class NumpyPanelOps:
         pass
 
     def trsm(self, L, nb, W, B, m):
-        if m > 0:
+        # like the device kernels, everything after a failed pivot is skipped (the info flag)
+        if m > 0 and not getattr(self, '_info', 0):
             b = B.numpy()
             b[:m, :nb] = scipy.linalg.solve_triangular(np.tril(L.numpy()[:nb, :nb]), b[:m, :nb].T, lower=True).T
 
     def gemm_sub(self, C, A, B, m, n, k, lower_only=False):
-        if m > 0 and n > 0:
+        if m > 0 and n > 0 and not getattr(self, '_info', 0):
             c = C.numpy()
             upd = A.numpy()[:m, :k] @ B.numpy()[:n, :k].T
             if lower_only:
                 upd = np.where(np.tril(np.ones((m, n), bool)), upd, 0.0)
             c[:m, :n] -= upd
+
+    def gemm_sub_stair(self, C, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None):
+        if getattr(self, '_info', 0):
+            return
+        c, a, b = C.numpy(), A.numpy(), B.numpy()
+        if b_perm is not None:      # logical block s of B lives at physical block b_perm[s]
+            nbr = b_block_rows
+            b = np.concatenate([b[p * nbr:(p + 1) * nbr] for p in b_perm])
+        r = 0
+        for rows, cols in zip(seg_rows, seg_cols):
+            if rows > 0 and cols > 0:
+                c[r:r + rows, :cols] -= a[r:r + rows, :k] @ b[:cols, :k].T
+            r += rows
+
+    def fill_zero(self, t):
+        t.zero_()
+
+    def scale_cols(self, t, n, factor):
+        t[:, :n] *= factor
+
+    def gram_block(self, out, Xa, ma, Xb, mb, spec, scrub=True):
+        from oracle import g3_oracle as orc
+        K = orc.kernel_cov(spec, Xa.numpy()[:ma], Xb.numpy()[:mb])
+        out.numpy()[:ma, :mb] = orc.tt_to_num(K) if scrub else K
+
+    def chol_draws(self, cov, M, loc, Z):
+        from oracle import g3_oracle as orc
+        L, tries, fb = orc.cholesky_robust(cov.numpy()[:M, :M], return_info=True)
+        return np.asarray(loc)[:, None] + np.tril(L).dot(Z), tries, fb
 
     def logdet_block(self, D, nv):
         return float(np.sum(np.log(np.diag(D.numpy()[:nv, :nv])))) if nv > 0 else 0.0
@@ -115,8 +147,8 @@ def synth(N, d, M, seed):
     return X, y, Xs
 
 
-def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_path, dup=False):
-    """one rank of a distributed run; rank 0 writes (logp, mean, var) to out_path"""
+def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_path, dup=False, draws=0, dtype='f64'):
+    """one rank of a distributed run; rank 0 writes (logp, mean, var[, draws]) to out_path"""
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -139,14 +171,17 @@ def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_
             st = torch.cuda.Stream()
             torch.cuda.set_stream(st)
             dev.set_stream(st.cuda_stream)
-            dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=nb, torch_device=tdev)
+            dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=nb, torch_device=tdev,
+                                dtype=np.float32 if dtype == 'f32' else np.float64)
         else:
             dgp = DistributedGP(None, dist, rank, world, N, d, M, nb=nb, ops=NumpyPanelOps(torch))
         o = dgp.ops
-        lp = dgp.step(spec_n, spec_f, o.from_host(X), o.from_host(Xs), o.from_host(y))
+        Z = np.random.default_rng(5).standard_normal((M, draws)) if draws else None
+        lp = dgp.step(spec_n, spec_f, o.from_host(X), o.from_host(Xs), o.from_host(y), Z=Z)
         if rank == 0:
             prior = np.diag(orc.kernel_cov(spec_f, Xs))
             np.savez(out_path, logp=lp, mean=dgp.last['mean'], var=np.maximum(prior - dgp.last['ss'], 0),
-                     tries=dgp.last['tries'])
+                     tries=dgp.last['tries'], fallback=dgp.last['fallback'],
+                     draws=dgp.last['draws'] if draws else np.zeros(0))
     finally:
         dist.destroy_process_group()

@@ -57,6 +57,44 @@ def test_distributed_jitter_schedule(tmp_path):
     assert abs(float(r['logp']) - ref) <= 1e-5 * abs(ref)
 
 
+def test_distributed_exhausted_jitter_falls_back(tmp_path):
+    """an indefinite 'covariance' (SIN kernel with a large positive exponent, kernels.py:472, no noise):
+    the 20-step schedule is exhausted and every rank installs the reference's 1e-10 * I fallback
+    (tensors.py:215-222) instead of raising; logp equals the oracle's"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    world, N, d, M, nb = 2, 200, 1, 10, 128
+    spec_f = ('SIN', 1.0, np.full(d, 0.37), np.full(d, 40.0), None)
+    X, y, Xs = synth(N, d, M, 77)
+    K = orc.tt_to_cov(orc.tt_to_num(orc.kernel_cov(spec_f, X)))
+    _, tries, fb = orc.cholesky_robust(K, return_info=True)
+    assert fb, 'test premise: the oracle itself must reach the fallback'
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', False, spec_f, None, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert bool(r['fallback']) and int(r['tries']) == 20
+    ref = orc.GP(spec_f, None).logp(X, y)
+    assert abs(float(r['logp']) - ref) <= 1e-9 * abs(ref)
+
+
+@pytest.mark.parametrize('world,N,nb,M', [(2, 600, 128, 200), (3, 500, 128, 300), (1, 300, 128, 130)])
+def test_distributed_posterior_draws(tmp_path, world, N, nb, M):
+    """config-5 extras on the multi-rank driver: posterior covariance, its Cholesky and L Z draws
+    (gaussian.py:75-97) equal the oracle's sampler with the same normals"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    d, S = 3, 6
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', False, spec_f, 0.1, out, False, S), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    Z = np.random.default_rng(5).standard_normal((M, S))
+    gp = orc.GP(spec_f, 0.1)
+    ref = gp.sampler(Xs, X, y, rand=Z)
+    np.testing.assert_allclose(r['draws'], ref, atol=1e-7)
+
+
 def test_block_ranges_and_ownership():
     from g3py_amd.distributed import block_ranges
     assert block_ranges(640, 256) == [(0, 256), (256, 256), (512, 128)]

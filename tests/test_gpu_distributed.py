@@ -28,3 +28,39 @@ def test_hip_block_cyclic_matches_oracle(tmp_path, world, N, nb):
     assert abs(float(r['logp']) - ref) <= 1e-8 * abs(ref)
     np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-8)
     np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_hip_exhausted_jitter_falls_back(tmp_path, world):
+    """indefinite matrix: the distributed driver installs the reference's 1e-10 * I fallback
+    (tensors.py:215-222) on every rank instead of raising; same logp as the oracle"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    N, d, M, nb = 500, 1, 20, 256
+    spec_f = ('SIN', 1.0, np.full(d, 0.37), np.full(d, 40.0), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', True, spec_f, None, out), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    assert bool(r['fallback']) and int(r['tries']) == 20
+    ref = orc.GP(spec_f, None).logp(X, y)
+    assert abs(float(r['logp']) - ref) <= 1e-8 * abs(ref)
+
+
+@pytest.mark.parametrize('world,N,nb,M,dtype,tol', [(1, 1500, 512, 300, 'f64', 1e-7), (2, 1400, 256, 300, 'f64', 1e-7),
+                                                    (2, 1400, 256, 300, 'f32', 2e-3)])
+def test_hip_posterior_draws(tmp_path, world, N, nb, M, dtype, tol):
+    """BASELINE config 5's extras through the HIP tile operations: posterior covariance, its robust
+    Cholesky and loc + L Z draws (gaussian.py:75-97) against the oracle's sampler with the same normals"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    d, S = 4, 8
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', True, spec_f, 0.1, out, False, S, dtype),
+             nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    Z = np.random.default_rng(5).standard_normal((M, S))
+    ref = orc.GP(spec_f, 0.1).sampler(Xs, X, y, rand=Z)
+    np.testing.assert_allclose(r['draws'], ref, atol=tol)

@@ -38,6 +38,45 @@ def test_gemm_nt(dev, dt, m, n, k, lower):
 
 
 @pytest.mark.parametrize('dt', [np.float64, np.float32])
+@pytest.mark.parametrize('case', ['two_blocks', 'ragged_rhs', 'perm', 'big', 'empty_segment'])
+def test_gemm_nt_stair(dev, dt, case):
+    """staircase product (one launch): stacked row segments with their own widths, optional block
+    table for B -- the per-rank trailing update of the multi-GPU factorisation"""
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    k = 256
+    if case == 'two_blocks':
+        seg_rows, seg_cols, nbr, perm = [256, 256], [256, 768], 0, None
+    elif case == 'ragged_rhs':
+        seg_rows, seg_cols, nbr, perm = [512, 512, 512, 384], [512, 1536, 2048, 2560], 0, None
+    elif case == 'perm':
+        seg_rows, seg_cols, nbr = [256, 256, 128], [256, 512, 1024], 256
+        perm = [2, 0, 3, 1]
+    elif case == 'empty_segment':
+        seg_rows, seg_cols, nbr, perm = [128, 256, 128], [384, 0, 512], 0, None
+    else:   # enough tiles for the 128 x 128 kernel (>= 4096 tiles of 128 x 128)
+        seg_rows, seg_cols, nbr, perm = [1024] * 12, [512 * (i + 4) for i in range(12)], 512, None
+        perm = list(rng.permutation(max(seg_cols) // 512))
+        k = 128
+    m, n = sum(seg_rows), max(seg_cols)
+    A = rng.standard_normal((m, k)).astype(dt)
+    B = rng.standard_normal((n, k)).astype(dt)
+    C = rng.standard_normal((m, n + 64)).astype(dt)
+    Ad, Bd, Cd = dev.upload(A), dev.upload(B), dev.upload(C)
+    dev.gemm_nt_stair(Cd.ptr, Cd.ld, Ad.ptr, Ad.ld, Bd.ptr, Bd.ld, k, seg_rows, seg_cols, dt, alpha=-1.0, beta=1.0,
+                      b_block_rows=nbr, b_perm=perm)
+    got = dev.download(Cd)
+    Bl = B.astype(np.float64)
+    if perm is not None:
+        Bl = np.concatenate([Bl[p * nbr:(p + 1) * nbr] for p in perm])
+    ref = C.astype(np.float64).copy()
+    r = 0
+    for rows, cols in zip(seg_rows, seg_cols):
+        ref[r:r + rows, :cols] -= A[r:r + rows].astype(np.float64) @ Bl[:cols].T
+        r += rows
+    assert np.abs(got - ref).max() <= TOL[dt] * np.abs(ref).max() * max(1, k / 64)
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
 @pytest.mark.parametrize('lower', [False, True])
 def test_gemm_unaligned_c_takes_the_scalar_epilogue(dev, dt, lower):
     """C with an odd leading dimension / offset start is not 16-byte aligned row by row: the kernel

@@ -111,6 +111,47 @@ def test_full_size_factor_properties(dev, N, d, kind):
         assert abs(lp2 - lp) <= 1e-9 * abs(lp)
 
 
+@pytest.mark.parametrize('name', ['c2', 'c3', 'c4'])
+def test_full_size_configs_match_oracle_pins(dev, name):
+    """BASELINE configs 2, 3, 4 at FULL size against the CPU oracle's one-off run
+    (tests/golden/fullsize.json, written by oracle/gen_fullsize.py in the build container: scalars
+    only).  Tolerances as stated in DESIGN.md: logp 1e-8 relative, mean / variance 1e-8 absolute.
+    The oracle itself is unpinned by the reference for config 3's kernels (MAT52 + COS)."""
+    import json
+    import os
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'fullsize.json')))
+    if name not in gold:
+        pytest.skip('no pin generated for ' + name)
+    g = gold[name]
+    N, d, M = g['N'], g['d'], g['M']
+    X, y, Xs = _synth(N, d, M, g['seed'])
+    if g['kernel'] == 'se':
+        spec_f = ('SE', 1.0, np.ones(d), None)
+        prior = 1.0
+    else:
+        spec_f = ('sum', ('MAT52', 1.0, np.ones(d), None), ('COS', 0.5, np.full(d, 0.125), None))
+        prior = 1.5
+    spec_n = orc.with_noise(spec_f, g['noise'])
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, 128)
+    K = dev.alloc(Np + 128 + Mp, Np, np.float64)
+    W, a = dev.alloc_inverses(Np, np.float64), dev.alloc(1, Np, np.float64)
+    mu, ss = dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
+    st = dev.gp_factor_predict(compile_spec(spec_n, d), compile_spec(spec_f, d), dev.upload(X), N, d, dev.upload(y),
+                               dev.upload(Xs), M, K, W, a, mu, ss)
+    lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
+    assert st['info'] == 0 and st['tries'] == 0
+    assert abs(lp - g['logp']) <= 1e-8 * abs(g['logp']), (lp, g['logp'])
+    assert abs(st['logdet'] - g['logdet']) <= 1e-8 * abs(g['logdet'])
+    nq = len(g['mean'])
+    np.testing.assert_allclose(dev.download(mu, 1, nq)[0], g['mean'], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(np.maximum(prior - dev.download(ss, 1, nq)[0], 0), g['variance'], rtol=0, atol=1e-8)
+    for b in (K, W, a, mu, ss):
+        b.free()
+
+
 def test_potrf_blocking_invariance(dev, monkeypatch):
     """the look-ahead panel width must not change the factor beyond rounding"""
     import scipy.linalg
