@@ -25,6 +25,10 @@
 
 constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
 constexpr int GROUP_M = 4; // row-blocks per raster group
+#ifndef G3_SMALL_STAGES
+#define G3_SMALL_STAGES 4  // LDS buffers of the 64 x 64 and 32 x 128 tiles (latency-bound critical-path products)
+#endif
+constexpr int SMALL_STAGES = G3_SMALL_STAGES;
 
 // ---- tile raster.  The host describes the ACTIVE tiles of a launch as a list of row groups (a few
 // consecutive row tiles each) with a column-tile count per group; the table travels by value in the
@@ -37,16 +41,20 @@ constexpr int G3_DENSE_OFF = 1 << 30;
 struct RasterTab {
   int ngroups;
   int diag_off;                             // element (row, col) is wanted iff col <= row + diag_off
-  int prefix[G3_RASTER_MAX + 1];            // first virtual tile id of group g; prefix[ngroups] = grid size
-  unsigned short row0[G3_RASTER_MAX];       // first row tile of group g
-  unsigned char nrows[G3_RASTER_MAX];       // row tiles in group g (its tiles are ordered column-major)
+  // per group, packed so that the search and the payload of a small launch share one cache line
+  // (the table is read with dependent scalar loads at the start of every workgroup)
+  struct Group {
+    int prefix;                             // first virtual tile id of the group; g[ngroups].prefix = grid size
+    unsigned short row0;                    // first row tile
+    unsigned short nrows;                   // row tiles in the group (its tiles are ordered column-major)
+  } g[G3_RASTER_MAX + 1];
   // optional row-block permutation of B: logical block s (b_nb rows) lives at physical block
   // b_blk[s] -- the gathered panel of the multi-GPU sweep arrives rank-major, not in global order
   int b_nb;                                 // 0: B is in logical order
   unsigned short b_blk[G3_RASTER_MAX];
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
 gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                int K, T alpha, T beta, const int* __restrict__ info,
@@ -79,22 +87,24 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     int lo = 0, hi = tab.ngroups;            // largest g with prefix[g] <= v  (prefix[0] = 0, v < prefix[ngroups])
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (tab.prefix[mid] <= v) lo = mid; else hi = mid;
+      if (tab.g[mid].prefix <= v) lo = mid; else hi = mid;
     }
-    const int w = v - tab.prefix[lo];
-    const int rows = (int)tab.nrows[lo];
+    const int w = v - tab.g[lo].prefix;
+    const int rows = (int)tab.g[lo].nrows;
     bn = w / rows;
-    bm = (int)tab.row0[lo] + (w - bn * rows);
+    bm = (int)tab.g[lo].row0 + (w - bn * rows);
   }
   const int doff = tab.diag_off;
   const bool lower_only = doff < G3_DENSE_OFF;
   const int m0 = bm * BM, n0 = bn * BN;
   if (lower_only && n0 > m0 + BM - 1 + doff) return;    // a tile of a group above its own row's limit
-  if (info != nullptr && *info != 0) return;
+  // a failed pivot earlier in the sweep turns every later launch into a no-op; the flag is requested
+  // now and tested only before the first store, so its round trip hides under the first DMA
+  const int failed = (info != nullptr) ? *info : 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                      // [2][BM][ROWB]
-  char* sB = smem + 2 * BM * ROWB;      // [2][BN][ROWB]
+  char* sA = smem;                           // [NSTAGE][BM][ROWB]
+  char* sB = smem + NSTAGE * BM * ROWB;      // [NSTAGE][BN][ROWB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
@@ -159,13 +169,15 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     }
   };
 
-  // two LDS buffers: the DMA of tile kt+1 is in flight during all 64 MFMAs of tile kt; the
-  // vmcnt(0) + barrier at the end of an iteration both publishes tile kt+1 and guarantees
-  // everyone has finished reading the buffer the next DMA will overwrite
+  // NSTAGE LDS buffers, NSTAGE - 1 K tiles of DMA in flight.  The big tile is matrix-pipe bound
+  // (64 MFMAs = 4096 cycles per K tile and wave, twice that with the partner workgroup): two
+  // buffers hide a memory round trip completely.  The small tiles of the critical path are not:
+  // a 64 x 64 tile has 0.5 us of MFMA per K tile against 1-2 us of load latency, so with two
+  // buffers every K tile costs a full round trip (K = 256: 33 us measured for a 10-tile SYRK);
+  // four buffers keep three round trips in flight.
   const int KT = K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  constexpr int LPS = BM / 8 / NW + BN / 8 / NW;           // DMA instructions per wave and stage
+  static_assert((NSTAGE - 2) * LPS <= 63, "vmcnt range");
   // epilogue geometry (see below).  (Requesting the first chunk of C before the last K tile would
   // hide its latency too, but costs 25 VGPRs: the kernel must stay <= 224 so that the
   // critical-path diagonal kernel still fits beside one of these workgroups.)
@@ -175,7 +187,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   constexpr int RPP = NT / VPR;                            // rows per pass of the whole workgroup
   constexpr int NPASS = RC / RPP;
   constexpr int NCH = BM / RC;
-  static_assert(RC * PITCH <= 2 * (BM + BN) * ROWB, "epilogue chunk must fit in the staging LDS");
+  static_assert(RC * PITCH <= NSTAGE * (BM + BN) * ROWB, "epilogue chunk must fit in the staging LDS");
   static_assert(NT % VPR == 0 && RC % RPP == 0 && BM % RC == 0, "epilogue tiling");
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (ldc % EPC == 0);
   const bool rmw = vec_ok && beta != T(0);
@@ -189,14 +201,30 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
       if (!(lower_only && col > row + doff)) cnext[p] = *reinterpret_cast<const chunk_t*>(C + (int64_t)row * ldc + col);
     }
   };
+  // small tiles have registers to spare: request the first chunk of C before anything else
+  constexpr bool EARLY_C = NSTAGE > 2;
+  if (EARLY_C && rmw) fetch_c(0);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < KT) stage(s, s * BK);
+  int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) stage(buf ^ 1, (kt + 1) * BK);
+    // K tile kt has landed once at most the NSTAGE - 2 younger stages are outstanding (loads retire
+    // in order); near the end fewer stages were issued, so wait for everything
+    if (NSTAGE > 2 && kt + NSTAGE - 2 < KT) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPS) : "memory");   // (the C prefetch is older: covered)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();          // tile kt is published; everyone has finished tile kt - 1, whose buffer is refilled next
+    const int nxt = kt + NSTAGE - 1;
+    if (nxt < KT) stage(buf == 0 ? NSTAGE - 1 : buf - 1, nxt * BK);
     compute(buf, 0);
     compute(buf, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
   }
+  __syncthreads();            // the epilogue re-uses the staging LDS
+  if (failed != 0) return;
 
   // ---- epilogue.  The accumulators are in MFMA layout (a lane holds 4 rows x 1 column of each
   // 16 x 16 tile): written straight to C that is 128-byte pieces scattered over 64 rows per
@@ -206,7 +234,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   // BN * sizeof(T) contiguous bytes per row (1 KiB for the 128-column fp64 tile).
   if (vec_ok) {
     const int col_l = lane & 15;
-    if (rmw) fetch_c(0);
+    if (rmw && !EARLY_C) fetch_c(0);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // this chunk's C vectors were requested one step ago; request the next chunk's now
@@ -310,9 +338,9 @@ static long long build_raster(const GemmShape& sh, RasterTab* tab) {
   auto push = [&](int64_t row_tile0, int64_t rows, int64_t nc) -> bool {
     if (rows <= 0 || nc <= 0) return true;
     if (ng >= G3_RASTER_MAX) return false;
-    tab->prefix[ng] = (int)total;
-    tab->row0[ng] = (unsigned short)row_tile0;
-    tab->nrows[ng] = (unsigned char)rows;
+    tab->g[ng].prefix = (int)total;
+    tab->g[ng].row0 = (unsigned short)row_tile0;
+    tab->g[ng].nrows = (unsigned short)rows;
     total += rows * nc;
     ++ng;
     return true;
@@ -336,7 +364,7 @@ static long long build_raster(const GemmShape& sh, RasterTab* tab) {
     const int64_t tiles_n = sh.n / BN;
     int64_t gh = GROUP_M;
     if ((tiles_m + gh - 1) / gh > G3_RASTER_MAX) gh = (tiles_m + G3_RASTER_MAX - 1) / G3_RASTER_MAX;
-    if (gh > 255) return -1;
+    if (gh > 65535) return -1;
     for (int64_t t = 0; t < tiles_m; t += gh) {
       const int64_t rows = tiles_m - t < gh ? tiles_m - t : gh;
       int64_t nc = tiles_n;
@@ -349,7 +377,9 @@ static long long build_raster(const GemmShape& sh, RasterTab* tab) {
     }
   }
   tab->ngroups = ng;
-  tab->prefix[ng] = (int)total;
+  tab->g[ng].prefix = (int)total;
+  tab->g[ng].row0 = 0;
+  tab->g[ng].nrows = 1;
   tab->b_nb = 0;
   if (sh.b_nb > 0 && sh.b_perm) {
     if (sh.nperm > G3_RASTER_MAX || sh.b_nb % BN) return -1;
@@ -359,12 +389,12 @@ static long long build_raster(const GemmShape& sh, RasterTab* tab) {
   return total;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                       int64_t ldb, int64_t k, double alpha, double beta, const GemmShape& sh) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr int LDS = 2 * (BM + BN) * ROWB;
-  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN>;
+  constexpr int LDS = NSTAGE * (BM + BN) * ROWB;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, NSTAGE>;
   // the attribute belongs to the (function, device) pair: cached per device.  Setting it twice from
   // two threads is harmless (same value), so the flag needs no lock.
   static bool attr_set[G3_MAX_DEVICES] = {};
@@ -419,12 +449,12 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
     forced = e ? atoi(e) : 0;
   }
   if (forced == 1 && sh.kind != 2 && sh.m % 256 == 0 && sh.n % 128 == 0)
-    return launch_cfg<T, 256, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 256, 128, 64, 64, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 2 && all128)
-    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 128, 128, 64, 64, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 4 && sh.kind != 2 && sh.n % 128 == 0)
-    return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 32, 128, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   // Tile choice (measured on MI355X, scripts/gemm_bench.py):
   //  * in-place panel solves (`wide`, C aliases A, n = 128): thin 32 x 128 tiles always -- one
   //    tile must span the 128 output columns, and 4x more workgroups beat 128 x 128 tiles from
@@ -435,14 +465,21 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   // (a 256 x 128 tile, one block per CU, was 4-5 % slower than 128 x 128 everywhere.)
   if (wide) {
     if (sh.kind == 0 && sh.n % 128 == 0 && sh.m % 32 == 0)
-      return launch_cfg<T, 32, 128, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+      return launch_cfg<T, 32, 128, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
     snprintf(ctx->err, sizeof(ctx->err), "in-place panel GEMM needs n %% 128 == 0 and m %% 32 == 0 (m=%lld n=%lld)",
              (long long)sh.m, (long long)sh.n);
     return G3_ERR_HIP;
   }
   if (all128 && blocks128 >= big_tile_min())
-    return launch_cfg<T, 128, 128, 64, 64>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  return launch_cfg<T, 64, 64, 32, 32>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 128, 128, 64, 64, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  // 64 x 64 tiles: a small grid is latency-bound (deep pipeline, 2 workgroups per CU are plenty); a
+  // grid that fills the chip several times over is throughput-bound and wants the occupancy of the
+  // two-buffer variant (5 workgroups per CU)
+  static int64_t deep_max = -1;
+  if (deep_max < 0) { const char* e = getenv("G3_DEEP_MAX"); deep_max = e ? atoll(e) : 1024; }
+  if ((int64_t)(shape_elems(sh) / (64.0 * 64.0)) * g3_nbatch(ctx) <= deep_max)
+    return launch_cfg<T, 64, 64, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  return launch_cfg<T, 64, 64, 32, 32, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
 }
 
 static int launch_dt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
