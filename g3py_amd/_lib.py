@@ -86,12 +86,15 @@ _SIGS = {
                               _I64, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _P], C.c_int),
+    'g3_gp_sample': ([_P, _P, _I64, _I64, _P, _P, _I64, C.c_int, _P], C.c_int),
     'g3_grad_layout': ([C.POINTER(KernelProg), C.POINTER(GradMap)], C.c_int),
     'g3_potri': ([_P, _P, _I64, _I64, _P, C.c_int, _P, _I64, _P, _I64], C.c_int),
     'g3_gram_grad': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
                       _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_dlogp': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _I64, _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_dlogp_batched': ([_P, C.POINTER(KernelProg), C.c_int, C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64,
+                             _I64, _P, _P, C.c_int, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_prof_enable': ([_P, C.c_int], C.c_int),
     'g3_prof_reset': ([_P], C.c_int),
     'g3_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),

@@ -284,7 +284,8 @@ diag_stats_kernel(T* A, int64_t n, int64_t ld, double* out, int lift, int64_t bs
 }
 
 template <typename T>
-__global__ void diag_add_kernel(T* A, int64_t n, int64_t ld, T v) {
+__global__ void diag_add_kernel(T* A, int64_t n, int64_t ld, T v, int64_t bstride) {
+  A += (int64_t)blockIdx.y * bstride;            // batch member (grid.y)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) A[i * ld + i] += v;
 }
@@ -400,11 +401,18 @@ extern "C" int g3_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype
   if (n < 0) return -3;
   if (ld < n) return -4;
   if (n == 0) return G3_OK;
-  const unsigned nb = (unsigned)((n + 255) / 256);
+  return g3i_diag_add(ctx, A, n, ld, dt, value);
+}
+
+// stream-ordered; in batch mode every member gets the same increment
+int g3i_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value) {
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)g3_nbatch(ctx));
   if (dt == G3_F64)
-    hipLaunchKernelGGL((diag_add_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, (double*)A, n, ld, value);
+    hipLaunchKernelGGL((diag_add_kernel<double>), grid, dim3(256), 0, ctx->stream, (double*)A, n, ld, value,
+                       g3_bstride_of(ctx, A));
   else
-    hipLaunchKernelGGL((diag_add_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, (float*)A, n, ld, (float)value);
+    hipLaunchKernelGGL((diag_add_kernel<float>), grid, dim3(256), 0, ctx->stream, (float*)A, n, ld, (float)value,
+                       g3_bstride_of(ctx, A));
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -837,4 +845,65 @@ extern "C" int g3_gp_cross(g3_ctx* ctx, const g3_kernel_prog* prog, const void* 
     g3i_prof_end(ctx, pr);
   }
   return rc;
+}
+
+
+// draws = loc + L Z  (gaussian.py:92-95).  Z^T and the product live in the context's workspace.
+template <typename T>
+static int gp_sample_t(g3_ctx* ctx, const T* L, int64_t M, int64_t ldl, const T* loc, const T* Z, int64_t S, T* out) {
+  const int64_t Mp = g3_roundup(M, 128), Sp = g3_roundup(S, 64);
+  const size_t zt_bytes = (size_t)Sp * Mp * sizeof(T), c_bytes = (size_t)Mp * Sp * sizeof(T);
+  int rc = g3i_ensure_work(ctx, zt_bytes + c_bytes);
+  if (rc) return rc;
+  T* Zt_dev = (T*)ctx->work;
+  T* C_dev = (T*)((char*)ctx->work + zt_bytes);
+  // Z^T, zero padded, assembled on the host (M x S is small next to the M x M factor)
+  T* zt = (T*)calloc((size_t)Sp * Mp, sizeof(T));
+  if (!zt) return G3_ERR_NOMEM;
+  for (int64_t i = 0; i < M; ++i)
+    for (int64_t s = 0; s < S; ++s) zt[s * Mp + i] = Z[i * S + s];
+  hipError_t e = hipMemcpyAsync(Zt_dev, zt, zt_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free(zt);
+  if (e != hipSuccess) {
+    snprintf(ctx->err, sizeof(ctx->err), "g3_gp_sample: upload of Z failed: %s", hipGetErrorString(e));
+    return G3_ERR_HIP;
+  }
+  rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  const g3_dtype dt = sizeof(T) == 8 ? G3_F64 : G3_F32;
+  rc = g3i_gemm_nt(ctx, C_dev, Sp, L, ldl, Zt_dev, Mp, Mp, Sp, Mp, 1.0, 0.0, dt, 0);      // C = L (Z^T)^T
+  if (rc) return rc;
+  T* c = (T*)malloc(c_bytes);
+  if (!c) return G3_ERR_NOMEM;
+  e = hipMemcpyAsync(c, C_dev, c_bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    free(c);
+    snprintf(ctx->err, sizeof(ctx->err), "g3_gp_sample: download failed: %s", hipGetErrorString(e));
+    return G3_ERR_HIP;
+  }
+  for (int64_t i = 0; i < M; ++i)
+    for (int64_t s = 0; s < S; ++s) out[i * S + s] = loc[i] + c[i * Sp + s];
+  free(c);
+  return G3_OK;
+}
+
+extern "C" int g3_gp_sample(g3_ctx* ctx, const void* L_dev, int64_t M, int64_t ldl, const void* loc_host,
+                            const void* Z_host, int64_t S, g3_dtype dt, void* out_host) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!L_dev) return -2;
+  if (M <= 0) return -3;
+  const int64_t Mp = g3_roundup(M, 128), al = 16 / (int64_t)g3_esize(dt);
+  if (ldl < Mp || ldl % al) return -4;
+  if (!loc_host) return -5;
+  if (!Z_host) return -6;
+  if (S <= 0) return -7;
+  if (!out_host) return -9;
+  if (dt == G3_F64)
+    return gp_sample_t<double>(ctx, (const double*)L_dev, M, ldl, (const double*)loc_host, (const double*)Z_host, S,
+                               (double*)out_host);
+  return gp_sample_t<float>(ctx, (const float*)L_dev, M, ldl, (const float*)loc_host, (const float*)Z_host, S,
+                            (float*)out_host);
 }

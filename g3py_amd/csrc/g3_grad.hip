@@ -60,9 +60,11 @@ int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* in
   const bool two = nblk >= 3;   // small problems: everything on the caller's stream
   if (!two) sB = sA;
 
-  G3_HIP(hipMemset2DAsync(Y, (size_t)ldy * es, 0, (size_t)n * es, (size_t)n, sA));
-  G3_HIP(hipMemset2DAsync(C, (size_t)ldc * es, 0, (size_t)n * es, (size_t)n, sA));
-  rc = g3_diag_add(ctx, Y, n, ldy, dt, 1.0);
+  for (int b = 0; b < g3_nbatch(ctx); ++b) {     // batch mode: every member's Y and K^-1
+    G3_HIP(hipMemset2DAsync((char*)Y + (size_t)b * g3_bstride_of(ctx, Y) * es, (size_t)ldy * es, 0, (size_t)n * es, (size_t)n, sA));
+    G3_HIP(hipMemset2DAsync((char*)C + (size_t)b * g3_bstride_of(ctx, C) * es, (size_t)ldc * es, 0, (size_t)n * es, (size_t)n, sA));
+  }
+  rc = g3i_diag_add(ctx, Y, n, ldy, dt, 1.0);
   if (rc) return rc;
   if (two) {
     G3_HIP(hipEventRecord(evB[nblk], sA));
@@ -750,4 +752,66 @@ extern "C" int g3_gp_dlogp(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_gra
   rc = g3_rows_dot_ss(ctx, Y_dev, Np, Np, ldy, a_dev, dt, alpha_dev, nullptr);
   if (rc) return rc;
   return g3i_gram_grad(ctx, prog, map, X_dev, N, ldx, d, dt, Kinv_dev, ldc, alpha_dev, out_host);
+}
+
+
+// Batched dlogp: `batch` factorisations produced by ONE g3_gp_factor_batched sweep (members kstride
+// elements apart in L_dev, diagonal-block inverses Npad*128 apart, a_dev batch x Npad) -- the caller
+// pattern of fixed_dlogp / find_MAP restarts (g3py/processes/stochastic.py:554-564: a Python loop
+// over single gradients in the reference).  K^-1 of every member comes out of one batched potri
+// sweep (grid.y = member in every MFMA GEMM and diagonal-block launch); the O(N^2) kernel-parameter
+// sums then run member by member.  Y_dev / Kinv_dev: batch members, kstride apart, ld = ldl.
+extern "C" int g3_gp_dlogp_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const g3_grad_map* map,
+                                   const void* X_dev, int64_t N, int64_t ldx, int d, const void* L_dev, int64_t ldl,
+                                   int64_t kstride, const void* invd_dev, const void* a_dev, g3_dtype dt, void* Y_dev,
+                                   void* Kinv_dev, void* alpha_dev, double* out_host) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!progs) return -2;
+  if (batch < 1 || batch > G3_MAX_BATCH) return -3;
+  if (!map) return -4;
+  for (int b = 0; b < batch; ++b) {
+    if (progs[b].nleaf < 0 || progs[b].nleaf > G3_MAXLEAF || progs[b].nprod < 0 || progs[b].nprod > G3_MAXPROD) return -2;
+    if (check_map(&progs[b], map)) return -4;
+  }
+  if (!X_dev) return -5;
+  if (N <= 0) return -6;
+  if (d < 1 || d > G3_MAXCOLS) return -8;
+  if (ldx < d) return -7;
+  const int64_t Np = g3_roundup(N, G3_LB), al = 16 / (int64_t)g3_esize(dt);
+  const size_t es = g3_esize(dt);
+  if (!L_dev) return -9;
+  if (ldl < Np || ldl % al) return -10;
+  if (kstride < Np * ldl || kstride % al) return -11;
+  if (!invd_dev) return -12;
+  if (!a_dev) return -13;
+  if (!Y_dev) return -15;
+  if (!Kinv_dev) return -16;
+  if (!alpha_dev) return -17;
+  if (!out_host) return -18;
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  if (batch > 1) {
+    ctx->batch = batch;
+    ctx->bstride = kstride;
+    ctx->bstride_w = Np * G3_LB;
+    ctx->bw_base = (const char*)invd_dev;
+    ctx->bw_bytes = (size_t)batch * Np * G3_LB * es;
+  }
+  const int rec = g3i_prof_begin(ctx, G3_TAG_POTRF, 2.0 * (double)batch * (double)N * N * N / 3.0);
+  rc = g3i_potri(ctx, L_dev, Np, ldl, invd_dev, dt, Y_dev, ldl, Kinv_dev, ldl);
+  g3i_prof_end(ctx, rec);
+  ctx->batch = 0;
+  ctx->bw_base = nullptr;
+  if (rc) return rc;
+  const int nslots = map->nslots;
+  for (int b = 0; b < batch && !rc; ++b) {
+    const char* Yb = (const char*)Y_dev + (size_t)b * kstride * es;
+    const char* Cb = (const char*)Kinv_dev + (size_t)b * kstride * es;
+    const char* ab = (const char*)a_dev + (size_t)b * Np * es;
+    char* alb = (char*)alpha_dev + (size_t)b * Np * es;
+    rc = g3_rows_dot_ss(ctx, Yb, Np, Np, ldl, ab, dt, alb, nullptr);        // alpha = L^-T a
+    if (!rc) rc = g3i_gram_grad(ctx, &progs[b], map, X_dev, N, ldx, d, dt, Cb, ldl, alb, out_host + (size_t)b * nslots);
+  }
+  return rc;
 }

@@ -303,6 +303,27 @@ class Device:
                                   mu.ptr if mu is not None else None, ss.ptr if ss is not None else None)
         _check(self, rc, 'g3_gp_cross')
 
+    def gp_dlogp_batched(self, progs, gmap, X, N, d, K, kstride, W, a, Y, Kinv, alpha):
+        """after gp_factor_batched: per member K^-1, alpha and the kernel-parameter sums; returns (B, nslots)"""
+        B = len(progs)
+        arr = (_lib.KernelProg * B)(*progs)
+        out = (C.c_double * (max(gmap.nslots, 1) * B))()
+        rc = self.lib.g3_gp_dlogp_batched(self.ctx, arr, B, C.byref(gmap), X.ptr, N, X.ld, d, K.ptr, K.ld, kstride,
+                                          W.ptr, a.ptr, _lib.dtype_code(K.dtype), Y.ptr, Kinv.ptr, alpha.ptr, out)
+        _check(self, rc, 'g3_gp_dlogp_batched')
+        return np.array(out[:]).reshape(B, max(gmap.nslots, 1))[:, :gmap.nslots]
+
+    def gp_sample(self, L, M, loc, Z):
+        """loc[:, None] + L Z for host normals Z (M x S); L is the padded device factor"""
+        Z = np.ascontiguousarray(Z, dtype=L.dtype)
+        loc = np.ascontiguousarray(loc, dtype=L.dtype)
+        S = Z.shape[1]
+        out = np.empty((M, S), dtype=L.dtype)
+        rc = self.lib.g3_gp_sample(self.ctx, L.ptr, M, L.ld, loc.ctypes.data, Z.ctypes.data, S,
+                                   _lib.dtype_code(L.dtype), out.ctypes.data)
+        _check(self, rc, 'g3_gp_sample')
+        return out
+
     # ---- gradient of logp (SURVEY.md section 8f rank 1)
     def grad_layout(self, prog):
         m = _lib.GradMap()

@@ -539,3 +539,29 @@ class DistributedGP:
         logp = -0.5 * self.N * np.log(2 * np.pi) - 0.5 * quad - logdet
         self.last.update(logdet=logdet, quad=quad, mean=mean, ss=ss, logp=logp)
         return logp
+
+
+# --------------------------------------------------------------------------- replicas
+def logp_chain_sharded(process, chain, dist, rank, world, prior=False, torch_device=None):
+    """logp of every row of a flat-parameter chain with the rows dealt round-robin to the ranks.
+
+    The second way the path scales: `find_MAP` restarts, `fixed_logp`,
+    `sample_hypers` evaluate MANY independent hyper-parameter vectors on the same observations
+    (g3py/processes/stochastic.py:515-564, 740-783 -- a process pool in the reference).  These are
+    replicas: every rank holds the same `process` (same observations) on its own GPU, evaluates rows
+    rank, rank + world, ... through its batched sweep (`logp_chain` -> g3_gp_factor_batched) and the
+    scalars are combined by one all-reduce of a vector that is zero outside a rank's own rows.
+    No covariance data ever crosses xGMI."""
+    import torch
+    chain = np.atleast_2d(np.asarray(chain, dtype=np.float64))
+    out = np.zeros(len(chain), dtype=np.float64)
+    mine = np.arange(rank, len(chain), world)
+    if len(mine):
+        out[mine] = np.asarray(process.logp_chain(chain[mine], prior=prior), dtype=np.float64)
+    if world > 1:
+        t = torch.from_numpy(out)
+        if torch_device is not None:
+            t = t.to(torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out = t.cpu().numpy()
+    return out

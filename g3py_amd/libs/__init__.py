@@ -1,37 +1,44 @@
-"""Small host-side helpers with the reference's names (g3py/libs/__init__.py:17-60)."""
-from copy import copy
+"""Small host-side helpers carrying the reference's names (boundary: g3py/libs/__init__.py:17-60).
+
+`DictObj` is the return type of `predict`, `scores` and `params`: a dict whose keys also read as
+attributes.  Only the behaviour is the boundary -- keys as attributes, AttributeError (not KeyError)
+for a missing name, `clone()` / `copy()` giving an independent DictObj, construction from a mapping
+passed as `data=`.
+"""
+import copy as _copy
+
+_MISSING = object()
 
 
 class DictObj(dict):
-    """dict with attribute access -- the return type of `predict` and of `params`
-    (g3py/libs/__init__.py:17-44)."""
+    """dict with attribute access."""
+
+    __slots__ = ()
 
     def __init__(self, data=None, *args, **kwargs):
-        super().__init__(*args, **kwargs)
+        dict.__init__(self, *args, **kwargs)
         if data is not None:
-            for k, v in data.items():
-                self[k] = v
+            self.update(data)
 
+    # attribute protocol on top of the mapping: one lookup, AttributeError on a miss
     def __getattr__(self, name):
-        if name in self:
-            return self[name]
-        raise AttributeError("No such attribute: " + name)
+        value = dict.get(self, name, _MISSING)
+        if value is _MISSING:
+            raise AttributeError("No such attribute: " + name)
+        return value
 
-    def __setattr__(self, name, value):
-        self[name] = value
+    __setattr__ = dict.__setitem__
 
     def __delattr__(self, name):
-        if name in self:
-            del self[name]
-        else:
+        if dict.pop(self, name, _MISSING) is _MISSING:
             raise AttributeError("No such attribute: " + name)
 
-    def clone(self):
-        return DictObj(data=self)
-
     def copy(self):
-        return DictObj(data=self)
+        return type(self)(data=self)
+
+    clone = copy
 
 
 def clone(c):
-    return copy(c)
+    """shallow copy (g3py/libs/__init__.py:55-56)"""
+    return _copy.copy(c)

@@ -68,31 +68,6 @@ class EllipticalProcess(StochasticProcess):
         return r
 
     # ---------------------------------------------------------------- helpers
-    def _values(self, params):
-        """transformed-space params dict -> natural-space values by hyper name; also the
-        log-Jacobian term of the FlatExp variables (hypers/__init__.py:199-200)."""
-        memo = getattr(self, '_values_memo', None)
-        if memo is not None and memo[0] is params:          # th_logp -> th_loglike -> ... share one params object
-            return memo[1], memo[2]
-        values, logjac = {}, 0.0
-        for v in self.model.vars:
-            p = np.asarray(params[v.key], dtype=np.float64)
-            if v.positive:
-                with np.errstate(over='ignore'):
-                    e = np.exp(p)
-                logjac += float(np.sum(np.where(e > 1e-6, 0.0, -np.inf)))
-                values[v.name] = e
-            else:
-                values[v.name] = p
-        # optional L1 / L2 potentials enter th_logp like pm.Potential terms (stochastic.py:305)
-        for _, reg, c, sel in self.model.potentials:
-            if reg == 'L1':
-                logjac += c * -float(sum(np.sum(np.abs(values[h.name])) for h in sel))
-            elif reg == 'L2':
-                logjac += c * -float(sum(np.sum(np.asarray(values[h.name]) ** 2) for h in sel))
-        self._values_memo = (params, values, logjac)
-        return values, logjac
-
     def _x(self, a):
         a = np.asarray(a, dtype=self.dtype)
         return a.reshape(len(a), 1) if a.ndim < 2 else np.ascontiguousarray(a)

@@ -71,31 +71,18 @@ class GaussianProcess(EllipticalProcess):
         jittered factor the same way -- and zero when logp takes its constant -1e30 branch.
         K^-1 and the kernel-parameter sums are computed on the device (g3_gp_dlogp)."""
         values, _ = self._values(params)
-        nat = {v.name: np.zeros(v.shape, dtype=np.float64) for v in self.model.vars}
-        for _, reg, c, sel in self.model.potentials:                # hypers/__init__.py:97-109
-            for h in sel:
-                hv = np.asarray(values[h.name], dtype=np.float64)
-                nat[h.name] = nat[h.name] + (-c * np.sign(hv) if reg == 'L1' else -2.0 * c * hv)
+        nat = self._potential_gradient(values)
         if not prior:
             ll = self.th_loglike(space, inputs, outputs, vector, params)
             if np.isfinite(ll) and ll != self.dtype.type(SENTINEL):
                 self._dloglike(values, inputs, outputs, nat)
-        flat = []
-        for v in self.model.vars:
-            g = np.asarray(nat[v.name], dtype=np.float64).reshape(v.shape)
-            if v.positive:
-                g = g * np.asarray(values[v.name], dtype=np.float64)
-            flat.append(g.reshape(-1))
-        flat = np.concatenate(flat) if flat else np.zeros(0)
-        flat = np.where(np.isnan(flat), 0.0, np.where(np.isinf(flat), float(np.float32(1e10)), flat))   # tt_to_num
-        return flat.astype(self.dtype)
+        return self._flat_gradient(values, nat)
 
     def _dlogp_scale(self, values, c, st, nat):
         return 1.0
 
     def _dloglike(self, values, inputs, outputs, nat):
         """adds d loglike / d (natural-space hyper) into `nat`"""
-        from ..device import spec_leaves
         dev = self.device
         c = self._factor(values, inputs, outputs)
         st = self._solve(c, values, 'logp')
@@ -118,7 +105,12 @@ class GaussianProcess(EllipticalProcess):
             c['grad'] = dict(prog=prog, gmap=gmap, slots=slots,
                              alpha=np.sqrt(s) * dev.download(alpha, 1, N)[0].astype(np.float64))
         g = c['grad']
-        prog, gmap, slots, alpha = g['prog'], g['gmap'], g['slots'], g['alpha']   # alpha = s K^-1 delta
+        self._chain_rule(values, inputs, outputs, nat, g['prog'], g['gmap'], g['slots'], g['alpha'], d)
+
+    def _chain_rule(self, values, inputs, outputs, nat, prog, gmap, slots, alpha, d):
+        """host part of d loglike: route the device's per-leaf parameter sums (`slots`) to the model's
+        variables and add the O(N) location / warping terms on alpha = s K^-1 delta"""
+        from ..device import spec_leaves
         # kernel hypers: leaf parameter slots -> the HyperVars that fed them
         by_name = {v.name: v for v in self.model.vars}
         refs = spec_leaves(self.f_kernel_noise.spec(_Refs(), d))
@@ -148,6 +140,82 @@ class GaussianProcess(EllipticalProcess):
             for h, dinv, dlogdet in self.f_mapping.grad(y, values):
                 if getattr(h, 'name', None) in by_name:
                     nat[h.name] = nat[h.name] + (-alpha.dot(np.asarray(dinv, dtype=np.float64)) + float(dlogdet))
+
+    def _flat_gradient(self, values, nat):
+        """natural-space gradients -> flat vector in creation order, transformed space, tt_to_num'ed"""
+        flat = []
+        for v in self.model.vars:
+            g = np.asarray(nat[v.name], dtype=np.float64).reshape(v.shape)
+            if v.positive:
+                g = g * np.asarray(values[v.name], dtype=np.float64)
+            flat.append(g.reshape(-1))
+        flat = np.concatenate(flat) if flat else np.zeros(0)
+        flat = np.where(np.isnan(flat), 0.0, np.where(np.isinf(flat), float(np.float32(1e10)), flat))   # tt_to_num
+        return flat.astype(self.dtype)
+
+    def _potential_gradient(self, values):
+        nat = {v.name: np.zeros(v.shape, dtype=np.float64) for v in self.model.vars}
+        for _, reg, c, sel in self.model.potentials:                # hypers/__init__.py:97-109
+            for h in sel:
+                hv = np.asarray(values[h.name], dtype=np.float64)
+                nat[h.name] = nat[h.name] + (-c * np.sign(hv) if reg == 'L1' else -2.0 * c * hv)
+        return nat
+
+    def dlogp_chain(self, chain, batch=None):
+        """one dlogp per row of a flat-parameter chain, shape (rows, ndim) -- what fixed_dlogp averages
+        (stochastic.py:554-564: a loop of single gradients in the reference).  `batch` rows at a time
+        share ONE Gram launch, ONE factorisation sweep (g3_gp_factor_batched) and ONE K^-1 sweep
+        (g3_gp_dlogp_batched); the O(N) chain-rule pieces stay on the host."""
+        chain = np.atleast_2d(np.asarray(chain, dtype=np.float64))
+        n_rows = len(chain)
+        out = np.zeros((n_rows, self.active.ndim), dtype=self.dtype)
+        custom_scale = type(self)._dlogp_scale is not GaussianProcess._dlogp_scale
+        if not self.is_observed or n_rows == 0 or custom_scale:
+            for i in range(n_rows):          # Student-t scaling differs per member: one at a time
+                out[i] = self.dlogp(chain[i], array=True)
+            return out
+        dev = self.device
+        X = self._x(self.inputs)
+        y = np.asarray(self.outputs, dtype=self.dtype).reshape(-1)
+        N, d = X.shape
+        Np = _lib.roundup(N)
+        kstride = (Np + _lib.G3_RHS_PAD) * Np
+        if batch is None:
+            batch = int(4e9 // (3 * kstride * self.dtype.itemsize))
+        batch = max(1, min(int(batch), n_rows, _lib.G3_MAX_BATCH))
+        Xd = dev.upload(X)
+        K, Y, Ki = (dev.alloc(batch * (Np + _lib.G3_RHS_PAD), Np, self.dtype) for _ in range(3))
+        W = dev.alloc(batch * Np, _lib.G3_PAD, self.dtype)
+        a, al = dev.alloc(batch, Np, self.dtype), dev.alloc(batch, Np, self.dtype)
+        for lo in range(0, n_rows, batch):
+            live, progs, deltas, vals = [], [], [], []
+            for i in range(lo, min(lo + batch, n_rows)):
+                values, _ = self._values(self.active.array_to_dict(chain[i]))
+                with np.errstate(all='ignore'):
+                    delta = np.asarray(self.f_mapping.inv(y, values), dtype=self.dtype) - self.f_location(X, values)
+                    det_m = self.f_mapping.logdet_dinv(y, values)
+                if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):     # constant -1e30 branch
+                    out[i] = self._flat_gradient(values, self._potential_gradient(values))
+                    continue
+                live.append(i)
+                progs.append(self._prog(self.f_kernel_noise, values, d))
+                deltas.append(delta)
+                vals.append(values)
+            if not live:
+                continue
+            stats = dev.gp_factor_batched(progs, Xd, N, d, dev.upload(np.stack(deltas).astype(self.dtype)), K, kstride, W, a)
+            gmap = dev.grad_layout(progs[0])
+            slots = dev.gp_dlogp_batched(progs, gmap, Xd, N, d, K, kstride, W, a, Y, Ki, al)
+            alphas = dev.download(al, len(live), N).astype(np.float64)
+            for j, i in enumerate(live):
+                nat = self._potential_gradient(vals[j])
+                st = stats[j]
+                if np.isfinite(st['logdet']) and st['nonfinite'] == 0:
+                    self._chain_rule(vals[j], X, y, nat, progs[j], gmap, slots[j], alphas[j], d)
+                out[i] = self._flat_gradient(vals[j], nat)
+        for b in (K, Y, Ki, W, a, al):
+            b.free()
+        return out
 
     # ---- many hyper-parameter vectors on the same observations (stochastic.py:515-520)
     def logp_chain(self, chain, prior=False, batch=None):
@@ -228,17 +296,12 @@ class GaussianProcess(EllipticalProcess):
         if rand is None:
             rand = np.random.randn(M, samples)
         rand = np.asarray(rand, dtype=self.dtype)
-        S = rand.shape[1]
         loc = self.location(params, space, inputs, outputs, prior=prior, noise=noise)
-        Ld, _, Mp = self._cholesky_dev(params, space, inputs, outputs, prior=prior, noise=noise)   # stays on the device
-        dev = self.device
-        Sp = _lib.roundup(S, 64)
-        Zt = dev.upload(np.ascontiguousarray(rand.T), pad_rows=Sp, pad_cols=Mp)
-        out = dev.alloc(Sp, Mp, self.dtype)
-        dev.gemm_nt(out, Zt, Ld, Sp, Mp, Mp)                      # (L Z)^T
-        g = loc[:, None] + dev.download(out, S, M).T
-        return np.array([self.mapping(params, space, inputs, outputs=k.T) for k in g.T]).T
-
+        Ld, _, _ = self._cholesky_dev(params, space, inputs, outputs, prior=prior, noise=noise)   # stays on the device
+        g = self.device.gp_sample(Ld, M, loc, rand)                # loc + L Z, one call (g3_gp_sample)
+        # the mapping is element-wise: one vectorised pass over the M x S draws instead of the
+        # reference's per-sample loop (gaussian.py:97)
+        return self.mapping(params, space, inputs, outputs=g)
 
     _methods = EllipticalProcess._methods + (('dlogp', 'th_dlogp'),)
 

@@ -13,58 +13,70 @@ from .metrics import Delta, Difference, ARD_L1, ARD_L2
 pi = np.pi
 
 
+def _free_slot(owner, attr, label, shape=()):
+    """A hyper-parameter slot of a parametric function: `None` means "make it a free positive
+    variable called <label>"; whatever ends up in the slot is registered in `owner.hypers` when it
+    is a free variable (a number stays a constant).  One helper for var / alpha / freq / rate."""
+    value = getattr(owner, attr)
+    if value is None:
+        value = Hypers.FlatExp(label, shape=shape)
+        setattr(owner, attr, value)
+    if isinstance(value, HyperVar):
+        owner.hypers.append(value)
+    return value
+
+
+def _combine(left, right, node_kernels, node_scalar):
+    """`left (op) right` of the kernel algebra: two kernels make a composition (operand order kept),
+    a kernel and a number make a scale / shift of the kernel (boundary: kernels.py:51-75)"""
+    lk, rk = isinstance(left, Kernel), isinstance(right, Kernel)
+    if lk and rk:
+        return node_kernels(left, right)
+    return node_scalar(left, right) if lk else node_scalar(right, left)
+
+
 class Kernel(Hypers):
+    """covariance function = var * (something of a metric); `metric` may be a class (instantiated on
+    the same columns) or a ready instance"""
+
     def __init__(self, x=None, name=None, metric=Delta, var=None):
-        if type(metric) is type:
-            self.metric = metric(x)
-        else:
-            self.metric = metric
+        self.metric = metric(x) if isinstance(metric, type) else metric
         super().__init__(x, name)
         self.var = var
 
     def check_hypers(self, parent=''):
-        if self.var is None:
-            self.var = Hypers.FlatExp(parent + self.name + '_var')
-        if isinstance(self.var, HyperVar):
-            self.hypers += [self.var]
+        _free_slot(self, 'var', parent + self.name + '_var')
         self.metric.check_hypers(parent + self.name + '_')
-        self.hypers += [h for h in self.metric.hypers if isinstance(h, HyperVar)]
+        self.hypers.extend(h for h in self.metric.hypers if isinstance(h, HyperVar))
 
     def check_dims(self, x=None):
         super().check_dims(x)
         self.metric.check_dims(x)
 
     def default_hypers(self, x=None, y=None):
+        defaults = dict(self.metric.default_hypers(x, y))
         if isinstance(self.var, HyperVar):
-            return {self.var: y.var(), **self.metric.default_hypers(x, y)}
-        return self.metric.default_hypers(x, y)
+            defaults[self.var] = y.var()
+        return defaults
 
-    # ---- algebra (kernels.py:51-75)
+    # ---- algebra
     def __mul__(self, other):
-        if issubclass(type(other), Kernel):
-            return KernelProd(self, other)
-        return KernelScale(self, other)
-    __imul__ = __mul__
+        return _combine(self, other, KernelProd, KernelScale)
 
     def __rmul__(self, other):
-        if issubclass(type(other), Kernel):
-            return KernelProd(other, self)
-        return KernelScale(self, other)
+        return _combine(other, self, KernelProd, KernelScale)
 
     def __add__(self, other):
-        if issubclass(type(other), Kernel):
-            return KernelSum(self, other)
-        return KernelShift(self, other)
-    __iadd__ = __add__
+        return _combine(self, other, KernelSum, KernelShift)
 
     def __radd__(self, other):
-        if issubclass(type(other), Kernel):
-            return KernelSum(other, self)
-        return KernelShift(self, other)
+        return _combine(other, self, KernelSum, KernelShift)
 
-    def __str__(self):
-        return str(self.__class__.__name__) + '[m=' + str(self.metric) + ',h=' + str(self.hypers) + ']'
-    __repr__ = __str__
+    __imul__, __iadd__ = __mul__, __add__
+
+    def __repr__(self):
+        return '%s[m=%s,h=%s]' % (type(self).__name__, self.metric, self.hypers)
+    __str__ = __repr__
 
     # ---- evaluation
     def spec(self, values, d):
@@ -74,20 +86,19 @@ class Kernel(Hypers):
         """Kernel.cov(x1, x2=None) -- kernels.py:106-110: Gram matrix on the GPU.
         `params`: natural-space values keyed by hyper name (only needed for free hypers)."""
         from ...device import Device, compile_spec
-        from ..._lib import G3_GRAM_SCRUB
         dev = device or Device.default()
-        x1 = np.asarray(x1, dtype=dtype)
-        x1 = x1[:, None] if x1.ndim == 1 else x1
+
+        def columns(x):
+            x = np.asarray(x, dtype=dtype)
+            return x[:, None] if x.ndim == 1 else x
+        x1 = columns(x1)
         d = x1.shape[1]
         prog = compile_spec(self.spec(params or {}, d), d)
         X1 = dev.upload(x1)
-        X2 = None
-        n2 = x1.shape[0]
+        X2, n2 = None, x1.shape[0]
         if x2 is not None:
-            x2 = np.asarray(x2, dtype=dtype)
-            x2 = x2[:, None] if x2.ndim == 1 else x2
-            X2 = dev.upload(x2)
-            n2 = x2.shape[0]
+            x2 = columns(x2)
+            X2, n2 = dev.upload(x2), x2.shape[0]
         out = dev.alloc(x1.shape[0], n2, dtype)
         dev.gram(prog, X1, X2, d, out, x1.shape[0], n2, 0)
         return dev.download(out)
@@ -106,77 +117,87 @@ class KernelStationary(Kernel):
                 self.metric.dims_index(d))
 
 
-class KernelOperation(Kernel):
+class _KernelNode(Kernel):
+    """Interior node of a kernel expression: it owns no hyper-parameters, it forwards every
+    bookkeeping request to its kernel operands (`parts`) and joins the answers.  `op` is the
+    symbol shown in names; constants of scale / shift nodes live in `element`."""
+    op = 'op'
+
+    def _init_node(self):
+        self.hypers = []
+        self.potential = None
+
+    @property
+    def parts(self):
+        raise NotImplementedError
+
+    def _labels(self, how):
+        raise NotImplementedError
+
+    def check_hypers(self, parent=''):
+        collected = []
+        for part in self.parts:
+            part.check_hypers(parent=parent)
+            collected += part.hypers
+        self.hypers = collected if len(self.parts) > 1 else self.parts[0].hypers
+
+    def check_dims(self, x=None):
+        for part in self.parts:
+            part.check_dims(x)
+
+    def default_hypers_dims(self, x=None, y=None):
+        merged = {}
+        for part in self.parts:
+            merged.update(part.default_hypers_dims(x, y))
+        return merged
+
+    def check_potential(self):
+        Hypers.check_potential(self)
+        for part in self.parts:
+            part.check_potential()
+
+    @property
+    def name(self):
+        return (' ' + self.op + ' ').join(self._labels(lambda k: k.name))
+
+    def __repr__(self):
+        return (' ' + self.op + ' ').join(self._labels(str))
+    __str__ = __repr__
+
+
+class KernelOperation(_KernelNode):
+    """a kernel combined with a constant (`element`)"""
+
     def __init__(self, _k, _element):
-        self.k = _k
-        self.element = _element
-        self.hypers = []
-        self.potential = None
-        self.op = 'op'
-
-    def check_hypers(self, parent=''):
-        self.k.check_hypers(parent=parent)
-        self.hypers = self.k.hypers
-
-    def check_dims(self, x=None):
-        self.k.check_dims(x)
-
-    def default_hypers_dims(self, x=None, y=None):
-        return self.k.default_hypers_dims(x, y)
-
-    def check_potential(self):
-        super().check_potential()
-        self.k.check_potential()
+        self.k, self.element = _k, _element
+        self._init_node()
 
     @property
-    def name(self):
-        return str(self.element) + " " + self.op + " " + self.k.name
+    def parts(self):
+        return (self.k,)
 
-    def __str__(self):
-        return str(self.element) + " " + self.op + " " + str(self.k)
-    __repr__ = __str__
+    def _labels(self, how):
+        return [str(self.element), how(self.k)]
 
 
-class KernelComposition(Kernel):
+class KernelComposition(_KernelNode):
+    """two kernels combined"""
+
     def __init__(self, _k1, _k2):
-        self.k1 = _k1
-        self.k2 = _k2
-        self.hypers = []
-        self.potential = None
-        self.op = 'op'
-
-    def check_hypers(self, parent=''):
-        self.k1.check_hypers(parent=parent)
-        self.k2.check_hypers(parent=parent)
-        self.hypers = self.k1.hypers + self.k2.hypers
-
-    def check_dims(self, x=None):
-        self.k1.check_dims(x)
-        self.k2.check_dims(x)
-
-    def default_hypers_dims(self, x=None, y=None):
-        return {**self.k1.default_hypers_dims(x, y), **self.k2.default_hypers_dims(x, y)}
-
-    def check_potential(self):
-        super().check_potential()
-        self.k1.check_potential()
-        self.k2.check_potential()
+        self.k1, self.k2 = _k1, _k2
+        self._init_node()
 
     @property
-    def name(self):
-        return self.k1.name + " " + self.op + " " + self.k2.name
+    def parts(self):
+        return (self.k1, self.k2)
 
-    def __str__(self):
-        return str(self.k1) + " " + self.op + " " + str(self.k2)
-    __repr__ = __str__
+    def _labels(self, how):
+        return [how(self.k1), how(self.k2)]
 
 
 class KernelScale(KernelOperation):
     """element * k.cov -- kernels.py:192-200"""
-
-    def __init__(self, _k, _element):
-        super().__init__(_k, _element)
-        self.op = '*'
+    op = '*'
 
     def spec(self, values, d):
         return ('scale', float(self.element), self.k.spec(values, d))
@@ -184,24 +205,22 @@ class KernelScale(KernelOperation):
 
 class KernelShift(KernelOperation):
     """element + k.cov -- kernels.py:203-211"""
-
-    def __init__(self, _k, _element):
-        super().__init__(_k, _element)
-        self.op = '+'
+    op = '+'
 
     def spec(self, values, d):
         return ('shift', float(self.element), self.k.spec(values, d))
 
 
 class KernelProd(KernelComposition):
-    """k1.cov * k2.cov -- kernels.py:214-229"""
+    """k1.cov * k2.cov -- kernels.py:214-229.  Two free variances in a product are not
+    identifiable: when neither factor has its variance set, the second one is pinned to 1."""
+    op = '*'
 
     def __init__(self, _k1, _k2):
         super().__init__(_k1, _k2)
-        if hasattr(self.k1, 'var') and hasattr(self.k2, 'var'):
-            if self.k1.var is None and self.k2.var is None:
-                self.k2.var = 1.0
-        self.op = '*'
+        unset = [getattr(k, 'var', 0) is None for k in (_k1, _k2)]
+        if all(unset):
+            _k2.var = 1.0
 
     def spec(self, values, d):
         return ('prod', self.k1.spec(values, d), self.k2.spec(values, d))
@@ -209,10 +228,7 @@ class KernelProd(KernelComposition):
 
 class KernelSum(KernelComposition):
     """k1.cov + k2.cov -- kernels.py:232-244"""
-
-    def __init__(self, _k1, _k2):
-        super().__init__(_k1, _k2)
-        self.op = '+'
+    op = '+'
 
     def spec(self, values, d):
         return ('sum', self.k1.spec(values, d), self.k2.spec(values, d))
@@ -250,13 +266,12 @@ class RQ(KernelStationary):
 
     def check_hypers(self, parent=''):
         super().check_hypers(parent=parent)
-        if self.alpha is None:
-            self.alpha = Hypers.FlatExp(parent + self.name + '_alpha')
-        if isinstance(self.alpha, HyperVar):
-            self.hypers += [self.alpha]
+        _free_slot(self, 'alpha', parent + self.name + '_alpha')
 
     def default_hypers(self, x=None, y=None):
-        return {self.alpha: 1.0, **super().default_hypers(x, y)}
+        defaults = super().default_hypers(x, y)
+        defaults[self.alpha] = 1.0
+        return defaults
 
     def spec(self, values, d):
         return ('RQ', value_of(self.var, values), value_of(self.metric.rate, values),
@@ -302,22 +317,22 @@ class KernelPeriodic(KernelStationary):
 
     def check_hypers(self, parent=''):
         super().check_hypers(parent=parent)
-        if self.freq is None:
-            self.freq = Hypers.FlatExp(parent + self.name + '_freq', shape=self.shape)
-        if self.rate is None:
-            self.rate = Hypers.FlatExp(parent + self.name + '_rate', shape=self.shape)
-        if isinstance(self.rate, HyperVar):
-            self.hypers += [self.rate]
-        if isinstance(self.freq, HyperVar):
-            self.hypers += [self.freq]
+        # creation order freq, rate fixes the variables' positions in the flat parameter vector
+        # (boundary: the reference creates them in this order and lists rate first in `hypers`)
+        made = {a: getattr(self, a) is None for a in ('freq', 'rate')}
+        for attr in ('freq', 'rate'):
+            if made[attr]:
+                setattr(self, attr, Hypers.FlatExp(parent + self.name + '_' + attr, shape=self.shape))
+        self.hypers.extend(h for h in (self.rate, self.freq) if isinstance(h, HyperVar))
 
     def default_hypers(self, x=None, y=None):
-        r = {}
-        if isinstance(self.freq, HyperVar):
-            r[self.freq] = 1 / (x.max(axis=0) - x.min(axis=0))
-        if isinstance(self.rate, HyperVar):
-            r[self.rate] = 1 / np.abs(x[1:] - x[:-1]).mean(axis=0)
-        return {**r, **super().default_hypers(x, y)}
+        # one full period over the observed span; decay length of the mean spacing of consecutive rows
+        guesses = (('freq', lambda: 1 / (x.max(axis=0) - x.min(axis=0))),
+                   ('rate', lambda: 1 / np.abs(np.diff(x, axis=0)).mean(axis=0)))
+        defaults = {getattr(self, a): guess() for a, guess in guesses if isinstance(getattr(self, a), HyperVar)}
+        for k, v in super().default_hypers(x, y).items():
+            defaults[k] = v
+        return defaults
 
     def spec(self, values, d):
         if self.uses_rate:

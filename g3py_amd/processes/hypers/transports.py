@@ -133,6 +133,26 @@ class TLocation(TElemwise):
         return 0.0
 
 
+class TScale(TElemwise):
+    """y = x * s(inputs) -- transports.py:165-181; `scale` is any parametric function of the inputs
+    (called as scale(inputs, values) like the means); log det dT^-1 = -sum log s(inputs)"""
+
+    def __init__(self, scale=None, x=None, name=None):
+        super().__init__(x, name)
+        self.scale = scale
+        self.parametrics.append(scale)
+
+    def __call__(self, inputs, outputs, noise=False, values=None):
+        return outputs * self.scale(np.asarray(inputs), values)
+
+    def inv(self, inputs, outputs, noise=False, values=None):
+        return outputs / self.scale(np.asarray(inputs), values)
+
+    def logdet_dinv(self, inputs, outputs, values=None):
+        with np.errstate(all='ignore'):
+            return -np.sum(np.log(self.scale(np.asarray(inputs), values)))
+
+
 class TMapping(TElemwise):
     """y = mapping(x) -- transports.py:184-197"""
 
@@ -151,7 +171,26 @@ class TMapping(TElemwise):
         return self.mapping.logdet_dinv(np.asarray(outputs), values)
 
 
-class TKernel(Transport):
+class TLinear(Transport):
+    """marker: transports that are linear in the reference vector (transports.py:137-138)"""
+
+
+class TNoLinear(Transport):
+    """marker: non-linear transports (transports.py:141-142)"""
+
+
+class TTriangular(TNoLinear):
+    """triangular transport from a generator (transports.py:260-263).  The reference defines the
+    constructor only (no map, inverse or log-determinant): kept as the same shell -- calling it
+    raises NotImplementedError through Transport."""
+
+    def __init__(self, generator, x=None, name=None):
+        super().__init__(x, name)
+        self.generator = generator
+        self.parametrics.append(generator)
+
+
+class TKernel(TLinear):
     """y = chol(K(inputs)) x -- transports.py:200-257, on the device"""
 
     def __init__(self, kernel, noisy=False, x=None, name=None, dtype=np.float64, device=None):

@@ -209,46 +209,34 @@ class StochasticProcess:
     def filter_params(self, params):
         return {k: params[k] for k in self.model.test_point}   # models.py:471-473
 
-    # ---- space and observations (stochastic.py:150-201, 219-259: copy on set)
+    # ---- space and observations (boundary: stochastic.py:150-201, 219-259 -- copy on set)
+    # how each array handed to set_space is normalised: True = matrix (a vector becomes one column),
+    # False = vector (a matrix is flattened to its first axis)
+    _ARRAY_RANK2 = (('space', True), ('hidden', False), ('order', False), ('inputs', True),
+                    ('outputs', False), ('index', False))
+    # a vector that, when not supplied for a one-dimensional space, mirrors a matrix; and the
+    # matrix whose length it must match otherwise (it falls back to 0..n-1)
+    _MIRRORS = (('order', 'space'), ('index', 'inputs'))
+
     def set_space(self, space=None, hidden=None, order=None, inputs=None, outputs=None, index=None):
-        if space is not None:
-            space = np.asarray(space)
-            if len(space.shape) < 2:
-                space = space.reshape(len(space), 1)
-            self.space = space
-        if hidden is not None:
-            hidden = np.asarray(hidden)
-            if len(hidden.shape) > 1:
-                hidden = hidden.reshape(len(hidden))
-            self.hidden = hidden
-        if order is not None:
-            order = np.asarray(order)
-            if len(order.shape) > 1:
-                order = order.reshape(len(order))
-            self.order = order
-        elif self.nspace == 1:
-            self.order = self.space.reshape(len(self.space))
-        if inputs is not None:
-            inputs = np.asarray(inputs)
-            if len(inputs.shape) < 2:
-                inputs = inputs.reshape(len(inputs), 1)
-            self.inputs = inputs
-        if outputs is not None:
-            outputs = np.asarray(outputs)
-            if len(outputs.shape) > 1:
-                outputs = outputs.reshape(len(outputs))
-            self.outputs = outputs
-        if index is not None:
-            index = np.asarray(index)
-            if len(index.shape) > 1:
-                index = index.reshape(len(index))
-            self.index = index
-        elif self.nspace == 1:
-            self.index = self.inputs.reshape(len(self.inputs))
-        if len(self.order) != len(self.space):
-            self.order = np.arange(len(self.space))
-        if len(self.index) != len(self.inputs):
-            self.index = np.arange(len(self.inputs))
+        given = dict(space=space, hidden=hidden, order=order, inputs=inputs, outputs=outputs, index=index)
+        for name, rank2 in self._ARRAY_RANK2:
+            a = given[name]
+            if a is None:
+                continue
+            a = np.asarray(a)
+            n = len(a)
+            if rank2 and a.ndim < 2:
+                a = a.reshape(n, 1)
+            elif not rank2 and a.ndim > 1:
+                a = a.reshape(n)
+            setattr(self, name, a)
+        for vec, mat in self._MIRRORS:
+            m = getattr(self, mat)
+            if given[vec] is None and self.nspace == 1:
+                setattr(self, vec, m.reshape(len(m)))
+            if len(getattr(self, vec)) != len(m):
+                setattr(self, vec, np.arange(len(m)))
 
     def observed(self, inputs=None, outputs=None, order=None, index=None, hidden=None):
         self.set_space(inputs=inputs, outputs=outputs, order=order, index=index, hidden=hidden)
@@ -273,6 +261,34 @@ class StochasticProcess:
     @hidden.setter
     def hidden(self, value):
         self.np_hidden = value
+
+    def _values(self, params):
+        """transformed-space params dict -> natural-space values by hyper name, and the terms every
+        process adds to logp besides the observed density: the log-Jacobian of the FlatExp variables
+        (hypers/__init__.py:199-200) and the L1 / L2 potentials registered by check_potential
+        (hypers/__init__.py:94-109; stochastic.py:305).  Shared by the elliptical and the transport
+        processes."""
+        memo = getattr(self, '_values_memo', None)
+        if memo is not None and memo[0] is params:          # th_logp -> th_loglike -> ... share one params object
+            return memo[1], memo[2]
+        values, logjac = {}, 0.0
+        for v in self.model.vars:
+            p = np.asarray(params[v.key], dtype=np.float64)
+            if v.positive:
+                with np.errstate(over='ignore'):
+                    e = np.exp(p)
+                logjac += float(np.sum(np.where(e > 1e-6, 0.0, -np.inf)))
+                values[v.name] = e
+            else:
+                values[v.name] = p
+        # optional L1 / L2 potentials enter th_logp like pm.Potential terms (stochastic.py:305)
+        for _, reg, c, sel in self.model.potentials:
+            if reg == 'L1':
+                logjac += c * -float(sum(np.sum(np.abs(values[h.name])) for h in sel))
+            elif reg == 'L2':
+                logjac += c * -float(sum(np.sum(np.asarray(values[h.name]) ** 2) for h in sel))
+        self._values_memo = (params, values, logjac)
+        return values, logjac
 
     # ---- to be provided by subclasses
     def default_hypers(self):
@@ -329,108 +345,106 @@ class StochasticProcess:
             name = 'array_' + name
         return self.compiles[name]
 
+    def _call_defaults(self, params, space, inputs, outputs, prior, array):
+        """fill in what a caller left out (boundary: stochastic.py:387-402): current parameters (as a
+        flat vector when array=True; a supplied dict is cut down to the model's variables), the
+        stored space / observations, and the prior when nothing has been observed"""
+        if params is None:
+            params = self.active.dict_to_array(self.params) if array else self.params
+        elif not array:
+            params = self.filter_params(params)
+        unobserved_call = inputs is None and not self.is_observed
+        stored = (self.space, self.inputs, self.outputs)
+        space, inputs, outputs = (s if a is None else a for a, s in zip((space, inputs, outputs), stored))
+        return params, space, inputs, outputs, (True if unobserved_call else prior)
+
     @staticmethod
     def _method_name(method=None):
-        def lambda_method(self, params=None, space=None, inputs=None, outputs=None, vector=[], prior=False,
-                          noise=False, array=False, *args, **kwargs):
-            if params is None:
-                if array:
-                    params = self.active.dict_to_array(self.params)
-                else:
-                    params = self.params
-            elif not array:
-                params = self.filter_params(params)
-            if inputs is None and not self.is_observed:
-                prior = True
-            if space is None:
-                space = self.space
-            if inputs is None:
-                inputs = self.inputs
-            if outputs is None:
-                outputs = self.outputs
+        """public statistic bound to an instance: signature (params, space, inputs, outputs, vector,
+        prior, noise, array) as in the reference; resolves defaults, then runs the registry entry"""
+        def statistic(self, params=None, space=None, inputs=None, outputs=None, vector=[], prior=False,
+                      noise=False, array=False, *args, **kwargs):
+            params, space, inputs, outputs, prior = self._call_defaults(params, space, inputs, outputs, prior, array)
             kwargs.pop('simulations', None)   # accepted and unused, as in the reference's th_* methods
-            return self._compiled(method, prior, noise, array, args, kwargs)(params, space, inputs, outputs, vector)
-        return lambda_method
+            fn = self._compiled(method, prior, noise, array, args, kwargs)
+            return fn(params, space, inputs, outputs, vector)
+        statistic.__name__ = str(method)
+        return statistic
 
     @property
     def executed(self):
         return {k: v.executed for k, v in self.compiles.items()}
 
-    # ---- predict (stochastic.py:444-513)
+    # ---- predict (boundary: stochastic.py:444-513 -- switches and returned keys)
+    # (switch, returned key, method, extra keyword arguments, noise override)
+    _PREDICT_TABLE = (
+        ('mean', 'mean', 'mean', {}, None),
+        ('var', 'variance', 'variance', {}, None),
+        ('std', 'std', 'std', {}, None),
+        ('cov', 'covariance', 'covariance', {}, None),
+        ('median', 'median', 'median', {}, None),
+        ('quantiles', 'quantile_up', 'quantiler', {'q': 0.975}, None),
+        ('quantiles', 'quantile_down', 'quantiler', {'q': 0.025}, None),
+        ('quantiles_noise', 'noise_std', 'std', {}, True),
+        ('quantiles_noise', 'noise_up', 'quantiler', {'q': 0.975}, True),
+        ('quantiles_noise', 'noise_down', 'quantiler', {'q': 0.025}, True),
+    )
+
     def predict(self, params=None, space=None, inputs=None, outputs=None, mean=True, std=True, var=False,
                 cov=False, median=False, quantiles=False, quantiles_noise=False, samples=0, distribution=False,
                 prior=False, noise=False, simulations=None):
-        if params is None:
-            params = self.params
-        if not self.is_observed:
-            prior = True
-        if space is None:
-            space = self.space
-        if inputs is None:
-            inputs = self.inputs
-        if outputs is None:
-            outputs = self.outputs
-        n_simulations = 1
-        if type(simulations) is int:
-            n_simulations = simulations
-            simulations = self.sampler(params, space, inputs, outputs, prior=prior, noise=noise, samples=simulations)
+        params = self.params if params is None else params
+        prior = prior or not self.is_observed
+        space = self.space if space is None else space
+        inputs = self.inputs if inputs is None else inputs
+        outputs = self.outputs if outputs is None else outputs
+        where = (params, space, inputs, outputs)
+        if type(simulations) is int:    # the reference draws them here and then ignores them downstream
+            self.sampler(*where, prior=prior, noise=noise, samples=simulations)
+        switches = dict(mean=mean, var=var, std=std, cov=cov, median=median, quantiles=quantiles,
+                        quantiles_noise=quantiles_noise)
         values = DictObj()
-        if mean:
-            values['mean'] = self.mean(params, space, inputs, outputs, prior=prior, noise=noise)
-        if var:
-            values['variance'] = self.variance(params, space, inputs, outputs, prior=prior, noise=noise)
-        if std:
-            values['std'] = self.std(params, space, inputs, outputs, prior=prior, noise=noise)
-        if cov:
-            values['covariance'] = self.covariance(params, space, inputs, outputs, prior=prior, noise=noise)
-        if median:
-            values['median'] = self.median(params, space, inputs, outputs, prior=prior, noise=noise)
-        if quantiles:
-            values['quantile_up'] = self.quantiler(params, space, inputs, outputs, q=0.975, prior=prior, noise=noise)
-            values['quantile_down'] = self.quantiler(params, space, inputs, outputs, q=0.025, prior=prior, noise=noise)
-        if quantiles_noise:
-            values['noise_std'] = self.std(params, space, inputs, outputs, prior=prior, noise=True)
-            values['noise_up'] = self.quantiler(params, space, inputs, outputs, q=0.975, prior=prior, noise=True)
-            values['noise_down'] = self.quantiler(params, space, inputs, outputs, q=0.025, prior=prior, noise=True)
+        for switch, key, method, extra, noise_override in self._PREDICT_TABLE:
+            if switches[switch]:
+                values[key] = getattr(self, method)(*where, prior=prior,
+                                                    noise=noise if noise_override is None else noise_override, **extra)
         if samples > 0:
-            values['samples'] = self.sampler(params, space, inputs, outputs, samples=samples, prior=prior, noise=noise)
+            values['samples'] = self.sampler(*where, samples=samples, prior=prior, noise=noise)
         if distribution:
-            values['logpredictive'] = lambda x: self.logpredictive(params, space, inputs, outputs, vector=x,
-                                                                   prior=prior, noise=True)
+            def logpredictive(x, _where=where, _prior=prior):
+                return self.logpredictive(*_where, vector=x, prior=_prior, noise=True)
+            values['logpredictive'] = logpredictive
         return values
 
     def sample(self, params=None, space=None, inputs=None, outputs=None, samples=1, prior=False, noise=False):
-        """models.py:443-446"""
-        S = self.predict(params=params, space=space, inputs=inputs, outputs=outputs, mean=False, std=False, var=False,
-                         cov=False, median=False, quantiles=False, quantiles_noise=False, samples=samples, prior=prior,
-                         noise=noise)
-        return S['samples']
+        """draws only (boundary: models.py:443-446)"""
+        return self.predict(params=params, space=space, inputs=inputs, outputs=outputs, mean=False, std=False,
+                            samples=samples, prior=prior, noise=noise)['samples']
 
     def scores(self, params=None, space=None, hidden=None, inputs=None, outputs=None, logp=False, logpred=False,
                bias=True, variance=False, median=False, *args, **kwargs):
-        """the scoring harness that consumes mean / variance / median / logpredictive (models.py:449-469):
-        `_l1`, `_l2`, `_mse`, `_rmse`, `_median_l1`, `_median_l2`, `_logp`, `_loglike`, `_logprior`, `_nlpd`"""
-        if hidden is None:
-            hidden = self.hidden
+        """scoring harness over mean / variance / median / logpredictive against the hidden truth
+        (boundary: models.py:449-469 -- the keys `_l1`, `_l2`, `_mse`, `_rmse`, `_median_l1`,
+        `_median_l2`, `_logp`, `_loglike`, `_logprior`, `_nlpd`)"""
+        truth = self.hidden if hidden is None else hidden
         pred = self.predict(params=params, space=space, inputs=inputs, outputs=outputs, mean=True, var=variance,
                             median=median, distribution=logpred)
-        scores = DictObj()
+
+        def err(which, power):
+            return np.mean(np.abs(pred[which] - truth) ** power)
+        out = DictObj()
         if bias:
-            scores['_l1'] = np.mean(np.abs(pred.mean - hidden))
-            scores['_l2'] = np.mean((pred.mean - hidden) ** 2)
+            out.update(_l1=err('mean', 1), _l2=err('mean', 2))
         if variance:
-            scores['_mse'] = np.mean((pred.mean - hidden) ** 2 + pred.variance)
-            scores['_rmse'] = np.sqrt(scores['_mse'])
+            mse = np.mean((pred.mean - truth) ** 2 + pred.variance)
+            out.update(_mse=mse, _rmse=np.sqrt(mse))
         if median:
-            scores['_median_l1'] = np.mean(np.abs(pred.median - hidden))
-            scores['_median_l2'] = np.mean((pred.median - hidden) ** 2)
+            out.update(_median_l1=err('median', 1), _median_l2=err('median', 2))
         if logp:
-            scores['_logp'] = self.logp(params)
-            scores['_loglike'] = self.loglike(params)
-            scores['_logprior'] = self.logp(params, prior=True)
+            out.update(_logp=self.logp(params), _loglike=self.loglike(params), _logprior=self.logp(params, prior=True))
         if logpred:
-            scores['_nlpd'] = - pred.logpredictive(hidden) / len(hidden)
-        return scores
+            out['_nlpd'] = -pred.logpredictive(truth) / len(truth)
+        return out
 
     def logp_chain(self, chain, prior=False):
         """stochastic.py:515-520: one logp per row of a flat-parameter chain"""
@@ -462,5 +476,8 @@ class StochasticProcess:
 
     def fixed_dlogp(self, sampling_params, return_array=False):
         rows = self._fixed_rows(sampling_params)
-        r = np.array([self.dlogp(p, array=True)[self.active.sampling_dims] for p in rows])
+        if hasattr(self, 'dlogp_chain'):      # one batched factor + K^-1 sweep where the process provides it
+            r = np.asarray(self.dlogp_chain(rows))[:, self.active.sampling_dims]
+        else:
+            r = np.array([self.dlogp(p, array=True)[self.active.sampling_dims] for p in rows])
         return r if return_array else np.mean(r, axis=0)

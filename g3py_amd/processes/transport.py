@@ -32,20 +32,6 @@ class TransportProcess(StochasticProcess):
     def default_hypers(self):
         return self.f_transport.default_hypers_dims(self.inputs, self.outputs)
 
-    def _values(self, params):
-        """transformed-space params -> natural values; log-Jacobian of the FlatExp variables"""
-        values, logjac = {}, 0.0
-        for v in self.model.vars:
-            p = np.asarray(params[v.key], dtype=np.float64)
-            if v.positive:
-                with np.errstate(over='ignore'):
-                    e = np.exp(p)
-                logjac += float(np.sum(np.where(e > 1e-6, 0.0, -np.inf)))
-                values[v.name] = e
-            else:
-                values[v.name] = p
-        return values, logjac
-
     # ---- the transports of transport.py:33-98
     def th_transport(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         values, _ = self._values(params)
@@ -74,6 +60,33 @@ class TransportProcess(StochasticProcess):
                 ('transport_inv', 'th_transport_inv'))
 
 
+class TransportGaussianDistribution:
+    """Density of y = T(x), x ~ N(0, I) (g3py/processes/transport.py:214-246): the reference's
+    pm.Continuous subclass reduced to its arithmetic.  `logp_t` takes numeric arrays and the
+    natural-space hyper values; NaN / Inf anywhere gives the reference's -1e30 (transport.py:240-243)."""
+
+    def __init__(self, transport=None, inputs=None, values=None, dtype=np.float64):
+        self.transport = ID() if transport is None else transport
+        self.th_inputs = inputs
+        self.values = values
+        self.dtype = np.dtype(dtype)
+
+    @classmethod
+    def logp_t(cls, value, transport, inputs, values=None, dtype=np.float64):
+        t = np.dtype(dtype).type
+        y = np.asarray(value, dtype=dtype)
+        with np.errstate(all='ignore'):
+            delta = np.asarray(transport.inv(inputs, y, noise=True, values=values))      # transport.py:226
+            det_m = transport.logdet_dinv(inputs, y, values=values)                      # transport.py:227
+        if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):
+            return t(SENTINEL)
+        npi = t(-0.5) * t(len(y)) * np.log(t(2.0 * np.pi))                               # transport.py:230
+        return t(npi + t(-0.5) * t(delta.dot(delta)) + t(det_m))                         # transport.py:231-238
+
+    def logp(self, value):
+        return self.logp_t(value, self.transport, self.th_inputs, self.values, self.dtype)
+
+
 class TransportGaussianProcess(TransportProcess):
     def __init__(self, *args, **kwargs):
         if 'name' not in kwargs:
@@ -83,15 +96,7 @@ class TransportGaussianProcess(TransportProcess):
     # ---- log-density (TransportGaussianDistribution.logp_t, transport.py:222-243)
     def th_loglike(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         values, _ = self._values(params)
-        t = self.dtype.type
-        y = np.asarray(outputs, dtype=self.dtype)
-        with np.errstate(all='ignore'):
-            delta = np.asarray(self.f_transport.inv(inputs, y, noise=True, values=values))
-            det_m = self.f_transport.logdet_dinv(inputs, y, values=values)
-        if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):
-            return t(SENTINEL)
-        npi = t(-0.5) * t(len(y)) * np.log(t(2.0 * np.pi))
-        return t(npi + t(-0.5) * t(delta.dot(delta)) + t(det_m))
+        return TransportGaussianDistribution.logp_t(outputs, self.f_transport, inputs, values, self.dtype)
 
     def th_logp(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         _, logjac = self._values(params)

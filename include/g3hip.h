@@ -314,6 +314,27 @@ int g3_gp_dlogp(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map,
                 const void* a_dev, g3_dtype dt, void* Y_dev, int64_t ldy, void* Kinv_dev, int64_t ldc,
                 void* alpha_dev, double* out_host);
 
+/* Batched g3_gp_dlogp after ONE g3_gp_factor_batched sweep (same member layout: factors kstride
+ * elements apart in L_dev with leading dimension ldl, block inverses roundup(N,128)*128 apart,
+ * a_dev batch x roundup(N,128)).  Replaces the reference's Python loop over single gradients
+ * (fixed_dlogp, g3py/processes/stochastic.py:554-564).  Y_dev and Kinv_dev hold `batch` members
+ * kstride apart (ld = ldl); alpha_dev is batch x roundup(N,128); out_host is batch x map->nslots.
+ * All programs must share one structure (one g3_grad_map). */
+int g3_gp_dlogp_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const g3_grad_map* map,
+                        const void* X_dev, int64_t N, int64_t ldx, int d, const void* L_dev, int64_t ldl,
+                        int64_t kstride, const void* invd_dev, const void* a_dev, g3_dtype dt, void* Y_dev,
+                        void* Kinv_dev, void* alpha_dev, double* out_host);
+
+/* Latent draws of the sampler (g3py/processes/gaussian.py:89-95, before the mapping):
+ *     out[i][s] = loc[i] + sum_j L[i][j] Z[j][s]
+ * L_dev: lower Cholesky factor of the prior / posterior covariance of the M query points, stored
+ * roundup(M,128)-square and zero outside its M x M lower triangle (what g3_potrf_robust writes into
+ * a zeroed buffer); loc_host: M values; Z_host: the caller's standard normals, M x S row-major
+ * (np.random.randn(len(space), samples), gaussian.py:91); out_host: M x S row-major.  The product
+ * runs in the MFMA GEMM; host buffers are borrowed for the call. */
+int g3_gp_sample(g3_ctx* ctx, const void* L_dev, int64_t M, int64_t ldl, const void* loc_host,
+                 const void* Z_host, int64_t S, g3_dtype dt, void* out_host);
+
 /* ---- profiling (bench.py's live roofline measurement) -------------------------------------
  * When enabled, HIP-event pairs are recorded ON THE CONTEXT'S STREAM around every launch of
  * the MFMA GEMM (one tag per tile configuration) and around the phases of g3_gp_factor /

@@ -784,6 +784,37 @@ class TKernelOracle:
         return cho.dot(np.concatenate([outputs_inv, pred]))[len(inputs):]                    # :253-257
 
 
+class TScaleOracle:
+    """TScale -- g3py/processes/hypers/transports.py:165-181 with a constant scale function."""
+
+    def __init__(self, scale):
+        self.scale = scale
+
+    def _s(self, inputs):
+        return np.full(len(inputs), self.scale, dtype=np.float64)
+
+    def __call__(self, inputs, outputs, noise=False):
+        return outputs * self._s(inputs)                                                     # :171-172
+
+    def inv(self, inputs, outputs, noise=False):
+        return outputs / self._s(inputs)                                                     # :174-175
+
+    def logdet_dinv(self, inputs, outputs):
+        return -np.sum(np.log(self._s(inputs)))                                              # :177-181
+
+
+def transport_logp(value, t1, t2, inputs):
+    """TransportGaussianDistribution.logp_t for the composition t1 @ t2 -- g3py/processes/transport.py:
+    220-243 with TransportComposed.inv / logdet_dinv (hypers/transports.py:103-107)."""
+    value = np.asarray(value, dtype=np.float64)
+    inner = t1.inv(inputs, value, noise=True)
+    delta = t2.inv(inputs, inner, noise=True)                                                # :226 via :103-104
+    det_m = t2.logdet_dinv(inputs, inner) + t1.logdet_dinv(inputs, value)                    # :227 via :106-107
+    if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):
+        return np.float32(-1e30)                                                             # :240-243
+    return -0.5 * len(value) * np.log(2.0 * np.pi) - 0.5 * delta.dot(delta) + det_m          # :230-238
+
+
 # --------------------------------------------------------------------------- CPU baseline
 def cpu_hot_path(X, y, Xs, var=1.0, rate=1.0, noise=0.1):
     """One pass of the benchmark hot path on the CPU (bench.py `cpu_baseline`, kind "port"):

@@ -185,3 +185,26 @@ def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_
                      draws=dgp.last['draws'] if draws else np.zeros(0))
     finally:
         dist.destroy_process_group()
+
+
+def chain_worker(rank, world, port, N, d, rows, out_path):
+    """one rank of a replica-sharded logp_chain run (two ranks may share cuda:0 over gloo)"""
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        from g3py_amd.distributed import logp_chain_sharded
+        X, y, _ = synth(N, d, 4, 91)
+        gp = g3.GaussianProcess(space=X[:4], location=g3.Zero(), kernel=g3.SE(X))
+        gp.observed(X, y)
+        rng = np.random.default_rng(3)
+        chain = gp.active.dict_to_array(gp.params)[None, :] + 0.2 * rng.standard_normal((rows, gp.active.ndim))
+        got = logp_chain_sharded(gp, chain, dist, rank, world)
+        if rank == 0:
+            ref = np.array([gp.logp(c, array=True) for c in chain])
+            np.savez(out_path, got=got, ref=ref)
+    finally:
+        dist.destroy_process_group()

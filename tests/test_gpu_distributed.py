@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from dist_helpers import worker, synth  # noqa: E402
+from dist_helpers import worker, synth, chain_worker  # noqa: E402
 from test_distributed_cpu import _free_port  # noqa: E402
 
 
@@ -64,3 +64,13 @@ def test_hip_posterior_draws(tmp_path, world, N, nb, M, dtype, tol):
     Z = np.random.default_rng(5).standard_normal((M, S))
     ref = orc.GP(spec_f, 0.1).sampler(Xs, X, y, rand=Z)
     np.testing.assert_allclose(r['draws'], ref, atol=tol)
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_logp_chain_sharded_over_replicas(tmp_path, world):
+    """chain rows dealt to the ranks as replicas: equal to one-at-a-time logp"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(chain_worker, args=(world, _free_port(), 300, 3, 11, out), nprocs=world, join=True)
+    r = np.load(out)
+    np.testing.assert_allclose(r['got'], r['ref'], rtol=1e-11)

@@ -553,3 +553,103 @@ def test_transport_gaussian_process_is_the_warped_gp(golden_dir):
     y2 = y.copy(); y2[0] = np.nan
     assert tgp.logp(p, outputs=y2) == np.float32(-1e30)
     assert 'posterior_transport' in tgp.compiles and 'prior_transport' in tgp.compiles
+
+
+def test_tscale_and_transport_density_match_oracle():
+    """TScale (transports.py:165-181) composed with a noisy TKernel: map, inverse, log-determinant and
+    the transport log-density TransportGaussianDistribution.logp_t (transport.py:220-243) against the
+    literal restatement; TTriangular is the reference's constructor-only shell"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(21)
+    X = rng.uniform(0, 3, (260, 2))
+    y = 1.7 * (np.sin(X.sum(1)) + 0.05 * rng.standard_normal(260))
+    r = np.array([0.7, 1.3])
+    T = g3.TScale(g3.Bias(X)) @ g3.TKernel(g3.SE(X), noisy=True)
+    tgp = g3.TGP(space=X[:5], transport=T)
+    tgp.observed(X, y)
+    p = _params(tgp, SE_var=1.1, SE_rate=r, NoiseSE_var=0.05, Bias_Bias=1.7)
+    values = {'TGP_SE_var': 1.1, 'TGP_SE_rate': r, 'TGP_NoiseSE_var': 0.05, 'TGP_Bias_Bias': 1.7}
+    ts, tk = orc.TScaleOracle(1.7), orc.TKernelOracle(('SE', 1.1, r, None), 0.05)
+    v = rng.standard_normal(260)
+    np.testing.assert_allclose(T.t1(X, v, values=values), ts(X, v), rtol=1e-15)
+    np.testing.assert_allclose(T.t1.inv(X, v, values=values), ts.inv(X, v), rtol=1e-15)
+    assert abs(T.t1.logdet_dinv(X, v, values=values) - ts.logdet_dinv(X, v)) <= 1e-12
+    np.testing.assert_allclose(T(X, v, noise=True, values=values), ts(X, tk(X, v, noise=True)), atol=1e-9)
+    ref = orc.transport_logp(y, ts, tk, X)
+    assert abs(tgp.loglike(p) - ref) <= 1e-8 * abs(ref)
+    dist = g3.TransportGaussianDistribution(T, X, values)
+    assert abs(dist.logp(y) - ref) <= 1e-8 * abs(ref)
+    assert g3.TransportGaussianDistribution.logp_t(np.where(np.arange(260) == 3, np.nan, y), T, X, values) == np.float32(-1e30)
+    tri = g3.TTriangular(g3.Bias(X))
+    assert isinstance(tri, g3.TNoLinear) and tri.generator is tri.parametrics[0]
+    with pytest.raises(NotImplementedError):
+        tri(X, v)
+
+
+def test_transport_process_includes_potentials():
+    """a potential registered on a transport's hypers enters logp exactly as for the elliptical
+    processes (hypers/__init__.py:94-109; stochastic.py:300-306)"""
+    import g3py_amd as g3
+    rng = np.random.default_rng(22)
+    X = rng.uniform(0, 3, (150, 1))
+    y = np.sin(X[:, 0]) + 0.05 * rng.standard_normal(150)
+
+    def build(potential):
+        T = g3.TLocation(g3.Bias(X)) @ g3.TKernel(g3.SE(X), noisy=True)
+        if potential:
+            T.set_potential(hypers='rate', reg='L2', c=0.5)
+        t = g3.TGP(space=X[:4], transport=T)
+        t.observed(X, y)
+        return t
+    plain, pot = build(False), build(True)
+    p = _params(plain, SE_var=0.9, SE_rate=np.array([1.4]), NoiseSE_var=0.1, Bias_Bias=0.2)
+    assert len(pot.model.potentials) == 1 and len(plain.model.potentials) == 0
+    expect = plain.logp(p) + 0.5 * -(1.4 ** 2)
+    assert abs(pot.logp(p) - expect) <= 1e-10 * abs(expect)
+    assert abs(pot.logp(p, prior=True) - (plain.logp(p, prior=True) - 0.5 * 1.4 ** 2)) <= 1e-12
+
+
+def test_batched_dlogp_chain_matches_single_gradients():
+    """dlogp_chain / fixed_dlogp: one batched factor + K^-1 sweep (g3_gp_dlogp_batched) equals the loop
+    of single dlogp evaluations (stochastic.py:554-564), warped GP with a Bias location, ragged N"""
+    import g3py_amd as g3
+    rng = np.random.default_rng(31)
+    N, d = 330, 3
+    X = rng.uniform(0, 4, (N, d))
+    y = np.exp(0.4 * np.sin(X.sum(1))) + 0.02 * rng.standard_normal(N)
+    gp = g3.WGP(space=X[:5], location=g3.Bias(X), kernel=g3.SE(X) + g3.MAT32(X, name='M'), mapping=g3.LogShifted(y))
+    gp.observed(X, y)
+    base = gp.active.dict_to_array(gp.params)
+    chain = base[None, :] + 0.15 * rng.standard_normal((7, len(base)))
+    got = gp.dlogp_chain(chain, batch=4)
+    ref = np.array([gp.dlogp(c, array=True) for c in chain])
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9)
+    # fixed_dlogp over a fixed chain uses the batched sweep
+    gp.active.fix_vars(chain, keys=[gp.model.vars[0].key])
+    sp = gp.active.sampling_params(base)
+    r = gp.fixed_dlogp(sp, return_array=True)
+    rows = gp.active.fixed_chain.copy()
+    ref2 = np.array([gp.dlogp(c, array=True)[gp.active.sampling_dims] for c in rows])
+    np.testing.assert_allclose(r, ref2, rtol=1e-9, atol=1e-9)
+
+
+def test_sampler_single_call_and_vectorised_mapping(golden_dir):
+    """g3_gp_sample: loc + L Z in one C-ABI call, mapping applied to the whole M x S matrix;
+    same draws as the oracle's per-sample loop (gaussian.py:89-97)"""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(33)
+    X, Xs = rng.uniform(0, 3, (200, 2)), rng.uniform(0, 3, (37, 2))
+    y = np.sinh(np.sin(X.sum(1))) + 0.03 * rng.standard_normal(200)
+    Z = rng.standard_normal((37, 5))
+    r = np.array([0.9, 1.2])
+    gp = g3.WGP(space=Xs, location=g3.Zero(), kernel=g3.SE(X), mapping=g3.ArcsinhLinear(y))
+    gp.observed(X, y)
+    p = _params(gp, SE_var=1.0, SE_rate=r, Noise_var=0.1, ArcsinhLinear_shift=0.1, ArcsinhLinear_scale=0.8)
+    o = orc.GP(('SE', 1.0, r, None), 0.1, ('Zero',), ('ArcsinhLinear', 0.1, 0.8))
+    for prior in (False, True):
+        got = gp.sampler(p, rand=Z, prior=prior)
+        ref = o.sampler(Xs, X, y, rand=Z, prior=prior)
+        assert got.shape == (37, 5)
+        np.testing.assert_allclose(got, ref, atol=2e-6)
