@@ -47,6 +47,9 @@ class StudentTProcess(EllipticalProcess):
     #      plus the degrees-of-freedom term (what Theano's reverse mode gives for studentT.py:114-135)
     th_dlogp = GaussianProcess.th_dlogp
     _dloglike = GaussianProcess._dloglike
+    _chain_rule = GaussianProcess._chain_rule
+    _flat_gradient = GaussianProcess._flat_gradient
+    _potential_gradient = GaussianProcess._potential_gradient
 
     def _dlogp_scale(self, values, c, st, nat):
         nu, n, beta = float(self.f_degree(values)), float(c['N']), float(st['quad'])
