@@ -68,10 +68,14 @@ def synth(N, d, M, seed):
     return X, y, Xs
 
 
-def step_flops(N, M):
+def step_flops(N, M, S=0):
     """algorithmic flops of one step: potrf N^3/3, trsv N^2,
-    trsm N^2 M, mean+variance 2 N M"""
-    return N ** 3 / 3.0 + float(N) ** 2 + float(N) ** 2 * M + 2.0 * N * M
+    trsm N^2 M, mean+variance 2 N M; with S > 0 draws also the posterior covariance N M^2, its
+    Cholesky M^3/3 and L Z: M^2 S"""
+    f = N ** 3 / 3.0 + float(N) ** 2 + float(N) ** 2 * M + 2.0 * N * M
+    if S > 0:
+        f += float(N) * M * M + M ** 3 / 3.0 + float(M) * M * S
+    return f
 
 
 def cpu_baseline(N, d, M, seed, n_cpu):
@@ -111,6 +115,8 @@ def main():
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
     ap.add_argument('--grad', action='store_true', help='also time dlogp (K^-1 + kernel-parameter sums, SURVEY.md 8f rank 1) '
                                                         'after the timed region; reported under "dlogp", never part of value')
+    ap.add_argument('--draws', type=int, default=-1, help='posterior draws S through the warped-GP path (BASELINE config 5: posterior '
+                                                          'covariance + second Cholesky + L Z + mapping); default 16 with --f32, else 0')
     ap.add_argument('--panel', dest='nb', type=int, default=0, help='row-block height of the multi-GPU distribution (0 = 1024 up to 4 GPUs, 512 beyond)')
     args = ap.parse_args()
 
@@ -165,7 +171,16 @@ def main():
     seed = 1005 if args.f32 else (1003 if args.kernel == 'mat52cos' else (1002 if args.n == 8192 else 1004))
     N, d, M = args.n, args.d, args.m
     X, y, Xs = synth(N, d, M, seed)
-    delta = y.copy()                      # Zero mean, identity mapping: delta = y
+    S = args.draws if args.draws >= 0 else (16 if args.f32 else 0)
+    if S > 0:
+        # BASELINE config 5: warped GP, BoxCoxLinear(shift=1, scale=1, power=1.2) on y - min(y) + 1
+        from g3py_amd.processes.hypers.mappings import BoxCoxLinear
+        yw = (y - y.min() + 1.0).astype(np.float32 if args.f32 else np.float64)
+        warp = BoxCoxLinear(shift=1.0, scale=1.0, power=1.2)
+        Z = np.random.Generator(np.random.PCG64(seed + 100)).standard_normal((M, S))
+        delta = np.asarray(warp.inv(yw), dtype=np.float64)        # refreshed inside every timed step
+    else:
+        delta = y.copy()                  # Zero mean, identity mapping: delta = y
     if args.kernel == 'se':
         spec_f = ('SE', 1.0, np.ones(d), None)
     else:
@@ -203,11 +218,32 @@ def main():
         prog_n, prog_f = compile_spec(spec_n, d), compile_spec(spec_f, d)
         result = {}
 
+        if S > 0:
+            Ksst = torch.empty((Mp, Mp), dtype=tdt, device=tdev)
+            Lst = torch.zeros((Mp, Mp), dtype=tdt, device=tdev)
+            Kssd, Lsd = wrap(Ksst, Mp, Mp), wrap(Lst, Mp, Mp)
+            Vd = dev.wrap(Kt.data_ptr() + (Np + 128) * Np * Kt.element_size(), Mp, Np, Np, npdt, keep=Kt)
+
         def step():
+            if S > 0:     # warped GP: delta = T^-1(y) - m(X) is part of every evaluation (gaussian.py:208)
+                dl = np.asarray(warp.inv(yw), dtype=npdt)
+                dt_.copy_(torch.from_numpy(dl[None, :]))
             # Gram + tall Cholesky: the delta row and the K(Xs, X) rows ride through the factorisation
             st = dev.gp_factor_predict(prog_n, prog_f, Xd, N, d, dd, Xsd, M, Kd, Wd, ad, mud, ssd)
+            lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
+            if S > 0:
+                lp += float(warp.logdet_dinv(yw))                                   # gaussian.py:225
+                # posterior covariance K_f(Xs, Xs) - V V^T (elliptical.py:90-92), lower triangle
+                dev.gram(prog_f, Xsd, None, d, Kssd, Mp, Mp, 0)
+                dev.gemm_nt(Kssd, Vd, Vd, Mp, Mp, Np, alpha=-1.0, beta=1.0, lower_only=True)
+                Lst.zero_()
+                tries, fb, _ = dev.potrf_robust(wrap(Ksst, M, M), wrap(Lst, M, M), M)   # cholesky_robust
+                loc = mut[0, :M].double().cpu().numpy()
+                g = dev.gp_sample(Lsd, M, loc.astype(npdt), Z.astype(npdt))         # loc + L Z (gaussian.py:92-95)
+                result['draws'] = np.asarray(warp(g))                               # mapping, vectorised
+                result['cov_tries'] = tries
             dev.sync()
-            result['logp'] = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
+            result['logp'] = lp
             result['stats'] = st
         parallelism = '1gpu'
     else:
@@ -218,7 +254,15 @@ def main():
         result = {}
 
         def step():
-            result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
+            if S > 0:
+                dl = np.asarray(warp.inv(yw), dtype=npdt)
+                dt_.copy_(torch.from_numpy(dl[None, :]))
+                lp = dgp.step(spec_n, spec_f, Xd, Xsd, dd, Z=Z) + float(warp.logdet_dinv(yw))
+                result['draws'] = np.asarray(warp(dgp.last['draws'].astype(npdt)))
+                result['cov_tries'] = dgp.last.get('cov_tries', 0)
+                result['logp'] = lp
+            else:
+                result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
         parallelism = 'row-block-cyclic x%d (nb=%d): RCCL diagonal-factor broadcast + panel all-gather, look-ahead' % (world, args.nb)
 
     for _ in range(args.warmup):
@@ -245,7 +289,7 @@ def main():
 
     if rank == 0:
         sec = elapsed / args.steps
-        flops = step_flops(N, M)
+        flops = step_flops(N, M, S)
         out = {
             'metric': 'GP logp+predict end-to-end (Gram+Cholesky+solves), N=%d %s: algorithmic TFLOP/s' % (N, 'fp32' if args.f32 else 'fp64'),
             'value': flops / sec / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
@@ -256,6 +300,13 @@ def main():
                                    % (N, d, M, M), 'N': N, 'd': d, 'M': M, 'parallelism': parallelism},
             'e2e_sec': sec, 'logp': float(result['logp']),
         }
+        if S > 0:
+            dr = result['draws']
+            out['config']['workload'] = ('warped ' + out['config']['workload'] + ' + posterior covariance + its Cholesky + %d draws '
+                                         'L Z + BoxCoxLinear mapping' % S)
+            out['config']['draws'] = S
+            out['draws'] = {'shape': list(dr.shape), 'finite': bool(np.all(np.isfinite(dr))), 'mean': float(np.mean(dr)),
+                            'std': float(np.std(dr)), 'cov_jitter_tries': int(result.get('cov_tries', 0))}
         ph = {k: v['ms'] / args.steps for k, v in prof.items() if v['count']}
         out['phases_ms'] = ph
         if prof['gram']['count'] and prof['gram']['ms'] > 0:
@@ -309,7 +360,7 @@ def main():
             out['cpu_baseline'] = cb
         # full-size pin: the CPU oracle's logp at this exact configuration (tests/golden/fullsize.json,
         # written once by oracle/gen_fullsize.py in the build container; data, not code)
-        ref = _golden_logp(N, d, M, seed, args.kernel) if not args.f32 else None
+        ref = _golden_logp(N, d, M, seed, args.kernel) if not (args.f32 or S > 0) else None
         if ref is not None:
             out['logp_ref'] = ref
             out['logp_rel_err'] = abs(out['logp'] - ref) / abs(ref)

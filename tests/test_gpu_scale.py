@@ -233,3 +233,65 @@ def test_batched_factor_n1024_b64(dev):
     ref = orc.GP(specs[5][1], specs[5][2][1]).logp(X, deltas[5])
     got5 = -0.5 * N * np.log(2 * np.pi) - 0.5 * stats[5]['quad'] - stats[5]['logdet']
     assert abs(got5 - ref) <= 1e-9 * abs(ref)
+
+
+def test_config5_full_size_fp32_draws_properties(dev):
+    """BASELINE config 5's shape on ONE GPU (fp32, N=65536, d=16, M=4096, S=16): factor + posterior covariance +
+    its Cholesky + draws, checked through size-independent properties (the CPU oracle covers this path at
+    N <= 1500 in test_hip_posterior_draws / test_sampler_single_call_and_vectorised_mapping):
+    (1) L (L^-1 delta) = delta on sampled rows, (2) L_post L_post^T = K_f(Xs, Xs) - V V^T on sampled entries,
+    (3) its diagonal equals the variance path (prior - ss), (4) the draws are linear in Z."""
+    import ctypes as C
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d, M, S = 65536, 16, 4096, 16
+    X, y, Xs = _synth(N, d, M, 1005)
+    X, y, Xs = X.astype(np.float32), y.astype(np.float32), Xs.astype(np.float32)
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    spec_n = ('sum', spec_f, ('NOISE', 0.1))
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, 128)
+    f4 = np.float32
+    K = dev.alloc(Np + 128 + Mp, Np, f4)
+    W, a = dev.alloc_inverses(Np, f4), dev.alloc(1, Np, f4)
+    mu, ss = dev.alloc(1, Mp, f4), dev.alloc(1, Mp, f4)
+    Xd, Xsd = dev.upload(X), dev.upload(Xs)
+    st = dev.gp_factor_predict(compile_spec(spec_n, d), compile_spec(spec_f, d), Xd, N, d, dev.upload(y), Xsd, M, K, W, a, mu, ss)
+    assert st['info'] == 0 and st['nonfinite'] == 0 and np.isfinite(st['logdet']) and np.isfinite(st['quad'])
+
+    def rows(buf, r0, i, n):
+        out = np.empty(int(n), dtype=f4)
+        assert dev.lib.g3_memcpy_d2h(dev.ctx, out.ctypes.data, int(buf.offset(int(r0 + i))), int(n) * 4) == 0
+        return out.astype(np.float64)
+    rng = np.random.default_rng(1)
+    av = dev.download(a, 1, N)[0].astype(np.float64)
+    for i in sorted(rng.choice(N, 6, replace=False)):
+        Li = rows(K, 0, i, i + 1)
+        assert abs(Li.dot(av[:i + 1]) - y[i]) <= 2e-3                                   # (1) fp32 round trip
+    # posterior covariance, its Cholesky, draws
+    V = dev.wrap(K.offset(Np + 128), Mp, Np, K.ld, f4, keep=K)
+    Kss = dev.alloc(Mp, Mp, f4)
+    dev.gram(compile_spec(spec_f, d), Xsd, None, d, Kss, Mp, Mp, 0)
+    dev.gemm_nt(Kss, V, V, Mp, Mp, Np, alpha=-1.0, beta=1.0, lower_only=True)
+    Lp = dev.alloc(Mp, Mp, f4, zero=True)
+    tries, fb, jit = dev.potrf_robust(dev.wrap(Kss.ptr, M, M, Kss.ld, f4, keep=Kss), dev.wrap(Lp.ptr, M, M, Lp.ld, f4, keep=Lp), M)
+    assert not fb
+    ssv = dev.download(ss, 1, M)[0].astype(np.float64)
+    pick = sorted(rng.choice(M, 5, replace=False))
+    Vr = {i: rows(K, Np + 128, i, N) for i in pick}
+    Lr = {i: rows(Lp, 0, i, i + 1) for i in pick}
+    from oracle import g3_oracle as orc
+    for i in pick:
+        for j in pick:
+            if j > i:
+                continue
+            want = orc.kernel_cov(spec_f, Xs[[i]].astype(np.float64), Xs[[j]].astype(np.float64))[0, 0] - Vr[i].dot(Vr[j])
+            got = Lr[i][:j + 1].dot(Lr[j][:j + 1])
+            assert abs(got - want - (jit if i == j else 0.0)) <= 3e-3, (i, j, got, want)  # (2)
+        assert abs((1.0 - ssv[i]) - (Lr[i].dot(Lr[i]) - jit)) <= 3e-3                     # (3)
+    loc = dev.download(mu, 1, M)[0]
+    Z1, Z2 = rng.standard_normal((M, S)).astype(f4), rng.standard_normal((M, S)).astype(f4)
+    g1, g2, g12 = dev.gp_sample(Lp, M, loc, Z1), dev.gp_sample(Lp, M, loc, Z2), dev.gp_sample(Lp, M, loc, Z1 + Z2)
+    assert np.all(np.isfinite(g12))
+    np.testing.assert_allclose(g12 - loc[:, None], (g1 - loc[:, None]) + (g2 - loc[:, None]), atol=2e-3)   # (4)
+    for b in (K, W, a, mu, ss, Kss, Lp):
+        b.free()
