@@ -78,26 +78,48 @@ def step_flops(N, M, S=0):
     return f
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the cgroup quota when there is one (a GPU box hands a
+    one-GPU job a share of the host), else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(N, d, M, seed, n_cpu):
+    """the CPU oracle (NumPy/SciPy restatement: same LAPACK entry points as the reference) on a bounded
+    sample of the workload, with the BLAS pool sized to the cores this job may use"""
     from oracle import g3_oracle as orc
     X, y, Xs = synth(N, d, M, seed)
     X, y = X[:n_cpu], y[:n_cpu]
-    t0 = time.perf_counter()
-    lp, mean, var, tm = orc.cpu_hot_path(X, y, Xs)
-    dt = time.perf_counter() - t0
+    cores = usable_cores()
+    blas = None
     try:
         import threadpoolctl
-        cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    return dict(value=step_flops(n_cpu, M) / dt / 1e12, unit='TFLOP/s', cores=int(cores), kind='port',
+        with threadpoolctl.threadpool_limits(limits=cores):
+            blas = sorted({p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()})
+            t0 = time.perf_counter()
+            lp, mean, var, tm = orc.cpu_hot_path(X, y, Xs)
+            dt = time.perf_counter() - t0
+    except ImportError:
+        t0 = time.perf_counter()
+        lp, mean, var, tm = orc.cpu_hot_path(X, y, Xs)
+        dt = time.perf_counter() - t0
+    threads = max(blas) if blas else cores
+    scale = (float(N) / n_cpu) ** 3
+    return dict(value=step_flops(n_cpu, M) / dt / 1e12, unit='TFLOP/s', cores=int(min(threads, cores)), kind='port',
                 sample='one pass of the same workload cut to N=%d (d=%d, M=%d, same generator and seed), '
-                       'oracle.cpu_hot_path: NumPy Gram + scipy dpotrf + solve_triangular' % (n_cpu, d, M),
-                seconds=dt, potrf_gflops=(n_cpu ** 3 / 3.0) / tm['potrf'] / 1e9, phases_sec=tm), lp
+                       'oracle.cpu_hot_path: NumPy Gram + scipy dpotrf + solve_triangular; BLAS threads %s, '
+                       'host reports %d CPUs, cgroup/affinity allows %d'
+                       % (n_cpu, d, M, blas, os.cpu_count() or 0, cores),
+                seconds=dt, potrf_gflops=(n_cpu ** 3 / 3.0) / tm['potrf'] / 1e9, phases_sec=tm,
+                full_size_seconds_extrapolated=dt * scale if n_cpu < N else dt,
+                extrapolation='N^3 from the sample (flagged: not measured)' if n_cpu < N else None), lp
 
 
 def main():
@@ -111,7 +133,7 @@ def main():
     ap.add_argument('--kernel', default='se', choices=['se', 'mat52cos'],
                     help='se: BASELINE configs 2/4; mat52cos: MAT52 + periodic COS sum kernel (config 3)')
     ap.add_argument('--f32', action='store_true', help='float32 arithmetic (config 5 runs in fp32)')
-    ap.add_argument('--cpu-n', type=int, default=8192, help='N of the bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-n', type=int, default=16384, help='N of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
     ap.add_argument('--grad', action='store_true', help='also time dlogp (K^-1 + kernel-parameter sums, SURVEY.md 8f rank 1) '
                                                         'after the timed region; reported under "dlogp", never part of value')
@@ -206,7 +228,9 @@ def main():
     Xt, Xst, dt_ = tens(X), tens(Xs), tens(delta[None, :])
     Xd, Xsd, dd = wrap(Xt, N, d), wrap(Xst, M, d), wrap(dt_, 1, N)
 
-    if world == 1:
+    # G3_FORCE_DIST=1: run the multi-GPU driver with one rank (development: its overhead over the in-library sweep)
+    use_dist = world > 1 or os.environ.get('G3_FORCE_DIST', '0') == '1'
+    if not use_dist:
         Kt = torch.empty((Np + 128 + Mp, Np), dtype=tdt, device=tdev)   # covariance + right-hand-side rows
         at = torch.empty((1, Np), dtype=tdt, device=tdev)
         Vt = torch.empty((Mp, Np), dtype=tdt, device=tdev)
@@ -268,7 +292,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
-    dev.prof_enable(0 if args.no_prof else (3 if world > 1 else 1))
+    dev.prof_enable(0 if args.no_prof else (3 if use_dist else 1))
     dev.prof_reset()
     if world > 1:
         dist.barrier()
@@ -321,7 +345,7 @@ def main():
         g = prof['gemm_bulk']
         kern = 'gemm_nt_kernel<%s,128,128,64,64>, launches with >= 1024 tiles ' % ('float' if args.f32 else 'double') + \
                '(bulk panel updates of the blocked Cholesky and of the trsm)'
-        if world > 1:
+        if use_dist:
             # the row-block layout issues per-block updates (m = nb rows): a 1-in-16 sample of the MFMA GEMM launches of rank 0
             g = {k: sum(prof[t][k] for t in ('gemm_bulk', 'gemm_mid', 'gemm_small')) for k in ('count', 'ms', 'work')}
             kern = 'gemm_nt_kernel<%s,*>: 1-in-16 sample of the MFMA GEMM launches of rank 0 (trailing updates and panel solves of ' \
@@ -332,12 +356,14 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': ach / peak,
                                'traffic': _traffic() if (world == 1 and not args.f32 and N == 32768) else None,
+                               'traffic_source': 'profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                                                 'passes of this command (not measured in this run)',
                                'kernel': kern,
                                'launches_per_step': g['count'] / args.steps,
                                'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],
                                'note': 'HIP events per launch on the launching stream; launches on the two '
                                        'look-ahead streams overlap, so summed launch time exceeds wall time'}
-        if world == 1 and args.grad:
+        if not use_dist and args.grad:
             gmap = dev.grad_layout(prog_n)
             Yt = torch.empty((Np, Np), dtype=tdt, device=tdev)
             Kit = torch.empty((Np, Np), dtype=tdt, device=tdev)
@@ -358,6 +384,8 @@ def main():
         if world == 1 and args.cpu_n > 0:
             cb, lp_cpu = cpu_baseline(N, d, M, seed, min(args.cpu_n, N))
             out['cpu_baseline'] = cb
+            if min(args.cpu_n, N) == N:      # the sample is the whole workload: the CPU logp must agree too
+                out['cpu_baseline']['logp'] = float(lp_cpu)
         # full-size pin: the CPU oracle's logp at this exact configuration (tests/golden/fullsize.json,
         # written once by oracle/gen_fullsize.py in the build container; data, not code)
         ref = _golden_logp(N, d, M, seed, args.kernel) if not (args.f32 or S > 0) else None

@@ -24,7 +24,10 @@
 #include "g3_mfma.h"
 
 constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
-constexpr int GROUP_M = 4; // row-blocks per raster group
+// row tiles per raster group.  Measured on a 30720^2 x 1024 lower-triangular update (rocprofv3 --pmc
+// FETCH_SIZE, profiles/r02_summary.md): 2 -> 66.8 TFLOP/s, 23.0 GB fetched; 4 -> 66.3, 22.6 GB;
+// 8 -> 65.9, 24.7 GB; 16 -> 64.8, 28.2 GB
+constexpr int GROUP_M = 4;
 #ifndef G3_SMALL_STAGES
 #define G3_SMALL_STAGES 4  // LDS buffers of the 64 x 64 and 32 x 128 tiles (latency-bound critical-path products)
 #endif

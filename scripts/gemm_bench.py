@@ -20,9 +20,10 @@ dev.set_stream(st.cuda_stream)
 for (m, n, k, lower) in shapes:
     lda = max(k, int(os.environ.get('G3_LDA', '0')))      # G3_LDA: the operand is a column block of a wider matrix
     A = torch.rand((max(m, n), lda), dtype=TDT, device='cuda') - 0.5
-    C = torch.rand((m, n), dtype=TDT, device='cuda')
+    ldc = max(n, int(os.environ.get('G3_LDC', '0')))      # G3_LDC: C is a block of a wider matrix
+    C = torch.rand((m, ldc), dtype=TDT, device='cuda')
     Ad = dev.wrap(A.data_ptr(), max(m, n), k, lda, DT)
-    Cd = dev.wrap(C.data_ptr(), m, n, n, DT)
+    Cd = dev.wrap(C.data_ptr(), m, n, ldc, DT)
     for _ in range(2):
         dev.gemm_nt(Cd, Ad, Ad, m, n, k, alpha=-1e-6, beta=float(os.environ.get('G3_BETA', '1.0')), lower_only=bool(lower))
     torch.cuda.synchronize()
@@ -35,4 +36,4 @@ for (m, n, k, lower) in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * k * ((m * n - n * (n - 1) / 2) if lower else m * n)
-    print(np.dtype(DT).name, 'm %6d n %6d k %6d lower %d cfg %s: %8.3f ms  %6.2f TFLOP/s' % (m, n, k, lower, os.environ.get('G3_GEMM_CFG', 'auto'), ms, fl / ms / 1e9))
+    print(np.dtype(DT).name, 'm %6d n %6d k %6d lower %d lda %d ldc %d cfg %s: %8.3f ms  %6.2f TFLOP/s' % (m, n, k, lower, lda, ldc, os.environ.get('G3_GEMM_CFG', 'auto'), ms, fl / ms / 1e9))

@@ -1,22 +1,27 @@
 """Turn the rocprofv3 outputs of one round (gpurun_out/rNN/{trace,pmc_fetch,pmc_write}) into the
 committed summaries under profiles/: kernel stats CSV, a markdown summary and the HBM-traffic
 JSON that bench.py reports as roofline.traffic.
-usage: python scripts/make_profile_summary.py r01 [passes_in_trace]"""
+usage: python scripts/make_profile_summary.py r02 [passes_in_trace] [trace_subdir] [out_suffix] [command text]
+  e.g.  make_profile_summary.py r02 4                       -> profiles/r02_summary.md (+ traffic)
+        make_profile_summary.py r02 7 c2 _c2 "bench.py --points 8192 ..."   -> profiles/r02_c2_summary.md"""
 import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 passes = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+sub = sys.argv[3] if len(sys.argv) > 3 else 'trace'
+suffix = sys.argv[4] if len(sys.argv) > 4 else ''
+command = sys.argv[5] if len(sys.argv) > 5 else 'python3 bench.py --steps 3 --warmup 1 --cpu-n 0'
 src = os.path.join('gpurun_out', tag)
 os.makedirs('profiles', exist_ok=True)
-stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]
-shutil.copy(stats, 'profiles/%s_kernel_stats.csv' % tag)
-trace = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_trace.csv'))[0]
+stats = glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv'))[0]
+shutil.copy(stats, 'profiles/%s%s_kernel_stats.csv' % (tag, suffix))
+trace = glob.glob(os.path.join(src, sub, '*', '*_kernel_trace.csv'))[0]
 tr = list(csv.DictReader(open(trace)))
 
 def klass(name, grid, wg):
     if 'gemm_nt' in name:
         cfg = name.split('<')[1].split('>')[0].replace(' ', '')
         blocks = int(grid) // int(wg)
-        if cfg.endswith('128,128,64,64'):
+        if ',128,128,64,64' in cfg:
             return 'gemm_nt<%s> grid>=1024 (bulk panel updates)' % cfg if blocks >= 1024 else 'gemm_nt<%s> grid<1024' % cfg
         return 'gemm_nt<%s>' % cfg
     return name.split('(')[0].replace('void ', '')
@@ -26,16 +31,16 @@ for r in tr:
     k = klass(r['Kernel_Name'], r['Grid_Size_X'], r['Workgroup_Size_X'])
     agg[k][0] += 1
     agg[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-lines = ['# rocprofv3 summary %s' % tag, '',
-         'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-n 0`',
-         '(N=32768, d=4, M=1024, fp64, 1x MI355X; %d passes of the hot path in the trace).' % passes,
-         'Raw per-kernel stats: `%s_kernel_stats.csv`.  Kernels on the two look-ahead streams overlap, so' % tag,
+lines = ['# rocprofv3 summary %s%s' % (tag, suffix), '',
+         'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- %s`' % command,
+         '(1x MI355X; %d passes of the hot path in the trace, warm-up included).' % passes,
+         'Raw per-kernel stats: `%s%s_kernel_stats.csv`.  Kernels on the two look-ahead streams overlap, so' % (tag, suffix),
          'summed kernel time exceeds wall time.', '',
          '| kernel (split by grid size) | launches/pass | total ms/pass | avg us/launch |', '|---|---|---|---|']
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
     lines.append('| %s | %.1f | %.2f | %.1f |' % (k, v[0] / passes, v[1] / 1e6 / passes, v[1] / v[0] / 1e3))
 traffic = {}
-for name, counter in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+for name, counter in [] if suffix else (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     fs = glob.glob(os.path.join(src, name, '*', '*_counter_collection.csv'))
     if not fs:
         continue
@@ -64,5 +69,5 @@ if traffic:
               '`rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` on `python3 bench.py --steps 1 --warmup 0 --cpu-n 0 --skip-events`.',
               'Per launch (average over %d launches): fetch %.3f GB (FETCH_SIZE x 2, gfx950 correction), write %.3f GB.' % (f['launches'], fetch_b / 1e9, write_b / 1e9),
               'Calibration on a known byte count: the Gram kernels wrote %.4f GB by WRITE_SIZE vs %.4f GB expected.' % ((cal or 0) / 1e9, out['gram_write_bytes_expected'] / 1e9)]
-open('profiles/%s_summary.md' % tag, 'w').write('\n'.join(lines) + '\n')
+open('profiles/%s%s_summary.md' % (tag, suffix), 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))

@@ -54,7 +54,7 @@ def test_distributed_jitter_schedule(tmp_path):
     y = np.sin(X.sum(1) / np.sqrt(d))
     ref = orc.GP(spec_f, None).logp(X, y)
     assert int(r['tries']) >= 1
-    assert abs(float(r['logp']) - ref) <= 1e-5 * abs(ref)
+    assert abs(float(r['logp']) - ref) <= 1e-8 * abs(ref)
 
 
 def test_distributed_exhausted_jitter_falls_back(tmp_path):

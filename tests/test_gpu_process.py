@@ -147,7 +147,9 @@ def test_jitter_path_through_process():
     ref = orc.GP(('SE', 1.0, np.array([1.0]), None), None).logp(X, y)
     got = gp.logp(p)
     assert gp._cache['stats']['tries'] >= 1
-    assert abs(got - ref) <= 1e-5 * abs(ref)         # identical jitter; rank-deficient => looser tolerance
+    # identical jitter schedule; measured 2e-12 here and <= 1e-11 up to N=3000 (profiles/r02_jitter_accuracy.txt:
+    # the difference to LAPACK comes from the factor's rounding, not from the inverse-based panel solves)
+    assert abs(got - ref) <= 1e-8 * abs(ref)
 
 
 def test_fp32_process_close_to_fp64(golden_dir):
