@@ -28,10 +28,12 @@ constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
 // FETCH_SIZE, profiles/r02_summary.md): 2 -> 66.8 TFLOP/s, 23.0 GB fetched; 4 -> 66.3, 22.6 GB;
 // 8 -> 65.9, 24.7 GB; 16 -> 64.8, 28.2 GB
 constexpr int GROUP_M = 4;
-#ifndef G3_SMALL_STAGES
-#define G3_SMALL_STAGES 4  // LDS buffers of the 64 x 64 and 32 x 128 tiles (latency-bound critical-path products)
-#endif
-constexpr int SMALL_STAGES = G3_SMALL_STAGES;
+// LDS buffers per tile configuration.  Two everywhere: deeper pipelines (four buffers) were measured on
+// the small tiles and LOST -- 64 / 80 KiB of LDS per workgroup no longer fits into the slot a retiring
+// bulk workgroup leaves behind, so the critical-path launches wait for several to retire at once
+// (N = 16384: 36.2 -> 38.1 ms; 8192: 8.8 -> 9.2 ms), while the uncontended latency of a tiny product
+// barely moves (12.0 -> 11.6 us).  The kernel keeps the general NSTAGE loop.
+constexpr int STAGES = 2;
 
 // ---- tile raster.  The host describes the ACTIVE tiles of a launch as a list of row groups (a few
 // consecutive row tiles each) with a column-tile count per group; the table travels by value in the
@@ -174,10 +176,8 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
 
   // NSTAGE LDS buffers, NSTAGE - 1 K tiles of DMA in flight.  The big tile is matrix-pipe bound
   // (64 MFMAs = 4096 cycles per K tile and wave, twice that with the partner workgroup): two
-  // buffers hide a memory round trip completely.  The small tiles of the critical path are not:
-  // a 64 x 64 tile has 0.5 us of MFMA per K tile against 1-2 us of load latency, so with two
-  // buffers every K tile costs a full round trip (K = 256: 33 us measured for a 10-tile SYRK);
-  // four buffers keep three round trips in flight.
+  // buffers hide a memory round trip completely.  (See STAGES above for why the small tiles stay
+  // at two buffers as well.)
   const int KT = K / BK;
   constexpr int LPS = BM / 8 / NW + BN / 8 / NW;           // DMA instructions per wave and stage
   static_assert((NSTAGE - 2) * LPS <= 63, "vmcnt range");
@@ -452,12 +452,12 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
     forced = e ? atoi(e) : 0;
   }
   if (forced == 1 && sh.kind != 2 && sh.m % 256 == 0 && sh.n % 128 == 0)
-    return launch_cfg<T, 256, 128, 64, 64, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 256, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 2 && all128)
-    return launch_cfg<T, 128, 128, 64, 64, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 4 && sh.kind != 2 && sh.n % 128 == 0)
-    return launch_cfg<T, 32, 128, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 32, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   // Tile choice (measured on MI355X, scripts/gemm_bench.py):
   //  * in-place panel solves (`wide`, C aliases A, n = 128): thin 32 x 128 tiles always -- one
   //    tile must span the 128 output columns, and 4x more workgroups beat 128 x 128 tiles from
@@ -468,21 +468,14 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   // (a 256 x 128 tile, one block per CU, was 4-5 % slower than 128 x 128 everywhere.)
   if (wide) {
     if (sh.kind == 0 && sh.n % 128 == 0 && sh.m % 32 == 0)
-      return launch_cfg<T, 32, 128, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+      return launch_cfg<T, 32, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
     snprintf(ctx->err, sizeof(ctx->err), "in-place panel GEMM needs n %% 128 == 0 and m %% 32 == 0 (m=%lld n=%lld)",
              (long long)sh.m, (long long)sh.n);
     return G3_ERR_HIP;
   }
   if (all128 && blocks128 >= big_tile_min())
-    return launch_cfg<T, 128, 128, 64, 64, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  // 64 x 64 tiles: a small grid is latency-bound (deep pipeline, 2 workgroups per CU are plenty); a
-  // grid that fills the chip several times over is throughput-bound and wants the occupancy of the
-  // two-buffer variant (5 workgroups per CU)
-  static int64_t deep_max = -1;
-  if (deep_max < 0) { const char* e = getenv("G3_DEEP_MAX"); deep_max = e ? atoll(e) : 1024; }
-  if ((int64_t)(shape_elems(sh) / (64.0 * 64.0)) * g3_nbatch(ctx) <= deep_max)
-    return launch_cfg<T, 64, 64, 32, 32, SMALL_STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  return launch_cfg<T, 64, 64, 32, 32, 2>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+    return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
 }
 
 static int launch_dt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
