@@ -9,6 +9,7 @@ Python host code -> ctypes -> libg3hip.so (hand-written HIP for gfx950).  No CPU
 from .libs import DictObj, clone
 from .libs.tensors import makefn, cholesky_robust, tt_to_num, tt_to_cov, tt_to_bounded, solve_lower_triangular
 from .processes import *
+from .bayesian import Experiment, random_obs, uniform_obs
 from .device import Device, DeviceArray, compile_spec
 from ._lib import G3Error
 

@@ -655,3 +655,39 @@ def test_sampler_single_call_and_vectorised_mapping(golden_dir):
         ref = o.sampler(Xs, X, y, rand=Z, prior=prior)
         assert got.shape == (37, 5)
         np.testing.assert_allclose(got, ref, atol=2e-6)
+
+
+def test_experiment_harness_scores_and_timings():
+    """Experiment (selection.py:43-338): split -> observe -> scores on observations / hold-out / test with the
+    time_* columns; the test scores equal a by-hand predict on the same split"""
+    import g3py_amd as g3
+    np.random.seed(4)
+    x = np.linspace(0, 4, 160)[:, None]
+    y = np.sin(2 * x[:, 0]) + 0.05 * np.random.randn(160)
+    models = [g3.GP(space=x, location=g3.Zero(), kernel=g3.SE(x), name='A'),
+              g3.GP(space=x, location=g3.Bias(x), kernel=g3.MAT32(x), name='B')]
+    ex = g3.Experiment(models)
+    ex.data(x, y, p=0.4, method='random', include_min=True)
+    ex.scores(logpred=True, mean=True, median=False, variance=True)
+    ex.model_selection(holdout='_l2', holdout_p=0.25)
+    ex.run(n_simulations=2)
+    ex.run(n_simulations=0, repeat=[0])                       # a stored split again
+    res = ex.results()
+    assert len(res) == 6 and set(res.model) == {'A', 'B'} and len(ex.simulations()) == 2
+    for c in ('time_params', 'time_obs', 'time_valid', 'time_test', 'obs_l1', 'valid_l2', 'test_l2', 'test_mse', 'test_nlpd'):
+        assert c in res.columns and np.all(np.isfinite(res[c].astype(float)))
+    assert (res.time_obs > 0).all() and (res.time_test > 0).all()
+    # by hand: model A on split 0, conditioned on observations + hold-out, scored on the test points
+    sim = ex.simulations().loc[0]
+    tr = np.concatenate([sim['obs'], sim['valid']])
+    gp = g3.GP(space=x[sim['test']], location=g3.Zero(), kernel=g3.SE(x), name='A')
+    gp.observed(x[sim['obs']], y[sim['obs']])
+    p = gp.params_default                                       # what the experiment used (defaults from the observations)
+    gp.observed(x[tr], y[tr])
+    want = np.mean((gp.mean(p) - y[sim['test']]) ** 2)
+    got = float(res[(res.n_sim == 0) & (res.model == 'A')].iloc[0].test_l2)
+    assert abs(got - want) <= 1e-9 * max(1.0, abs(want))
+    rep = res[(res.n_sim == 0) & (res.model == 'A')].test_l2.astype(float).values
+    assert len(rep) == 2 and abs(rep[0] - rep[1]) <= 1e-12
+    with pytest.raises(NotImplementedError):
+        ex.model_selection(find_MAP=True)
