@@ -22,6 +22,10 @@ class Difference(Metric):
 
 
 class ARD(Metric):
+    """automatic-relevance-determination metrics: one positive rate per selected column.  The default rate
+    is `default_scale` / (mean spacing of consecutive rows) per column (metrics.py:93-95, 104-108)."""
+    default_scale = 1.0
+
     def __init__(self, x, name=None, rate=None):
         super().__init__(x, name)
         self.rate = rate
@@ -30,23 +34,23 @@ class ARD(Metric):
         super().check_hypers(parent=parent)
         if self.rate is None:
             self.rate = Hypers.FlatExp(parent + 'rate', shape=self.shape)
-        self.hypers += [self.rate]
+        self.hypers.append(self.rate)
+
+    def default_hypers(self, x=None, y=None):
+        try:
+            spacing = np.abs(np.diff(x, axis=0)).mean(axis=0)
+        except Exception:
+            return {}
+        return {self.rate: self.default_scale / spacing}
 
 
 class ARD_L1(ARD):
     """dot(|x1 - x2|, rate) -- metrics.py:89-91"""
     kind = 'l1'
-
-    def default_hypers(self, x=None, y=None):
-        return {self.rate: 1 / np.abs(x[1:] - x[:-1]).mean(axis=0)}
+    default_scale = 1.0
 
 
 class ARD_L2(ARD):
     """dot((x1 - x2)**2, 0.5 * rate**2) -- metrics.py:100-102"""
     kind = 'l2'
-
-    def default_hypers(self, x=None, y=None):
-        try:
-            return {self.rate: 0.5 / np.abs(x[1:] - x[:-1]).mean(axis=0)}
-        except Exception:
-            return {}
+    default_scale = 0.5

@@ -79,16 +79,18 @@ class GraphicalModel:
         return sorted(set(range(self.ndim)) - set(self.fixed_dims))
 
     def sampling_params(self, params):
-        if isinstance(params, dict):
-            return self.dict_to_array(params)[self.sampling_dims]
-        return np.asarray(params)[self.sampling_dims]
+        """the entries an optimiser / sampler moves, from a dict or a flat vector"""
+        flat = self.dict_to_array(params) if isinstance(params, dict) else np.asarray(params)
+        return flat[self.sampling_dims]
 
     def dict_from_sampling_array(self, params):
-        if self.fixed_datatrace is None:
-            return self.array_to_dict(params)
-        r = self.dict_to_array(self.params)
-        r[self.sampling_dims] = params
-        return self.array_to_dict(r)
+        """inverse of sampling_params: the moved entries spliced into the current parameter vector"""
+        flat = np.asarray(params, dtype=np.float64)
+        if self.fixed_datatrace is not None:
+            full = self.dict_to_array(self.params)
+            full[self.sampling_dims] = flat
+            flat = full
+        return self.array_to_dict(flat)
 
     # ---- parameters
     def set_params(self, params=None):
@@ -96,9 +98,8 @@ class GraphicalModel:
 
     @property
     def params(self):
-        if self.current_params is not None:
-            return clone(self.current_params)
-        return self.params_default
+        """a copy of the parameters set with set_params, else the defaults"""
+        return self.params_default if self.current_params is None else clone(self.current_params)
 
     @property
     def params_test(self):
@@ -107,14 +108,18 @@ class GraphicalModel:
     @property
     def params_default(self):
         """models.py:174-182 + transformed_hypers (:46-53): defaults in transformed space"""
-        default = self.params_test
-        for name, component in self.components.items():
-            for k, v in component.default_hypers().items():
-                if k in self.model.vars:
-                    v = np.asarray(v, dtype=np.float64)
+        out = self.params_test
+        mine = set(self.model.vars)
+        for component in self.components.values():
+            for var, natural in component.default_hypers().items():
+                if var not in mine:
+                    continue
+                value = np.asarray(natural, dtype=np.float64)
+                if var.positive:
                     with np.errstate(all='ignore'):
-                        default[k.key] = (np.log(v) if k.positive else v).reshape(k.shape)
-        return default
+                        value = np.log(value)
+                out[var.key] = value.reshape(var.shape)
+        return out
 
     def transform_params(self, params, to_dict=True, to_transformed=True, complete=False):
         """natural <-> transformed names and values (models.py:232-260)"""
@@ -140,36 +145,18 @@ class StochasticProcess:
     def __init__(self, space=None, order=None, inputs=None, outputs=None, hidden=None, index=None,
                  name='SP', distribution=None, active=False, precompile=False, file=None, load=True,
                  compile_logp=True, dtype=np.float64, device=None, *args, **kwargs):
-        ndim = 1
         self.makefn = makefn
-        if space is not None:
-            if hasattr(space, 'shape'):
-                if len(space.shape) > 1:
-                    ndim = space.shape[1]
-            else:
-                ndim = int(space)
-        self.nspace = ndim
+        self.nspace = self._columns_of(space)
         self.name = name
         self.dtype = np.dtype(dtype)
         self._device = device
-        dt = self.dtype
-        # the reference's Theano shared variables start as these 2-point dummies (:46-56)
-        self._order = np.array([0.0, 1.0], dtype=dt)
-        self._space = np.array([[0.0, 1.0]] * self.nspace, dtype=dt).T
-        self._index = np.array([0.0, 1.0], dtype=dt)
-        self._inputs = np.array([[0.0, 1.0]] * self.nspace, dtype=dt).T
-        self._outputs = np.array([0.0, 1.0], dtype=dt)
-        self.is_observed = False
-        self.np_hidden = None
-        self.distribution = distribution
-        if active is True:
-            if GraphicalModel.active is None:
-                GraphicalModel.active = GraphicalModel('GM_' + self.name)
-            self.active = GraphicalModel.active
-        elif active is False:
-            self.active = GraphicalModel('GM_' + self.name)
-        else:
-            self.active = active
+        # until set_space / observed supply data every array is the reference's 2-point dummy (:46-56)
+        pair = np.array([0.0, 1.0], dtype=self.dtype)
+        grid = np.tile(pair[:, None], (1, self.nspace))
+        self._order, self._index, self._outputs = pair.copy(), pair.copy(), pair.copy()
+        self._space, self._inputs = grid.copy(), grid.copy()
+        self.is_observed, self.np_hidden, self.distribution = False, None, distribution
+        self.active = self._graph_for(active)
         self.active.add_component(self)
         self.compiles = DictObj()
         self.precompile = precompile
@@ -182,6 +169,24 @@ class StochasticProcess:
         self._compile_methods(compile_logp)
         if hidden is None:
             self.hidden = hidden
+
+    @staticmethod
+    def _columns_of(space):
+        """number of input columns: from an array's second axis, or given directly as an int"""
+        if space is None:
+            return 1
+        shape = getattr(space, 'shape', None)
+        if shape is None:
+            return int(space)
+        return shape[1] if len(shape) > 1 else 1
+
+    def _graph_for(self, active):
+        """True: the shared model of all active=True processes; False: a private one; else the given one"""
+        if active is True:
+            if GraphicalModel.active is None:
+                GraphicalModel.active = GraphicalModel('GM_' + self.name)
+            return GraphicalModel.active
+        return GraphicalModel('GM_' + self.name) if active is False else active
 
     # ---- parameters
     def set_params(self, *args, **kwargs):
@@ -322,14 +327,10 @@ class StochasticProcess:
                 self._compiled('th_logp', prior, False, True, (), {})
 
     def _compiled(self, method, prior, noise, array, args, kwargs):
-        name = ('prior' if prior else 'posterior') + method.replace('th', '')
-        if noise:
-            name += '_noise'
-        if len(args) > 0:
-            name += str(args)
-        if len(kwargs) > 0:
-            name += str(kwargs)
-        if not hasattr(self.compiles, name):
+        # registry key, e.g. posterior_logp, prior_kernel_sd_noise (boundary: stochastic.py:404-415)
+        name = ''.join(['prior' if prior else 'posterior', method.replace('th', ''), '_noise' if noise else '',
+                        str(args) if args else '', str(kwargs) if kwargs else ''])
+        if name not in self.compiles:
             impl = getattr(self, method)
 
             def fn(space, inputs, outputs, vector, params, _impl=impl):
@@ -339,11 +340,12 @@ class StochasticProcess:
             self.compiles[name] = self.makefn(th_vars, fn, givens=[('space', 'space_th'), ('inputs', 'inputs_th'),
                                                                     ('outputs', 'outputs_th')],
                                               bijection=None, precompile=self.precompile)
-        if array:
-            if not hasattr(self.compiles, 'array_' + name):
-                self.compiles['array_' + name] = self.compiles[name].clone(self.active.bijection.rmap)
-            name = 'array_' + name
-        return self.compiles[name]
+        if not array:
+            return self.compiles[name]
+        flat = 'array_' + name               # same function behind the flat-vector -> dict bijection
+        if flat not in self.compiles:
+            self.compiles[flat] = self.compiles[name].clone(self.active.bijection.rmap)
+        return self.compiles[flat]
 
     def _call_defaults(self, params, space, inputs, outputs, prior, array):
         """fill in what a caller left out (boundary: stochastic.py:387-402): current parameters (as a
@@ -448,10 +450,7 @@ class StochasticProcess:
 
     def logp_chain(self, chain, prior=False):
         """stochastic.py:515-520: one logp per row of a flat-parameter chain"""
-        out = np.empty(len(chain))
-        for i in range(len(out)):
-            out[i] = self.logp(chain[i], array=True, prior=prior)
-        return out
+        return np.array([self.logp(row, array=True, prior=prior) for row in chain], dtype=np.float64)
 
     # ---- averages over a fixed chain (stochastic.py:522-564): the rows of active.fixed_chain with
     #      the sampling dimensions overwritten by `sampling_params`
