@@ -284,21 +284,18 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
 // tiles exist only while they are live: A(W, j) is written out the moment it is final (step j),
 // W(W, j) comes into existence at step j, and nothing is live across the call that factors the
 // diagonal tile (wave W publishes its old W row before it, and rebuilds the row from LDS after).
+// diag128_core works on the caller's accumulator tiles aA (tiles (W, 0..W) of the block, lower part):
+// diag128_wave loads them from A; the fused 256-wide kernel below hands over the second diagonal block
+// straight from the registers it has just updated it in.  WT != nullptr: the finished inverse is also left
+// in LDS as 16 x 16 tiles (tile (i, j), j <= i, at index i (i + 1) / 2 + j), aliasing S -- the core
+// synchronises before and after writing them.
 template <typename T, bool FACTOR, int W>
-__device__ __forceinline__ void diag128_wave(T* A, int64_t ld, T* Wg, int64_t ldw, int* info, int64_t row_base,
-                                             DiagLds<T>& S, int lane) {
+__device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8], T* A, int64_t ld, T* Wg, int64_t ldw,
+                                             int* info, int64_t row_base, DiagLds<T>& S, int lane, T* WT) {
   using TO = TileOps<T>;
   using acc_t = typename TO::acc_t;
   using M = MfmaT<T>;
-  acc_t aA[8], aW[8];
-#pragma unroll
-  for (int j = 0; j <= W; ++j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * W + M::row(lane, r), col = 16 * j + (lane & 15);
-      aA[j][r] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
-    }
-  }
+  acc_t aW[8];
   // Per block step: [wave k: 16 x 16 factor + inverse] B1 [waves i > k: panel tile and
   // T_i = L(i,k) W_dd] B2 [trailing updates; wave k rebuilds its own W row meanwhile].  Buffers
   // written by wave k+1 for the NEXT step have the other parity, so no third barrier is needed and
@@ -360,6 +357,131 @@ __device__ __forceinline__ void diag128_wave(T* A, int64_t ld, T* Wg, int64_t ld
       if (j <= W) v = (row >= col) ? aW[j <= W ? j : 0][r] : T(0);
       Wg[(int64_t)row * ldw + col] = v;
     }
+  }
+  if (WT != nullptr) {
+    __syncthreads();                       // every wave is done with S: its memory becomes the tile array
+#pragma unroll
+    for (int j = 0; j <= W; ++j) {
+      acc_t t = aW[j];
+      if (j == W) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = (M::row(lane, r) >= (lane & 15)) ? t[r] : T(0);
+      }
+      TO::store(WT + (W * (W + 1) / 2 + j) * (16 * TS), t, lane);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, bool FACTOR, int W>
+__device__ __forceinline__ void diag128_wave(T* A, int64_t ld, T* Wg, int64_t ldw, int* info, int64_t row_base,
+                                             DiagLds<T>& S, int lane, T* WT = nullptr) {
+  using M = MfmaT<T>;
+  typename TileOps<T>::acc_t aA[8];
+#pragma unroll
+  for (int j = 0; j <= W; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * W + M::row(lane, r), col = 16 * j + (lane & 15);
+      aA[j][r] = (row >= col) ? A[(int64_t)row * ld + col] : T(0);
+    }
+  }
+  diag128_core<T, FACTOR, W>(aA, A, ld, Wg, ldw, info, row_base, S, lane, WT);
+}
+
+// ---- fused factorisation of a 256 x 256 diagonal block by ONE workgroup:
+//   diag(A00) -> L10 = A10 W0^T -> A11 -= L10 L10^T -> diag(A11)
+// i.e. the four launches of potrf_rec(256) (two diagonal kernels, one in-place panel product, one SYRK)
+// as one: on the critical path of every factorisation each launch costs its ~12 us of fixed latency --
+// 2-4x that while a bulk update streams through the same CUs -- for 4 MFLOP of work.  The two products
+// run on the same eight waves: W0 stays in LDS as tiles (in the memory the diagonal phase has
+// finished with), A10 is read straight into MFMA operand registers, L10 goes through LDS in two
+// 64-column halves for the SYRK, and the updated A11 never leaves the accumulators it is factored from.
+template <typename T, int W>
+__device__ __forceinline__ void potrf256_wave(T* A, int64_t ld, T* Wg, int* info, int64_t row_base, DiagLds<T>& S, int lane) {
+  using TO = TileOps<T>;
+  using acc_t = typename TO::acc_t;
+  using M = MfmaT<T>;
+  constexpr int TSZ = 16 * TS;
+  T* tiles = reinterpret_cast<T*>(&S);                                  // aliases S between the diagonal phases
+  static_assert(sizeof(DiagLds<T>) >= 36 * TSZ * sizeof(T), "tile array must fit in the diagonal kernel's LDS");
+  diag128_wave<T, true, W>(A, ld, Wg, G3_LB, info, row_base, S, lane, tiles);
+  T* A10 = A + (int64_t)G3_LB * ld;
+  T* A11 = A10 + G3_LB;
+  const int frow = lane & 15, kq = lane >> 4;
+  // ---- L10(W, j) = sum_{c <= j} A10(W, c) W0(j, c)^T
+  acc_t L[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) L[j] = acc_t{0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    T a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = A10[(int64_t)(16 * W + frow) * ld + 16 * c + 4 * q + kq];
+#pragma unroll
+    for (int j = c; j < 8; ++j) {
+      const T* y = tiles + (j * (j + 1) / 2 + c) * TSZ + frow * TS + kq;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L[j] = M::mfma(a[q], y[4 * q], L[j]);
+      __builtin_amdgcn_sched_barrier(0);   // one tile product at a time: the scheduler must not hoist later
+    }                                      // operand loads into this one's registers (144-VGPR budget)
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A10[(int64_t)(16 * W + M::row(lane, r)) * ld + 16 * j + frow] = L[j][r];
+  // ---- A11(W, j) -= sum_c L10(W, c) L10(j, c)^T, j <= W, in two halves of c through LDS.  (A11 is
+  // loaded only after the first half of L10 has left the registers: the kernel must stay within the 144
+  // VGPRs that let it run next to a bulk GEMM workgroup, like the 128-wide diagonal kernel.)
+  acc_t aA[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                       // the W0 tiles (h = 0) / the first half (h = 1) are no longer read
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) TO::store(tiles + (W * 4 + cc) * TSZ, L[4 * h + cc], lane);
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j <= W; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * W + M::row(lane, r), col = 16 * j + frow;
+          aA[j][r] = (row >= col) ? A11[(int64_t)row * ld + col] : T(0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= W; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        aA[j] = TO::mul_nt(tiles + (W * 4 + cc) * TSZ, tiles + (j * 4 + cc) * TSZ, aA[j], T(-1), lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) aA[W][r] = (M::row(lane, r) >= frow) ? aA[W][r] : T(0);   // strict upper part of the diagonal tile
+  __syncthreads();                         // S is about to be used as DiagLds again
+  diag128_core<T, true, W>(aA, A11, ld, Wg + G3_LB * G3_LB, G3_LB, info, row_base + G3_LB, S, lane, nullptr);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: must fit beside a bulk GEMM workgroup (2 x 128 + 224 <= 512 per SIMD)
+potrf256_kernel(T* A, int64_t ld, T* W, int* info, int64_t row_base, int64_t a_batch, int64_t w_batch) {
+  info += blockIdx.y;                       // batch member (grid.y)
+  if (*info != 0) return;
+  A += (int64_t)blockIdx.y * a_batch;
+  W += (int64_t)blockIdx.y * w_batch;
+  __shared__ DiagLds<T> S;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  switch (w) {
+    case 0: potrf256_wave<T, 0>(A, ld, W, info, row_base, S, lane); break;
+    case 1: potrf256_wave<T, 1>(A, ld, W, info, row_base, S, lane); break;
+    case 2: potrf256_wave<T, 2>(A, ld, W, info, row_base, S, lane); break;
+    case 3: potrf256_wave<T, 3>(A, ld, W, info, row_base, S, lane); break;
+    case 4: potrf256_wave<T, 4>(A, ld, W, info, row_base, S, lane); break;
+    case 5: potrf256_wave<T, 5>(A, ld, W, info, row_base, S, lane); break;
+    case 6: potrf256_wave<T, 6>(A, ld, W, info, row_base, S, lane); break;
+    default: potrf256_wave<T, 7>(A, ld, W, info, row_base, S, lane); break;
   }
 }
 
@@ -428,8 +550,25 @@ static int trsm_rec(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64
 }
 
 template <typename T>
+static int potrf_diag256(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base) {
+  const int pr = g3i_prof_begin(ctx, G3_TAG_LEAF, 256.0 * 256.0 * 256.0 / 3.0);
+  hipLaunchKernelGGL((potrf256_kernel<T>), dim3(1, (unsigned)g3_nbatch(ctx)), dim3(512), 0, ctx->stream, A, ld, W,
+                     ctx->d_info, row_base, g3_bstride_of(ctx, A), g3_bstride_of(ctx, W));
+  g3i_prof_end(ctx, pr);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+static bool fused256() {       // G3_FUSED256=0: the four-launch recursion (development comparison)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("G3_FUSED256"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
+template <typename T>
 static int potrf_rec(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t row_base, g3_dtype dt) {
   if (n == LB) return potrf_diag<T>(ctx, A, ld, W, row_base, dt);
+  if (n == 2 * LB && fused256()) return potrf_diag256<T>(ctx, A, ld, W, row_base);
   const int64_t n1 = split_point(n, LB), n2 = n - n1;
   int rc = potrf_rec<T>(ctx, A, n1, ld, W, row_base, dt);
   if (rc) return rc;
