@@ -59,17 +59,15 @@ struct RasterTab {
   unsigned short b_blk[G3_RASTER_MAX];
 };
 
+// One output tile: C[m0.., n0..] = alpha * A_rows * B_rows^T + beta * C, with gA / gB the first row of the
+// tile's A / B operand (k contiguous).  Shared by the GEMM kernel (one tile per workgroup) and the
+// stripe-local triangular solve (a workgroup runs a sequence of tiles on its own rows).  Ends with the
+// workgroup synchronised and the staging LDS free again.
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
-gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
-               int K, T alpha, T beta, const int* __restrict__ info,
-               int64_t bsC, int64_t bsA, int64_t bsB, const RasterTab tab) {
+__device__ __forceinline__ void gemm_tile(T* C, int64_t ldc, const T* gA, int64_t lda, const T* gB, int64_t ldb,
+                                          int K, T alpha, T beta, int m0, int n0, bool lower_only, int doff,
+                                          int failed, char* smem) {
   using M = MfmaT<T>;
-  // batch member (grid.y); strides are 0 for a single product
-  C += (int64_t)blockIdx.y * bsC;
-  A += (int64_t)blockIdx.y * bsA;
-  B += (int64_t)blockIdx.y * bsB;
-  if (info != nullptr) info += blockIdx.y;
   using chunk_t = typename M::chunk_t;
   using acc_t = typename M::acc_t;
   constexpr int EPC = M::EPC;
@@ -77,37 +75,6 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   constexpr int NWN = BN / WN;
   constexpr int NT = (BM / WM) * NWN * 64;
   constexpr int TM = WM / 16, TN = WN / 16;
-
-  // ---- tile assignment: XCD-aware, grouped raster over the ACTIVE tiles only.
-  // Workgroups are dealt round-robin over the 8 XCDs, so ids {x, x+8, ...} share an L2;
-  // remap so that each XCD walks a contiguous range of "virtual" ids, and order virtual
-  // ids group by group, column-major inside a group: the ~32 tiles an XCD works on at any
-  // time then form a (group height) x 8 patch that shares 4 A panels and 8 B panels through
-  // its L2 instead of streaming 32 distinct B panels from HBM.
-  int bm, bn;
-  {
-    const int nwg = gridDim.x, id = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    int lo = 0, hi = tab.ngroups;            // largest g with prefix[g] <= v  (prefix[0] = 0, v < prefix[ngroups])
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tab.g[mid].prefix <= v) lo = mid; else hi = mid;
-    }
-    const int w = v - tab.g[lo].prefix;
-    const int rows = (int)tab.g[lo].nrows;
-    bn = w / rows;
-    bm = (int)tab.g[lo].row0 + (w - bn * rows);
-  }
-  const int doff = tab.diag_off;
-  const bool lower_only = doff < G3_DENSE_OFF;
-  const int m0 = bm * BM, n0 = bn * BN;
-  if (lower_only && n0 > m0 + BM - 1 + doff) return;    // a tile of a group above its own row's limit
-  // a failed pivot earlier in the sweep turns every later launch into a no-op; the flag is requested
-  // now and tested only before the first store, so its round trip hides under the first DMA
-  const int failed = (info != nullptr) ? *info : 0;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                           // [NSTAGE][BM][ROWB]
   char* sB = smem + NSTAGE * BM * ROWB;      // [NSTAGE][BN][ROWB]
 
@@ -127,13 +94,6 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
   // c ^ ((r >> 1) & 7), which is what the fragment reads below expect.
   constexpr int NW = NT / 64;
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "rows per wave-instruction");
-  const T* gA = A + (int64_t)m0 * lda;
-  int64_t brow = n0;
-  if (tab.b_nb > 0) {
-    const int sblk = n0 / tab.b_nb;
-    brow = (int64_t)tab.b_blk[sblk] * tab.b_nb + (n0 - sblk * tab.b_nb);
-  }
-  const T* gB = B + brow * ldb;
   const int sr = lane >> 3, sc = lane & 7;
   auto stage = [&](int buf, int k0) {
     char* a = sA + buf * BM * ROWB;
@@ -227,7 +187,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
   }
   __syncthreads();            // the epilogue re-uses the staging LDS
-  if (failed != 0) return;
+  if (failed != 0) return;    // uniform: every thread of every workgroup reads the same flag
 
   // ---- epilogue.  The accumulators are in MFMA layout (a lane holds 4 rows x 1 column of each
   // 16 x 16 tile): written straight to C that is 128-byte pieces scattered over 64 rows per
@@ -280,7 +240,7 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     }
     return;
   }
-  // fallback (C not 16-byte aligned): element-wise from the MFMA layout
+  // fallback (C not 16-byte aligned): element-wise from the MFMA layout; no LDS involved
   const int col_l = lane & 15;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -298,6 +258,96 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
       }
     }
 }
+
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
+gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+               int K, T alpha, T beta, const int* __restrict__ info,
+               int64_t bsC, int64_t bsA, int64_t bsB, const RasterTab tab) {
+  // batch member (grid.y); strides are 0 for a single product
+  C += (int64_t)blockIdx.y * bsC;
+  A += (int64_t)blockIdx.y * bsA;
+  B += (int64_t)blockIdx.y * bsB;
+  if (info != nullptr) info += blockIdx.y;
+
+  // ---- tile assignment: XCD-aware, grouped raster over the ACTIVE tiles only.
+  // Workgroups are dealt round-robin over the 8 XCDs, so ids {x, x+8, ...} share an L2;
+  // remap so that each XCD walks a contiguous range of "virtual" ids, and order virtual
+  // ids group by group, column-major inside a group: the ~32 tiles an XCD works on at any
+  // time then form a (group height) x 8 patch that shares 4 A panels and 8 B panels through
+  // its L2 instead of streaming 32 distinct B panels from HBM.
+  int bm, bn;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    int lo = 0, hi = tab.ngroups;            // largest g with prefix[g] <= v  (prefix[0] = 0, v < prefix[ngroups])
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tab.g[mid].prefix <= v) lo = mid; else hi = mid;
+    }
+    const int w = v - tab.g[lo].prefix;
+    const int rows = (int)tab.g[lo].nrows;
+    bn = w / rows;
+    bm = (int)tab.g[lo].row0 + (w - bn * rows);
+  }
+  const int doff = tab.diag_off;
+  const bool lower_only = doff < G3_DENSE_OFF;
+  const int m0 = bm * BM, n0 = bn * BN;
+  if (lower_only && n0 > m0 + BM - 1 + doff) return;    // a tile of a group above its own row's limit
+  // a failed pivot earlier in the sweep turns every later launch into a no-op; the flag is requested
+  // now and tested only before the first store, so its round trip hides under the first DMA
+  const int failed = (info != nullptr) ? *info : 0;
+  int64_t brow = n0;
+  if (tab.b_nb > 0) {
+    const int sblk = n0 / tab.b_nb;
+    brow = (int64_t)tab.b_blk[sblk] * tab.b_nb + (n0 - sblk * tab.b_nb);
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_tile<T, BM, BN, WM, WN, NSTAGE>(C, ldc, A + (int64_t)m0 * lda, lda, B + brow * ldb, ldb, K, alpha, beta, m0, n0,
+                                       lower_only, doff, failed, smem);
+}
+
+// ---- stripe-local triangular solve: X <- X L^-T for a tall panel X (m x n, n <= 1024) in ONE launch.
+// The solve is independent row by row, so a workgroup owns a 32-row stripe of X and runs the whole
+// recursion of blocked products on it, in place:  leaf  X_j <- X_j W_j^T  (W_j = inverse of the j-th
+// 128 x 128 diagonal block; one 32 x 128 tile spans the block, so its rows are read before they are
+// overwritten)  and  update  X_hi -= X_lo L_hi,lo^T.  Each step reads what earlier steps of the SAME
+// workgroup wrote; the barrier between steps carries workgroup-scope release / acquire.  Replaces the
+// 2 n/128 - 1 launches of the recursive solve on the factorisation's critical path.
+constexpr int G3_TRSM_MAXOPS = 20;          // n <= 1024: 8 leaves + 12 update tiles of 128 columns
+struct TrsmOps {
+  int nops;
+  struct Op {      // one 32 x 128 output tile
+    int col;       // first column of the tile written
+    int acol;      // first column of the left operand (leaf: col)
+    int k;         // reduction length
+    int brow, bcol;  // leaf: index of the 128 x 128 inverse block (bcol unused); update: row / column of the L block
+    int leaf;
+  } op[G3_TRSM_MAXOPS];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const int* __restrict__ info,
+                   int64_t bsX, int64_t bsL, int64_t bsW, const TrsmOps ops) {
+  X += (int64_t)blockIdx.y * bsX;
+  L += (int64_t)blockIdx.y * bsL;
+  W += (int64_t)blockIdx.y * bsW;
+  if (info != nullptr) info += blockIdx.y;
+  const int failed = (info != nullptr) ? *info : 0;
+  if (failed != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int m0 = blockIdx.x * 32;
+  for (int i = 0; i < ops.nops; ++i) {
+    const auto o = ops.op[i];
+    const T* gB = o.leaf ? W + (int64_t)o.brow * G3_LB * G3_LB : L + (int64_t)o.brow * ldl + o.bcol;
+    gemm_tile<T, 32, 128, 32, 32, STAGES>(X, ldx, X + (int64_t)m0 * ldx + o.acol, ldx, gB, o.leaf ? (int64_t)G3_LB : ldl, o.k,
+                                          o.leaf ? T(1) : T(-1), o.leaf ? T(0) : T(1), m0, o.col, false, G3_DENSE_OFF, 0, smem);
+    __syncthreads();          // this tile's stores are visible to the workgroup's next step
+  }
+}
+
 
 // ---- host side: which elements of C a launch produces
 struct GemmShape {
@@ -506,6 +556,64 @@ int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t l
   if (m == 0 || n == 0) return G3_OK;
   const GemmShape sh{1, m, n, diag_off, 0, nullptr, nullptr, 0, nullptr, 0};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
+}
+
+// ---- stripe-local solve X <- X L^-T (X: m x n rows of a panel, n <= 1024, m % 32 == 0), one launch
+static int64_t trsm_split(int64_t n) {     // must mirror split_point() of g3_potrf.hip (same recursion shape)
+  int64_t g = G3_LB;
+  while (g * 2 <= n / 4 && g < 2048) g *= 2;
+  int64_t n1 = g3_roundup(n / 2, g);
+  if (n1 >= n) n1 = n - G3_LB;
+  return n1;
+}
+
+static void trsm_ops_rec(TrsmOps* ops, int64_t c0, int64_t n) {
+  if (n == G3_LB) {
+    auto& o = ops->op[ops->nops++];
+    o.col = (int)c0; o.acol = (int)c0; o.k = G3_LB; o.brow = (int)(c0 / G3_LB); o.bcol = 0; o.leaf = 1;
+    return;
+  }
+  const int64_t n1 = trsm_split(n), n2 = n - n1;
+  trsm_ops_rec(ops, c0, n1);
+  for (int64_t t = 0; t < n2; t += G3_LB) {       // X[:, c0+n1+t .. +128) -= X[:, c0 .. c0+n1) L[c0+n1+t .., c0 ..)^T
+    auto& o = ops->op[ops->nops++];
+    o.col = (int)(c0 + n1 + t); o.acol = (int)c0; o.k = (int)n1; o.brow = (int)(c0 + n1 + t); o.bcol = (int)c0; o.leaf = 0;
+  }
+  trsm_ops_rec(ops, c0 + n1, n2);
+}
+
+template <typename T>
+static int trsm_stripe_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* X, int64_t m, int64_t ldx, const T* W) {
+  constexpr int LDS = STAGES * (32 + 128) * ROWB;
+  auto kern = trsm_stripe_kernel<T>;
+  static bool attr_set[G3_MAX_DEVICES] = {};
+  const int dev_slot = ctx->device & (G3_MAX_DEVICES - 1);
+  if (!attr_set[dev_slot]) {
+    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set[dev_slot] = true;
+  }
+  TrsmOps ops;
+  ops.nops = 0;
+  trsm_ops_rec(&ops, 0, n);
+  const int pr = g3i_prof_begin(ctx, G3_TAG_GEMM_SMALL, (double)m * (double)n * (double)n);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(m / 32), (unsigned)g3_nbatch(ctx)), dim3(256), LDS, ctx->stream, X, ldx, L, ldl, W,
+                     ctx->d_info, g3_bstride_of(ctx, X), g3_bstride_of(ctx, L), g3_bstride_of(ctx, W), ops);
+  g3i_prof_end(ctx, pr);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+// L: n x n lower (its diagonal blocks' inverses in W, 128 x 128 each), X: m x n, in place.  Returns 1 when
+// the shape is outside what one launch covers (the caller recurses), 0 when done, < 0 on error.
+int g3i_trsm_stripe(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* X, int64_t m, int64_t ldx, const void* W,
+                    g3_dtype dt) {
+  if (n > 1024 || n % G3_LB || m % 32 || m <= 0) return 1;
+  const int64_t al = 16 / (int64_t)g3_esize(dt);
+  if (ldx % al || ldl % al || (((uintptr_t)X | (uintptr_t)L | (uintptr_t)W) & 15)) return 1;
+  int rc;
+  if (dt == G3_F64) rc = trsm_stripe_t<double>(ctx, (const double*)L, n, ldl, (double*)X, m, ldx, (const double*)W);
+  else rc = trsm_stripe_t<float>(ctx, (const float*)L, n, ldl, (float*)X, m, ldx, (const float*)W);
+  return rc;
 }
 
 // staircase: row segment s (seg_rows[s] rows, stacked) gets its first seg_cols[s] columns

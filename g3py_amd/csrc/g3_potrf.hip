@@ -534,9 +534,20 @@ static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_
 }
 
 // ---- across LB blocks
+static bool stripe_trsm() {     // G3_STRIPE_TRSM=0: the recursive multi-launch solve (development comparison)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("G3_STRIPE_TRSM"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 template <typename T>
 static int trsm_rec(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64_t m, int64_t ldb,
                     const T* W, g3_dtype dt) {
+  if (n > LB && n <= 1024 && stripe_trsm()) {
+    // the whole recursion below this point in one launch: a workgroup per 32-row stripe of B
+    const int rc = g3i_trsm_stripe(ctx, L, n, ldl, B, m, ldb, W, dt);
+    if (rc <= 0) return rc;
+  }
   if (n == LB)
     // B <- B W^T in place: one tile spans the 128 output columns, so a workgroup has read
     // its rows before it overwrites them
