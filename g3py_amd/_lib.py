@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libg3hip.so')
+LIB_PATH = os.environ.get('G3_LIB_PATH') or os.path.join(_HERE, 'lib', 'libg3hip.so')   # G3_LIB_PATH: another build (A/B runs)
 
 G3_MAXD, G3_MAXCOLS, G3_MAXLEAF, G3_MAXPROD, G3_MAXFAC = 32, 40, 8, 16, 4
 G3_F64, G3_F32 = 0, 1
