@@ -25,10 +25,12 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, G3_MAX_BATCH * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, 2 * sizeof(g3_kernel_prog));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, G3_PROG_SLOTS * sizeof(g3_kernel_prog));
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_info, G3_MAX_BATCH * sizeof(int), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_stats, 64 * sizeof(double), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_prog, 2 * sizeof(g3_kernel_prog), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_prog, G3_PROG_SLOTS * sizeof(g3_kernel_prog), hipHostMallocDefault);
+  for (int i = 0; i < G3_PROG_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->prog_ev[i], hipEventDisableTiming);
+  ctx->prog_last = -1;
   if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, G3_MAX_BATCH * sizeof(int));
   if (e != hipSuccess) {
     g3_ctx_destroy(ctx);
@@ -47,6 +49,7 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   if (ctx->d_info) (void)hipFree(ctx->d_info);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_prog) (void)hipFree(ctx->d_prog);
+  for (int i = 0; i < G3_PROG_SLOTS; ++i) if (ctx->prog_ev[i]) (void)hipEventDestroy(ctx->prog_ev[i]);
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
   if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
   if (ctx->h_prog) (void)hipHostFree(ctx->h_prog);

@@ -314,13 +314,25 @@ __global__ void gram_diag_kernel(const g3_kernel_prog* __restrict__ prog, const 
   if (i < n) out[i] = prog_eval<T>(prog, xi, xi, true, true);
 }
 
-int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr) {
-  // pinned staging keeps the copy asynchronous; wait for earlier users of the slot first
-  G3_HIP(hipStreamSynchronize(ctx->stream));
-  memcpy(&ctx->h_prog[slot], prog, sizeof(g3_kernel_prog));
-  G3_HIP(hipMemcpyAsync(&ctx->d_prog[slot], &ctx->h_prog[slot], sizeof(g3_kernel_prog),
+int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int /*slot*/, const g3_kernel_prog** dptr) {
+  // A ring of pinned + device slots keeps the host ahead of the stream: the launch that read the
+  // previous slot is already enqueued when the next program arrives, so an event recorded now sits
+  // behind it, and a slot is only waited for when the ring has wrapped onto work still in flight.
+  if (ctx->prog_last >= 0) {
+    G3_HIP(hipEventRecord(ctx->prog_ev[ctx->prog_last], ctx->stream));
+    ctx->prog_busy[ctx->prog_last] = true;
+  }
+  const int s = ctx->prog_next;
+  ctx->prog_next = (s + 1) % G3_PROG_SLOTS;
+  if (ctx->prog_busy[s]) {
+    G3_HIP(hipEventSynchronize(ctx->prog_ev[s]));
+    ctx->prog_busy[s] = false;
+  }
+  memcpy(&ctx->h_prog[s], prog, sizeof(g3_kernel_prog));
+  G3_HIP(hipMemcpyAsync(&ctx->d_prog[s], &ctx->h_prog[s], sizeof(g3_kernel_prog),
                         hipMemcpyHostToDevice, ctx->stream));
-  *dptr = &ctx->d_prog[slot];
+  ctx->prog_last = s;
+  *dptr = &ctx->d_prog[s];
   return G3_OK;
 }
 

@@ -9,6 +9,7 @@
 
 #define G3_LB 128   // diagonal block factored + inverted by ONE fused kernel; matrices are padded to it
 
+#define G3_PROG_SLOTS 8
 struct g3_ctx {
   int device;
   hipStream_t stream;      // stream work is enqueued on
@@ -32,7 +33,10 @@ struct g3_ctx {
   // small device scratch
   int* d_info;             // potrf info flag (one per batch member, G3_MAX_BATCH of them)
   double* d_stats;         // 64 doubles of reduction outputs
-  g3_kernel_prog* d_prog;  // kernel program (device copy, 2 slots)
+  g3_kernel_prog* d_prog;  // kernel programs (device copies, a ring of G3_PROG_SLOTS)
+  hipEvent_t prog_ev[G3_PROG_SLOTS];   // recorded behind the launch that read the slot
+  bool prog_busy[G3_PROG_SLOTS];
+  int prog_next, prog_last;
   // pinned host mirrors
   int* h_info;
   double* h_stats;
