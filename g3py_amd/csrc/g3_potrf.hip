@@ -157,6 +157,19 @@ __device__ __noinline__ void diag16(T* D, T* Wd, int lane, int* info, int64_t ba
   }
 }
 
+#ifdef G3_DIAG_TIMING   // measurement build only: 100 MHz timestamps of the block steps (wave 7 and the diagonal waves)
+__device__ unsigned long long g3_dbg_ts[128];
+extern "C" int g3_dbg_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g3_dbg_ts), sizeof(g3_dbg_ts));
+}
+#define G3_TS(slot) do { if (lane == 0) g3_dbg_ts[slot] = wall_clock64(); } while (0)
+// shader-cycle counter (20 bits, no waitcnt side effects) inside the 16 x 16 tile routine, first tile only
+#define G3_CY(slot) do { if (base == 0 && lane == 0) g3_dbg_ts[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G3_TS(slot) do { } while (0)
+#define G3_CY(slot) do { } while (0)
+#endif
+
 // fp64 variant of diag16 that keeps the O(16^3) part on the matrix pipe.  The 16 x 16 tile is
 // processed in four 4-column block steps; per step every lane redundantly factors and inverts the
 // 4 x 4 diagonal block from LDS broadcast reads (the only sequential arithmetic: 4 pivots instead
@@ -178,6 +191,7 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c0 = 4 * q;
+    G3_CY(96 + 8 * q + 0);
     // 1. the 4 x 4 diagonal block: Cholesky factor l and inverse w4 (every lane, uniform data)
     double d[4][4], l[4][4], w4[4][4], rp[4];
 #pragma unroll
@@ -223,6 +237,7 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
         w4[a][b] = -acc * rp[a];
       }
     }
+    G3_CY(96 + 8 * q + 1);
     // 2. this lane's panel element P[row][kq] = sum_{m <= kq} T[row][c0 + m] * w4[kq][m]
     double pv;
     const int ra = row - c0;                      // row inside the diagonal block when 0 <= ra < 4
@@ -249,6 +264,7 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
     } else {
       pv = (ra >= 4 || (ra >= 0 && kq <= ra)) ? D[row * TS + c0 + kq] : 0.0;
     }
+    G3_CY(96 + 8 * q + 2);
     // 3. rank-4 trailing update of the whole tile, back to LDS for the next block step
     if (FACTOR) {
       tA = M::mfma(-pv, pv, tA);
@@ -257,6 +273,7 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
     // 4. the finished columns c0..c0+3 of L: kept until the sweep is over (the tile stores of the
     //    later block steps overwrite the whole tile)
     pvq[q] = pv;
+    G3_CY(96 + 8 * q + 3);
     // 5. inverse: rows of this block, then the rows below
     double ah = 0.0;
 #pragma unroll
@@ -267,6 +284,7 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
     const double pb = (ra >= 4) ? pv : 0.0;
     aW = M::mfma(-pb, R[q], aW);
     aW[q] = R[q];
+    G3_CY(96 + 8 * q + 4);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) D[row * TS + 4 * q + kq] = pvq[q];
@@ -303,7 +321,9 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int par = k & 1;
+    if (W == 7) G3_TS(8 * k + 0);
     if (W == k) {
+      G3_TS(64 + 2 * k);
 #pragma unroll
       for (int j = 0; j < k; ++j) TO::store(S.Wr[par][j], aW[j], lane);   // old W(k, j): consumers multiply by T_i
       TO::store(S.D[par], aA[k], lane);
@@ -318,8 +338,10 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
           if (row >= col) A[(int64_t)(16 * k + row) * ld + 16 * k + col] = S.D[par][row * TS + col];
         }
       }
+      G3_TS(64 + 2 * k + 1);
     }
     __syncthreads();                       // W_dd and the old row k of W are published
+    if (W == 7) G3_TS(8 * k + 1);
     if (W > k) {
       TO::store(S.P[W], aA[k], lane);
       if (FACTOR) {
@@ -334,7 +356,9 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
       aW[k] = -t;
       TO::store(S.Tt[W], t, lane);
     }
+    if (W == 7) G3_TS(8 * k + 2);
     __syncthreads();                       // the panel L(:, k) is published
+    if (W == 7) G3_TS(8 * k + 3);
     if (W > k) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -346,6 +370,7 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
       for (int j = 0; j < k; ++j) aW[j] = TO::mul_nn(S.Wd[par], S.Wr[par][j], acc_t{0, 0, 0, 0}, T(1), lane);
       aW[k] = TO::load(S.Wd[par], lane);
     }
+    if (W == 7) G3_TS(8 * k + 4);
   }
   // write back W (full 128 x 128 block row, upper part zero); L went out tile by tile
 #pragma unroll

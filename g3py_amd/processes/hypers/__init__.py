@@ -68,55 +68,78 @@ class Model:
 
 
 def modelcontext(model=None):
-    if model is not None:
-        return model
-    if not _MODEL_STACK:
-        raise TypeError('No model on context stack.')
-    return _MODEL_STACK[-1]
+    """the model a new hyper-parameter registers with: the argument, else the innermost `with Model():`"""
+    if model is None:
+        if not _MODEL_STACK:
+            raise TypeError('No model on context stack.')
+        model = _MODEL_STACK[-1]
+    return model
 
 
-def zeros(shape):
-    return np.zeros(shape)
+zeros, ones = np.zeros, np.ones
 
 
-def ones(shape):
-    return np.ones(shape)
+class Slot:
+    """One hyper-parameter a `Hypers` subclass owns: the attribute it lives in, whether it is positive
+    (stored as a log, `FlatExp`) or free (`Flat`), the suffix of its registered name, whether it has one
+    entry per selected column, and whether the owner's own name is part of the registered name
+    (`<parent><Owner><suffix>` vs `<parent><suffix>`).  The registered names are the parameter-dict
+    contract of the reference."""
+    __slots__ = ('attr', 'positive', 'suffix', 'per_column', 'owner_named')
+
+    def __init__(self, attr, positive, suffix, per_column=False, owner_named=True):
+        self.attr, self.positive, self.suffix = attr, positive, suffix
+        self.per_column, self.owner_named = per_column, owner_named
+
+
+def _columns(a):
+    return a.shape[1] if len(a.shape) > 1 else 1
 
 
 class Hypers:
-    def __init__(self, x=None, name=None):
-        self.name = self.__class__.__name__ if name is None else name
-        self.hypers = []
-        self.shape = None
-        self.dims = None
-        self.potential = None
+    """Base of every hyper-parametric function.  A subclass lists its parameters in `SLOTS`; construction
+    (`Cls(x, name, <slot values...>)`, by position or keyword), registration (`check_hypers`) and the
+    `hypers` list all follow from that table."""
+    SLOTS = ()
+
+    def __init__(self, x=None, name=None, *given, **named):
+        self.name = type(self).__name__ if name is None else name
+        self.hypers, self.potential = [], None
+        self.shape = self.dims = None
+        attrs = [s.attr for s in self.SLOTS]
+        if len(given) > len(attrs):
+            raise TypeError('%s takes at most %d hyper-parameters' % (type(self).__name__, len(attrs)))
+        supplied = dict(zip(attrs, given))
+        for k, v in named.items():
+            if k not in attrs or k in supplied:
+                raise TypeError('%s got an unexpected or repeated argument %r' % (type(self).__name__, k))
+            supplied[k] = v
+        for a in attrs:
+            setattr(self, a, supplied.get(a))
         if x is not None:
             self.check_dims(x)
 
     def __str__(self):
-        if len(self.hypers) == 0:
-            return str(self.__class__.__name__)
-        return str(self.__class__.__name__) + '[h=' + str(self.hypers) + ']'
+        return type(self).__name__ + ('[h=%s]' % (self.hypers,) if self.hypers else '')
+
     __repr__ = __str__
 
     def check_dims(self, x=None):
-        """column selection rules of hypers/__init__.py:55-83"""
+        """column selection (hypers/__init__.py:55-83): a list picks columns, a (domain, columns) tuple
+        picks columns of a domain of known width, an array means all of its columns; decided once"""
         if self.shape is not None:
             return
-        if x is not None:
-            if type(x) is list:
-                self.dims = np.array(x)
-                self.shape = self.dims.shape
-            elif type(x) is tuple:
-                domain, self.dims = x
-                self.shape = domain.shape[1] if len(domain.shape) > 1 else 1
-            else:
-                x = np.asarray(x)
-                self.shape = x.shape[1] if len(x.shape) > 1 else 1
-                self.dims = slice(0, self.shape)
-        else:
-            self.shape = None
+        if x is None:
             self.dims = slice(None)
+        elif type(x) is list:
+            cols = np.array(x)
+            self.dims, self.shape = cols, cols.shape
+        elif type(x) is tuple:
+            domain, cols = x
+            self.dims, self.shape = cols, _columns(domain)
+        else:
+            self.shape = _columns(np.asarray(x))
+            self.dims = slice(0, self.shape)
 
     def dims_index(self, d):
         """self.dims as an explicit index array for an input with d columns (None = all)"""
@@ -128,7 +151,13 @@ class Hypers:
         return idx
 
     def check_hypers(self, parent=''):
-        pass
+        """register the parameters that were not supplied and list all of them in `self.hypers`"""
+        for s in self.SLOTS:
+            if getattr(self, s.attr) is None:
+                label = parent + (self.name if s.owner_named else '') + s.suffix
+                make = Hypers.FlatExp if s.positive else Hypers.Flat
+                setattr(self, s.attr, make(label, shape=self.shape) if s.per_column else make(label))
+            self.hypers.append(getattr(self, s.attr))
 
     def default_hypers(self, x=None, y=None):
         return {}
@@ -146,9 +175,9 @@ class Hypers:
         is c * (-sum |h|) or c * (-sum h^2) over the NATURAL-space hypers selected by name"""
         if getattr(self, 'potential', None) is None:
             return None
-        hypers, reg, c = self.potential
-        sel = [k for k in self.hypers if isinstance(k, HyperVar) and k.name.find(hypers) > 0]
-        pot = (self.name + '_' + hypers + '_' + reg, reg, float(c), sel)
+        pattern, reg, c = self.potential
+        sel = [k for k in self.hypers if isinstance(k, HyperVar) and k.name.find(pattern) > 0]
+        pot = ('_'.join((self.name, pattern, reg)), reg, float(c), sel)
         modelcontext().potentials.append(pot)
         return pot
 
@@ -164,17 +193,11 @@ class Hypers:
 class Freedom(Hypers):
     """degrees of freedom of the Student-t process: bound + degree with degree > 0
     (hypers/__init__.py:144-160)"""
+    SLOTS = (Slot('degree', True, '_degree'),)
 
     def __init__(self, x=None, name=None, degree=None, bound=np.float32(2.0)):
-        super().__init__(x, name)
-        self.degree = degree
+        Hypers.__init__(self, x, name, degree)
         self.bound = bound
-
-    def check_hypers(self, parent=''):
-        super().check_hypers(parent=parent)
-        if self.degree is None:
-            self.degree = Hypers.FlatExp(parent + self.name + '_degree')
-        self.hypers += [self.degree]
 
     def default_hypers(self, x=None, y=None):
         return {self.degree: np.float64(y.shape[0])}

@@ -3,7 +3,7 @@
 (`__call__`, `inv`, `logdet_dinv`) around the device path."""
 import numpy as np
 
-from . import Hypers, value_of
+from . import Hypers, Slot, value_of
 
 
 class Mapping(Hypers):
@@ -23,9 +23,6 @@ class Mapping(Hypers):
 
 
 class Identity(Mapping):
-    def __init__(self, y=None, name=None):
-        super().__init__(y, name)
-
     def __call__(self, x, values=None):
         return x
 
@@ -37,17 +34,7 @@ class Identity(Mapping):
 
 
 class LinearMapping(Mapping):
-    def __init__(self, y=None, name=None, shift=None, scale=None):
-        super().__init__(y, name)
-        self.shift = shift
-        self.scale = scale
-
-    def check_hypers(self, parent=''):
-        if self.shift is None:
-            self.shift = Hypers.Flat(parent + self.name + '_shift')
-        if self.scale is None:
-            self.scale = Hypers.FlatExp(parent + self.name + '_scale')
-        self.hypers += [self.shift, self.scale]
+    SLOTS = (Slot('shift', False, '_shift'), Slot('scale', True, '_scale'))
 
     def default_hypers(self, x=None, y=None):
         return {self.shift: 0.0, self.scale: 1.0}
@@ -74,14 +61,7 @@ class LinearMapping(Mapping):
 
 
 class LogShifted(Mapping):
-    def __init__(self, y=None, name=None, shift=None):
-        super().__init__(y, name)
-        self.shift = shift
-
-    def check_hypers(self, parent=''):
-        if self.shift is None:
-            self.shift = Hypers.Flat(parent + self.name + '_shift')
-        self.hypers += [self.shift]
+    SLOTS = (Slot('shift', False, '_shift'),)
 
     def default_hypers(self, x=None, y=None):
         return {self.shift: y.min() - 1}
@@ -105,20 +85,7 @@ class LogShifted(Mapping):
 
 
 class BoxCoxLinear(Mapping):
-    def __init__(self, y=None, name=None, shift=None, scale=None, power=None):
-        super().__init__(y, name)
-        self.shift = shift
-        self.scale = scale
-        self.power = power
-
-    def check_hypers(self, parent=''):
-        if self.shift is None:
-            self.shift = Hypers.Flat(parent + self.name + '_shift')
-        if self.scale is None:
-            self.scale = Hypers.FlatExp(parent + self.name + '_scale')
-        if self.power is None:
-            self.power = Hypers.FlatExp(parent + self.name + '_power')
-        self.hypers += [self.shift, self.scale, self.power]
+    SLOTS = (Slot('shift', False, '_shift'), Slot('scale', True, '_scale'), Slot('power', True, '_power'))
 
     def default_hypers(self, x=None, y=None):
         return {self.shift: 1.0, self.scale: 1.0, self.power: 1.0}
@@ -168,17 +135,7 @@ class BoxCoxLinear(Mapping):
 
 
 class ArcsinhLinear(Mapping):
-    def __init__(self, y=None, name=None, shift=None, scale=None):
-        super().__init__(y, name)
-        self.shift = shift
-        self.scale = scale
-
-    def check_hypers(self, parent=''):
-        if self.shift is None:
-            self.shift = Hypers.Flat(parent + self.name + '_shift')
-        if self.scale is None:
-            self.scale = Hypers.FlatExp(parent + self.name + '_scale')
-        self.hypers += [self.shift, self.scale]
+    SLOTS = (Slot('shift', False, '_shift'), Slot('scale', True, '_scale'))
 
     def default_hypers(self, x=None, y=None):
         return {self.shift: np.mean(y), self.scale: np.std(y)}

@@ -3,7 +3,7 @@
 path; `eval` takes natural-space hyper values."""
 import numpy as np
 
-from . import Hypers, value_of
+from . import Hypers, Slot, value_of
 
 
 class Mean(Hypers):
@@ -32,15 +32,7 @@ class Zero(Mean):
 
 
 class Bias(Mean):
-    def __init__(self, x=None, name=None, bias=None):
-        super().__init__(x, name)
-        self.bias = bias
-
-    def check_hypers(self, parent=''):
-        super().check_hypers(parent=parent)
-        if self.bias is None:
-            self.bias = Hypers.Flat(parent + self.name + '_Bias')
-        self.hypers += [self.bias]
+    SLOTS = (Slot('bias', False, '_Bias'),)
 
     def default_hypers(self, x=None, y=None):
         return {self.bias: y.mean()}
@@ -53,18 +45,7 @@ class Bias(Mean):
 
 
 class Linear(Mean):
-    def __init__(self, x=None, name=None, constant=None, coeff=None):
-        super().__init__(x, name)
-        self.constant = constant
-        self.coeff = coeff
-
-    def check_hypers(self, parent=''):
-        super().check_hypers(parent=parent)
-        if self.constant is None:
-            self.constant = Hypers.Flat(parent + self.name + '_Constant')
-        if self.coeff is None:
-            self.coeff = Hypers.Flat(parent + self.name + '_Coeff', shape=self.shape)
-        self.hypers += [self.constant, self.coeff]
+    SLOTS = (Slot('constant', False, '_Constant'), Slot('coeff', False, '_Coeff', per_column=True))
 
     def default_hypers(self, x=None, y=None):
         return {self.constant: y.mean(), self.coeff: y.mean() / x.mean(axis=0)}

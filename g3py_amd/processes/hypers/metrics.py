@@ -4,7 +4,7 @@ in the HIP Gram kernel (g3py_amd/csrc/g3_gram.hip), which never forms the n1 x n
 """
 import numpy as np
 
-from . import Hypers
+from . import Hypers, Slot
 
 
 class Metric(Hypers):
@@ -25,22 +25,12 @@ class ARD(Metric):
     """automatic-relevance-determination metrics: one positive rate per selected column.  The default rate
     is `default_scale` / (mean spacing of consecutive rows) per column (metrics.py:93-95, 104-108)."""
     default_scale = 1.0
-
-    def __init__(self, x, name=None, rate=None):
-        super().__init__(x, name)
-        self.rate = rate
-
-    def check_hypers(self, parent=''):
-        super().check_hypers(parent=parent)
-        if self.rate is None:
-            self.rate = Hypers.FlatExp(parent + 'rate', shape=self.shape)
-        self.hypers.append(self.rate)
+    SLOTS = (Slot('rate', True, 'rate', per_column=True, owner_named=False),)
 
     def default_hypers(self, x=None, y=None):
-        try:
-            spacing = np.abs(np.diff(x, axis=0)).mean(axis=0)
-        except Exception:
+        if x is None or np.ndim(x) < 1 or len(x) < 2:
             return {}
+        spacing = np.abs(np.diff(np.asarray(x, dtype=float), axis=0)).mean(axis=0)
         return {self.rate: self.default_scale / spacing}
 
 
