@@ -54,6 +54,9 @@ __device__ __forceinline__ float fast_rcp(float p) {
 #ifndef G3_DIAG16_MFMA
 #define G3_DIAG16_MFMA 1   // fp64: 4 x 4-blocked diagonal tiles on the matrix pipe (0: column sweep)
 #endif
+#ifndef G3_DIAG16_SYM
+#define G3_DIAG16_SYM 1    // fp64 factor path: register-resident symmetric tile routine (0: the LDS round-trip variant)
+#endif
 constexpr int TS = 17;   // LDS tile row stride in elements (16 + 1: conflict-free fragment reads)
 template <typename T>
 struct DiagLds {
@@ -291,6 +294,116 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
   TileOps<double>::store(Wd, aW, lane);
 }
 
+// Register-resident successor of diag16m<true> (fp64, factor + inverse).  The tile is kept SYMMETRIC in one
+// accumulator, and that removes every LDS round trip from the block steps:
+//   * C layout: register q of lane (g, c) is T[4q + g][c]; by symmetry that is T[c][4q + g], i.e. exactly the
+//     element lane (row = c, k = g) must supply as the A operand -- or lane (col = c, k = g) as the B operand --
+//     of a 16x16x4 product with the column block T[:, 4q .. 4q+3].  The accumulator register IS the operand.
+//   * the 4 x 4 diagonal block of step q sits in register q of lanes (a, 4q + b): ten v_readlane pairs.
+//   * the panel P = T[:, c0..c0+3] w4^T comes out of ONE MFMA as P^T = w4 T[:, c0..]^T: rows 0..3 of the
+//     result are register 0 of lane (i, n) = P[n][i] -- the (row, k) operand layout the rank-4 update
+//     needs for both of its operands, again without moving anything.
+// Per block step: readlanes -> 4 x 4 factor + inverse (uniform, every lane) -> two 10-way selects keyed on
+// (row & 3, k), the same masks for every step -> MFMA (panel) -> MFMA (rank-4 update); the two inverse
+// MFMAs are off the chain.  ~1000 cycles per block step instead of ~2300.
+__device__ __noinline__ void diag16s(double* D, double* Wd, int lane, int* info, int64_t base) {
+  using M = MfmaT<double>;
+  using acc_t = typename M::acc_t;
+  const int row = lane & 15, kq = lane >> 4;
+  const int r3 = row & 3, rq = row >> 2;
+  acc_t tS, aW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                   // symmetric copy of the tile (its lower triangle is valid)
+    const int i = 4 * r + kq, c = row;
+    tS[r] = (i >= c) ? D[i * TS + c] : D[c * TS + i];
+    aW[r] = (i == c) ? 1.0 : 0.0;
+  }
+  double pvq[4];
+  acc_t R = acc_t{0, 0, 0, 0};                    // rows of the previous block step's inverse, not yet applied below
+  double pb = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = 4 * q;
+    G3_CY(96 + 8 * q + 0);
+    // 1. the 4 x 4 diagonal block (uniform): factor l, inverse w4
+    double d[4][4], l[4][4], w4[4][4], rp[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        d[a][b] = (b <= a) ? readlane_t(tS[q], a * 16 + c0 + b) : 0.0;
+        l[a][b] = 0.0;
+        w4[a][b] = 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double p = d[j][j];
+      if (!(p > 0.0)) {   // also catches NaN
+        if (lane == 0) atomicCAS(info, 0, (int)(base + c0 + j + 1));
+        p = 1.0;
+      }
+      rp[j] = fast_rsqrt(p);
+#pragma unroll
+      for (int a = j + 1; a < 4; ++a) l[a][j] = d[a][j] * rp[j];
+#pragma unroll
+      for (int a = j + 1; a < 4; ++a)
+#pragma unroll
+        for (int b = j + 1; b <= a; ++b) d[a][b] = fma(-l[a][j], l[b][j], d[a][b]);
+      double dg = p * rp[j];                       // the diagonal entry itself is off the pivot chain
+      l[j][j] = fma(0.5 * rp[j], fma(-dg, dg, p), dg);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      w4[b][b] = rp[b];
+#pragma unroll
+      for (int a = b + 1; a < 4; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int m = b; m < a; ++m) acc = fma(l[a][m], w4[m][b], acc);
+        w4[a][b] = -acc * rp[a];
+      }
+    }
+    G3_CY(96 + 8 * q + 1);
+    // 2. the previous block step's inverse rows go into the rows below them now: the matrix pipe is idle
+    //    during the factor, and issuing this product any earlier would stall the instruction stream on R
+    if (q > 0) {
+      aW = M::mfma(-pb, R[q - 1], aW);
+      aW[q - 1] = R[q - 1];
+    }
+    // 3. this lane's entry (r3, kq) of w4 and of l (lower triangles; zero above): by column first, then by row
+    double wr[4], lr[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      wr[a] = 0.0;
+      lr[a] = 0.0;
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        wr[a] = (kq == b) ? w4[a][b] : wr[a];
+        lr[a] = (kq == b) ? l[a][b] : lr[a];
+      }
+    }
+    const double wsel = (r3 < 2) ? (r3 == 0 ? wr[0] : wr[1]) : (r3 == 2 ? wr[2] : wr[3]);
+    const double lsel = (r3 < 2) ? (r3 == 0 ? lr[0] : lr[1]) : (r3 == 2 ? lr[2] : lr[3]);
+    // 4. panel: P^T = w4 T[:, c0..c0+3]^T; register 0 of the product is P[row][kq]
+    const acc_t pt = M::mfma(rq == 0 ? wsel : 0.0, tS[q], acc_t{0, 0, 0, 0});
+    const double pv = (rq < q) ? 0.0 : ((rq == q) ? lsel : pt[0]);
+    G3_CY(96 + 8 * q + 2);
+    // 5. rank-4 update of the (symmetric) tile; columns c0..c0+3 of L are final
+    tS = M::mfma(-pv, pv, tS);
+    pvq[q] = pv;
+    G3_CY(96 + 8 * q + 3);
+    // 6. inverse rows of this block (W[c0.., :] <- w4 W[c0.., :]); applied to the rows below in the next step
+    R = M::mfma(rq == q ? wsel : 0.0, aW[q], acc_t{0, 0, 0, 0});
+    pb = (rq > q) ? pv : 0.0;
+    __builtin_amdgcn_sched_barrier(0);            // keep the order above: the scheduler must not move the next
+    G3_CY(96 + 8 * q + 4);                        // step's readlanes behind a product that waits for R
+  }
+  aW[3] = R[3];                                   // (no rows below the last block)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) D[row * TS + 4 * q + kq] = pvq[q];
+  TileOps<double>::store(Wd, aW, lane);
+}
+
 // The program of wave W (block row W) of the diagonal-block kernel, with W a compile-time constant:
 // every "does this wave take part" test folds away, so the register allocator sees the true
 // lifetime of each accumulator tile instead of the union over all waves.
@@ -327,7 +440,9 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
 #pragma unroll
       for (int j = 0; j < k; ++j) TO::store(S.Wr[par][j], aW[j], lane);   // old W(k, j): consumers multiply by T_i
       TO::store(S.D[par], aA[k], lane);
-      if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
+      if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA && FACTOR && G3_DIAG16_SYM)
+        diag16s((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
+      else if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
         diag16m<FACTOR>((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
       else
         diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
