@@ -303,9 +303,8 @@ __device__ __noinline__ void diag16m(double* D, double* Wd, int lane, int* info,
 //   * the panel P = T[:, c0..c0+3] w4^T comes out of ONE MFMA as P^T = w4 T[:, c0..]^T: rows 0..3 of the
 //     result are register 0 of lane (i, n) = P[n][i] -- the (row, k) operand layout the rank-4 update
 //     needs for both of its operands, again without moving anything.
-// Per block step: readlanes -> 4 x 4 factor + inverse (uniform, every lane) -> two 10-way selects keyed on
-// (row & 3, k), the same masks for every step -> MFMA (panel) -> MFMA (rank-4 update); the two inverse
-// MFMAs are off the chain.  ~1000 cycles per block step instead of ~2300.
+// Per block step: readlanes -> 4 x 4 factor (uniform, every lane) with the lane's own column of the inverse
+// carried along -> MFMA (panel) -> MFMA (rank-4 update); the two inverse MFMAs are off the chain.
 __device__ __noinline__ void diag16s(double* D, double* Wd, int lane, int* info, int64_t base) {
   using M = MfmaT<double>;
   using acc_t = typename M::acc_t;
@@ -318,30 +317,33 @@ __device__ __noinline__ void diag16s(double* D, double* Wd, int lane, int* info,
     tS[r] = (i >= c) ? D[i * TS + c] : D[c * TS + i];
     aW[r] = (i == c) ? 1.0 : 0.0;
   }
+  double e[4];                                    // column kq of the 4 x 4 identity: this lane inverts against it
+#pragma unroll
+  for (int a = 0; a < 4; ++a) e[a] = (kq == a) ? 1.0 : 0.0;
   double pvq[4];
+  int first_bad = 0;                              // 1-based column of the first failing pivot (uniform)
   acc_t R = acc_t{0, 0, 0, 0};                    // rows of the previous block step's inverse, not yet applied below
   double pb = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c0 = 4 * q;
     G3_CY(96 + 8 * q + 0);
-    // 1. the 4 x 4 diagonal block (uniform): factor l, inverse w4
-    double d[4][4], l[4][4], w4[4][4], rp[4];
+    // 1. the 4 x 4 diagonal block (uniform values, every lane): factor l; column kq of its inverse in x
+    double d[4][4], l[4][4], rp[4], x[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         d[a][b] = (b <= a) ? readlane_t(tS[q], a * 16 + c0 + b) : 0.0;
         l[a][b] = 0.0;
-        w4[a][b] = 0.0;
       }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      double p = d[j][j];
-      if (!(p > 0.0)) {   // also catches NaN
-        if (lane == 0) atomicCAS(info, 0, (int)(base + c0 + j + 1));
-        p = 1.0;
-      }
+      const double p = d[j][j];
+      // a non-positive (or NaN) pivot is only RECORDED here (uniform compare, scalar bookkeeping) and reported
+      // after the tile: the pivot chain carries no select and no branch.  The NaNs it then produces stay in
+      // this matrix, whose factorisation is discarded (every later kernel of the sweep tests the flag).
+      if (!(p > 0.0) && first_bad == 0) first_bad = c0 + j + 1;
       rp[j] = fast_rsqrt(p);
 #pragma unroll
       for (int a = j + 1; a < 4; ++a) l[a][j] = d[a][j] * rp[j];
@@ -349,19 +351,13 @@ __device__ __noinline__ void diag16s(double* D, double* Wd, int lane, int* info,
       for (int a = j + 1; a < 4; ++a)
 #pragma unroll
         for (int b = j + 1; b <= a; ++b) d[a][b] = fma(-l[a][j], l[b][j], d[a][b]);
-      double dg = p * rp[j];                       // the diagonal entry itself is off the pivot chain
-      l[j][j] = fma(0.5 * rp[j], fma(-dg, dg, p), dg);
-    }
+      // forward substitution l x = e_kq, one row per pivot: x[j] = (e[j] - sum_{m<j} l[j][m] x[m]) / l[j][j].
+      // Lanes of group kq get column kq of the inverse (zeros above the diagonal come out by themselves), so
+      // the entry (r3, kq) a lane must supply as an MFMA operand is x[r3] -- no 10-way select.
+      double acc = e[j];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      w4[b][b] = rp[b];
-#pragma unroll
-      for (int a = b + 1; a < 4; ++a) {
-        double acc = 0.0;
-#pragma unroll
-        for (int m = b; m < a; ++m) acc = fma(l[a][m], w4[m][b], acc);
-        w4[a][b] = -acc * rp[a];
-      }
+      for (int m = 0; m < j; ++m) acc = fma(-l[j][m], x[m], acc);
+      x[j] = acc * rp[j];
     }
     G3_CY(96 + 8 * q + 1);
     // 2. the previous block step's inverse rows go into the rows below them now: the matrix pipe is idle
@@ -370,35 +366,26 @@ __device__ __noinline__ void diag16s(double* D, double* Wd, int lane, int* info,
       aW = M::mfma(-pb, R[q - 1], aW);
       aW[q - 1] = R[q - 1];
     }
-    // 3. this lane's entry (r3, kq) of w4 and of l (lower triangles; zero above): by column first, then by row
-    double wr[4], lr[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      wr[a] = 0.0;
-      lr[a] = 0.0;
-#pragma unroll
-      for (int b = 0; b <= a; ++b) {
-        wr[a] = (kq == b) ? w4[a][b] : wr[a];
-        lr[a] = (kq == b) ? l[a][b] : lr[a];
-      }
-    }
-    const double wsel = (r3 < 2) ? (r3 == 0 ? wr[0] : wr[1]) : (r3 == 2 ? wr[2] : wr[3]);
-    const double lsel = (r3 < 2) ? (r3 == 0 ? lr[0] : lr[1]) : (r3 == 2 ? lr[2] : lr[3]);
-    // 4. panel: P^T = w4 T[:, c0..c0+3]^T; register 0 of the product is P[row][kq]
-    const acc_t pt = M::mfma(rq == 0 ? wsel : 0.0, tS[q], acc_t{0, 0, 0, 0});
-    const double pv = (rq < q) ? 0.0 : ((rq == q) ? lsel : pt[0]);
+    // 3. w4 placed on the rows of this block: the A operand of both products below
+    const double wsel = (r3 < 2) ? (r3 == 0 ? x[0] : x[1]) : (r3 == 2 ? x[2] : x[3]);
+    const double ah = (rq == q) ? wsel : 0.0;
+    // 4. panel: rows c0..c0+3 of w4 T[c0..c0+3, :] are P^T, i.e. register q of the product is P[row][kq].  For
+    //    the rows of the diagonal block itself that is w4 (l l^T) = l^T transposed back: the factor l, to rounding
+    const acc_t pt = M::mfma(ah, tS[q], acc_t{0, 0, 0, 0});
+    const double pv = (rq < q || (rq == q && kq > r3)) ? 0.0 : pt[q];
     G3_CY(96 + 8 * q + 2);
     // 5. rank-4 update of the (symmetric) tile; columns c0..c0+3 of L are final
     tS = M::mfma(-pv, pv, tS);
     pvq[q] = pv;
     G3_CY(96 + 8 * q + 3);
     // 6. inverse rows of this block (W[c0.., :] <- w4 W[c0.., :]); applied to the rows below in the next step
-    R = M::mfma(rq == q ? wsel : 0.0, aW[q], acc_t{0, 0, 0, 0});
+    R = M::mfma(ah, aW[q], acc_t{0, 0, 0, 0});
     pb = (rq > q) ? pv : 0.0;
     __builtin_amdgcn_sched_barrier(0);            // keep the order above: the scheduler must not move the next
     G3_CY(96 + 8 * q + 4);                        // step's readlanes behind a product that waits for R
   }
   aW[3] = R[3];                                   // (no rows below the last block)
+  if (first_bad != 0 && lane == 0) atomicCAS(info, 0, (int)(base + first_bad));
 #pragma unroll
   for (int q = 0; q < 4; ++q) D[row * TS + 4 * q + kq] = pvq[q];
   TileOps<double>::store(Wd, aW, lane);
@@ -545,7 +532,9 @@ __device__ __forceinline__ void potrf256_wave(T* A, int64_t ld, T* Wg, int* info
   constexpr int TSZ = 16 * TS;
   T* tiles = reinterpret_cast<T*>(&S);                                  // aliases S between the diagonal phases
   static_assert(sizeof(DiagLds<T>) >= 36 * TSZ * sizeof(T), "tile array must fit in the diagonal kernel's LDS");
+  if (W == 7) G3_TS(88);
   diag128_wave<T, true, W>(A, ld, Wg, G3_LB, info, row_base, S, lane, tiles);
+  if (W == 7) G3_TS(89);
   T* A10 = A + (int64_t)G3_LB * ld;
   T* A11 = A10 + G3_LB;
   const int frow = lane & 15, kq = lane >> 4;
@@ -570,6 +559,7 @@ __device__ __forceinline__ void potrf256_wave(T* A, int64_t ld, T* Wg, int* info
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) A10[(int64_t)(16 * W + M::row(lane, r)) * ld + 16 * j + frow] = L[j][r];
+  if (W == 7) G3_TS(90);
   // ---- A11(W, j) -= sum_c L10(W, c) L10(j, c)^T, j <= W, in two halves of c through LDS.  (A11 is
   // loaded only after the first half of L10 has left the registers: the kernel must stay within the 144
   // VGPRs that let it run next to a bulk GEMM workgroup, like the 128-wide diagonal kernel.)
@@ -600,7 +590,9 @@ __device__ __forceinline__ void potrf256_wave(T* A, int64_t ld, T* Wg, int* info
 #pragma unroll
   for (int r = 0; r < 4; ++r) aA[W][r] = (M::row(lane, r) >= frow) ? aA[W][r] : T(0);   // strict upper part of the diagonal tile
   __syncthreads();                         // S is about to be used as DiagLds again
+  if (W == 7) G3_TS(91);
   diag128_core<T, true, W>(aA, A11, ld, Wg + G3_LB * G3_LB, G3_LB, info, row_base + G3_LB, S, lane, nullptr);
+  if (W == 7) G3_TS(92);
 }
 
 template <typename T>

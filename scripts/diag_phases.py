@@ -25,3 +25,18 @@ for q in range(4):
     d = [(c[8 * q + i + 1] - c[8 * q + i])  for i in range(4)]
     nxt = (c[8 * (q + 1)] - c[8 * q + 4])  if q < 3 else 0
     print(q, d, 'to next step', nxt, '| total', sum(d))
+
+# fused 256-wide kernel (G3_NB=256 makes potrf(256) one call of it): phases seen by wave 7
+if os.environ.get('G3_NB') == '256':
+    B2 = rng.standard_normal((256, 128)); K2 = B2 @ B2.T / 128 + np.eye(256)
+    acc2 = np.zeros((20, 128))
+    for it in range(20):
+        Kt = torch.from_numpy(K2).cuda()
+        dev.potrf(dev.wrap(Kt.data_ptr(), 256, 256, 256, np.float64), 256)
+        torch.cuda.synchronize()
+        ts = (C.c_ulonglong * 128)()
+        assert dev.lib.g3_dbg_read(ts) == 0
+        acc2[it] = np.array(ts[:], dtype=np.float64)
+    u = np.median(acc2[5:, 88:93] - acc2[5:, 88:89], axis=0) * 0.01
+    print('potrf256 (us): first diagonal block %.2f | L10 product %.2f | SYRK %.2f | second diagonal block %.2f | total %.2f'
+          % (u[1], u[2] - u[1], u[3] - u[2], u[4] - u[3], u[4]))
