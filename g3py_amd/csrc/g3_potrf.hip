@@ -424,9 +424,7 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
     if (W == 7) G3_TS(8 * k + 0);
     if (W == k) {
       G3_TS(64 + 2 * k);
-#pragma unroll
-      for (int j = 0; j < k; ++j) TO::store(S.Wr[par][j], aW[j], lane);   // old W(k, j): consumers multiply by T_i
-      TO::store(S.D[par], aA[k], lane);
+      if (k == 0) TO::store(S.D[par], aA[k], lane);      // (k > 0: handed over in the previous step, below)
       if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA && FACTOR && G3_DIAG16_SYM)
         diag16s((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
       else if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
@@ -441,8 +439,20 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
         }
       }
       G3_TS(64 + 2 * k + 1);
+    } else if (W < k) {
+      // A finished wave helps the diagonal wave, which is busy with the 16 x 16 tile: row k of W was parked in
+      // S.Wr[par] one update short (step k-1's); wave W brings tile (k, W) up to date.
+      //   T = L(k,k-1) W_dd(k-1);  W(k,j) -= T W_old(k-1,j) for j < k-1;  W(k,k-1) = -T
+      const acc_t t = TO::mul_nn(S.P[k], S.Wd[par ^ 1], acc_t{0, 0, 0, 0}, T(1), lane);
+      if (W == k - 1) {
+        TO::store(S.Wr[par][W], -t, lane);
+      } else {
+        TO::store(S.Tt[W], t, lane);        // (this wave's own buffer: free since its block row is finished)
+        const acc_t w = TO::mul_nn(S.Tt[W], S.Wr[par ^ 1][W], TO::load(S.Wr[par][W], lane), T(-1), lane);
+        TO::store(S.Wr[par][W], w, lane);
+      }
     }
-    __syncthreads();                       // W_dd and the old row k of W are published
+    __syncthreads();                       // B1: W_dd and the old row k of W are published
     if (W == 7) G3_TS(8 * k + 1);
     if (W > k) {
       TO::store(S.P[W], aA[k], lane);
@@ -453,19 +463,30 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
         for (int r = 0; r < 4; ++r)         // final: write it out, its registers are free from here on
           A[(int64_t)(16 * W + M::row(lane, r)) * ld + 16 * k + (lane & 15)] = lk[r];
       }
+      if (W == k + 1) {
+        // The NEXT diagonal wave: all its diagonal tile still needs is its own panel tile, so the tile is
+        // finished and handed over here, before B2, and the wave starts the next 16 x 16 factorisation the
+        // moment B2 falls.  Its row of W is parked in LDS (nothing stays live across the tile routine) one
+        // update short; the finished waves complete it meanwhile (above).
+        if (FACTOR) aA[k + 1] = TO::mul_nt(S.P[W], S.P[W], aA[k + 1], T(-1), lane);
+        TO::store(S.D[par ^ 1], aA[k + 1], lane);
+#pragma unroll
+        for (int j = 0; j < k; ++j) TO::store(S.Wr[par ^ 1][j], aW[j], lane);
+      }
+    }
+    if (W == 7) G3_TS(8 * k + 2);
+    __syncthreads();                       // B2: the panel L(:, k) is published
+    if (W == 7) G3_TS(8 * k + 3);
+    if (W > k + 1) {
       // T_W = L(W,k) W_dd: W(W,j) -= T_W W_old(k,j) for j < k, and W(W,k) = -T_W (W_old(k,k) = I)
       const acc_t t = TO::mul_nn(S.P[W], S.Wd[par], acc_t{0, 0, 0, 0}, T(1), lane);
       aW[k] = -t;
       TO::store(S.Tt[W], t, lane);
-    }
-    if (W == 7) G3_TS(8 * k + 2);
-    __syncthreads();                       // the panel L(:, k) is published
-    if (W == 7) G3_TS(8 * k + 3);
-    if (W > k) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (FACTOR && j > k && j <= W) aA[j] = TO::mul_nt(S.P[W], S.P[j], aA[j], T(-1), lane);
         if (j < k) aW[j] = TO::mul_nn(S.Tt[W], S.Wr[par][j], aW[j], T(-1), lane);
+        if (sizeof(T) == 8 && (j & 1)) __builtin_amdgcn_sched_barrier(0);   // operand loads at most two tiles ahead (144-VGPR budget)
       }
     } else if (W == k) {          // off the critical path: W(k, :) <- W_dd W_old(k, :)
 #pragma unroll
