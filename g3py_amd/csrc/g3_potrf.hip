@@ -563,11 +563,19 @@ __device__ __forceinline__ void potrf256_wave(T* A, int64_t ld, T* Wg, int* info
   acc_t L[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) L[j] = acc_t{0, 0, 0, 0};
+  T an[4];                                 // operand of the NEXT column tile: its global round trip hides under this one's products
+#pragma unroll
+  for (int q = 0; q < 4; ++q) an[q] = A10[(int64_t)(16 * W + frow) * ld + 4 * q + kq];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     T a[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = A10[(int64_t)(16 * W + frow) * ld + 16 * c + 4 * q + kq];
+    for (int q = 0; q < 4; ++q) a[q] = an[q];
+    if (c + 1 < 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) an[q] = A10[(int64_t)(16 * W + frow) * ld + 16 * (c + 1) + 4 * q + kq];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = c; j < 8; ++j) {
       const T* y = tiles + (j * (j + 1) / 2 + c) * TSZ + frow * TS + kq;
@@ -625,7 +633,10 @@ potrf256_kernel(T* A, int64_t ld, T* W, int* info, int64_t row_base, int64_t a_b
   W += (int64_t)blockIdx.y * w_batch;
   __shared__ DiagLds<T> S;
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // block row of this wave.  Waves v and v + 4 share a SIMD and block row W carries work in proportion to W + 1:
+  // the rows are dealt 0 1 2 3 | 7 6 5 4 so that every SIMD gets the same total (rows 3 + 7 on one SIMD: 12 of 36)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = wv < 4 ? wv : 11 - wv;
   switch (w) {
     case 0: potrf256_wave<T, 0>(A, ld, W, info, row_base, S, lane); break;
     case 1: potrf256_wave<T, 1>(A, ld, W, info, row_base, S, lane); break;
@@ -651,7 +662,10 @@ diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w
   const int lane = threadIdx.x & 63;
   // wave index as a scalar: the eight wave programs below are selected by a uniform branch, so a
   // wave only ever executes (and counts the barriers of) its own program
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // block row of this wave.  Waves v and v + 4 share a SIMD and block row W carries work in proportion to W + 1:
+  // the rows are dealt 0 1 2 3 | 7 6 5 4 so that every SIMD gets the same total (rows 3 + 7 on one SIMD: 12 of 36)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = wv < 4 ? wv : 11 - wv;
   switch (w) {
     case 0: diag128_wave<T, FACTOR, 0>(A, ld, W, ldw, info, row_base, S, lane); break;
     case 1: diag128_wave<T, FACTOR, 1>(A, ld, W, ldw, info, row_base, S, lane); break;
@@ -896,7 +910,7 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
     const char* e = getenv("G3_NB");
     // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
     // kernels that dominates small problems, wide panels give the bulk updates more K
-    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 8192 ? 256 : (n <= 20480 ? 512 : 1024)));
+    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
     // a batched sweep is bound by work per launch, not by the chain: wider panels again
     if (!e && ctx->batch > 1 && NB < 256) NB = 256;
   }
