@@ -319,7 +319,7 @@ int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int /*slot*/, const
   // previous slot is already enqueued when the next program arrives, so an event recorded now sits
   // behind it, and a slot is only waited for when the ring has wrapped onto work still in flight.
   if (ctx->prog_last >= 0) {
-    G3_HIP(hipEventRecord(ctx->prog_ev[ctx->prog_last], ctx->stream));
+    G3_HIP(hipEventRecord(ctx->prog_ev[ctx->prog_last], ctx->prog_stream));
     ctx->prog_busy[ctx->prog_last] = true;
   }
   const int s = ctx->prog_next;
@@ -332,6 +332,7 @@ int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int /*slot*/, const
   G3_HIP(hipMemcpyAsync(&ctx->d_prog[s], &ctx->h_prog[s], sizeof(g3_kernel_prog),
                         hipMemcpyHostToDevice, ctx->stream));
   ctx->prog_last = s;
+  ctx->prog_stream = ctx->stream;
   *dptr = &ctx->d_prog[s];
   return G3_OK;
 }

@@ -37,6 +37,7 @@ struct g3_ctx {
   hipEvent_t prog_ev[G3_PROG_SLOTS];   // recorded behind the launch that read the slot
   bool prog_busy[G3_PROG_SLOTS];
   int prog_next, prog_last;
+  hipStream_t prog_stream;   // stream the last slot was uploaded / consumed on
   // pinned host mirrors
   int* h_info;
   double* h_stats;

@@ -895,6 +895,19 @@ int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* in
   return g3i_potrf_tall(ctx, A, n, ld, dt, invd, 0);
 }
 
+static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n) {
+  int64_t NB = ctx->nb_lookahead;
+  if (NB <= 0) {
+    const char* e = getenv("G3_NB");
+    // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
+    // kernels that dominates small problems, wide panels give the bulk updates more K
+    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
+    // a batched sweep is bound by work per launch, not by the chain: wider panels again
+    if (!e && ctx->batch > 1 && NB < 256) NB = 256;
+  }
+  return g3_roundup(NB < LB ? LB : NB, LB);
+}
+
 // Cholesky of the leading n x n block of a tall (n + E) x n matrix whose last E rows are
 // right-hand sides B: on return those rows hold B L^-T (the forward substitution rides along
 // with the panel solves and trailing updates of the factorisation -- no separate trsm pass).
@@ -905,16 +918,7 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
   // factorisations are bound by the bulk updates instead and measured 0.4 % slower with it.
   ctx->fuse256 = n <= 20480;
 
-  int64_t NB = ctx->nb_lookahead;
-  if (NB <= 0) {
-    const char* e = getenv("G3_NB");
-    // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
-    // kernels that dominates small problems, wide panels give the bulk updates more K
-    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
-    // a batched sweep is bound by work per launch, not by the chain: wider panels again
-    if (!e && ctx->batch > 1 && NB < 256) NB = 256;
-  }
-  NB = g3_roundup(NB < LB ? LB : NB, LB);
+  int64_t NB = g3i_panel_width(ctx, n);
   if (n >= 3 * NB) {
     if (dt == G3_F64) return potrf_lookahead<double>(ctx, (double*)A, n, ld, (double*)invd, NB, dt, E);
     return potrf_lookahead<float>(ctx, (float*)A, n, ld, (float*)invd, NB, dt, E);
