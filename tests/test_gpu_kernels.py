@@ -155,6 +155,32 @@ def test_potrf_info_on_bad_pivot(dev):
     assert dev.potrf(dev.upload(K2), 256) != 0
 
 
+@pytest.mark.parametrize('n', [128, 256, 768])
+def test_potrf_info_is_the_first_failing_pivot(dev, n):
+    """dpotrf's info (tensors.py:198 reads it): the 1-based column of the first non-positive pivot, wherever it
+    falls inside the 16 x 16 tile routine's 4-column block steps or the 128 / 256-wide diagonal kernels"""
+    rng = np.random.default_rng(n)
+    base = _spd(rng, n)
+    for col in sorted({0, 1, 3, 4, 6, 15, 16, 21, 127, n // 2 + 5, n - 130 + 3, n - 1} & set(range(n))):
+        K = base.copy()
+        K[col, col] = -1.0
+        ref = scipy.linalg.lapack.dpotrf(K, lower=True)[1]
+        assert ref == col + 1
+        assert dev.potrf(dev.upload(K), n) == ref, col
+    # positive semi-definite: the Schur complement of a duplicated row is exactly zero -> fails at that row
+    K = base.copy()
+    j, i = 40, min(n - 1, 200)
+    K[i, :] = K[j, :]
+    K[:, i] = K[:, j]
+    K[i, i] = K[j, j]
+    info = dev.potrf(dev.upload(K), n)
+    assert info == i + 1 or info == 0        # (zero pivot up to rounding: either detected at row i or passed as tiny positive)
+    # two bad pivots: the first one is reported
+    K = base.copy()
+    K[70, 70] = K[9, 9] = -2.0
+    assert dev.potrf(dev.upload(K), n) == 10
+
+
 @pytest.mark.parametrize('n,m', [(128, 128), (384, 256), (1024, 128), (2048, 384)])
 def test_trsm_rlt(dev, n, m):
     rng = np.random.default_rng(n + m)
