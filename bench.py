@@ -46,6 +46,52 @@ def _traffic():
         return None
 
 
+def shutil_which(name):
+    import shutil
+    return shutil.which(name) is not None
+
+
+def _measure_traffic(argv_workload):
+    """`--measure-traffic`: HBM bytes per bulk-GEMM launch measured NOW, by two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (one counter per pass, no other trace domain -- the guide's rule),
+    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, both in KB).  Returns (bytes, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    per = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix='g3pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
+        try:
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '--',
+                   sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '0', '--cpu-n', '0',
+                   '--skip-events'] + argv_workload
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, 'rocprofv3 --pmc %s child timed out' % counter
+            fs = glob.glob(os.path.join(tmp, '**', '*_counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None, 'rocprofv3 --pmc %s child failed (rc %s)' % (counter, r.returncode)
+            n, kb = 0, 0.0
+            for row in csv.DictReader(open(fs[0])):
+                name = row['Kernel_Name']
+                if 'gemm_nt_kernel' in name and ', 128, 128, 64, 64' in name and \
+                        int(row['Grid_Size']) // int(row['Workgroup_Size']) >= 1024:
+                    n += 1
+                    kb += float(row['Counter_Value'])
+            if n == 0:
+                return None, 'no bulk GEMM launch in the %s pass' % counter
+            per[counter] = kb * 1024.0 / n
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * per['FETCH_SIZE'] + per['WRITE_SIZE'], \
+        'measured in this run: two child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- bench.py --steps 1 ' \
+        '--warmup 0 --skip-events` (FETCH_SIZE x2, gfx950 correction; fetch %.3f GB + write %.3f GB per launch)' \
+        % (2.0 * per['FETCH_SIZE'] / 1e9, per['WRITE_SIZE'] / 1e9)
+
+
 def _golden_logp(N, d, M, seed, kernel):
     """logp of the CPU oracle at a full benchmark configuration, or None when it was never generated"""
     try:
@@ -135,6 +181,11 @@ def main():
     ap.add_argument('--f32', action='store_true', help='float32 arithmetic (config 5 runs in fp32)')
     ap.add_argument('--cpu-n', type=int, default=16384, help='N of the bounded CPU-baseline sample (0 = skip)')
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
+    ap.add_argument('--measure-traffic', dest='measure_traffic', action='store_true', default=None,
+                    help='measure roofline.traffic now: two rocprofv3 --pmc child passes of this workload (~10 s).  Default: on for '
+                         'the one-GPU fp64 headline workload, off otherwise')
+    ap.add_argument('--no-measure-traffic', dest='measure_traffic', action='store_false',
+                    help='quote profiles/rNN_traffic.json (committed PMC passes of the same command) instead')
     ap.add_argument('--grad', action='store_true', help='also time dlogp (K^-1 + kernel-parameter sums, SURVEY.md 8f rank 1) '
                                                         'after the timed region; reported under "dlogp", never part of value')
     ap.add_argument('--draws', type=int, default=-1, help='posterior draws S through the warped-GP path (BASELINE config 5: posterior '
@@ -392,6 +443,19 @@ def main():
         if ref is not None:
             out['logp_ref'] = ref
             out['logp_rel_err'] = abs(out['logp'] - ref) / abs(ref)
+        if args.measure_traffic is None:      # default: the headline line carries a traffic figure measured in the run itself
+            profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+            args.measure_traffic = (world == 1 and not args.f32 and N == 32768 and not args.no_prof and not profiled
+                                    and shutil_which('rocprofv3'))
+        if args.measure_traffic and world == 1 and 'roofline' in out:
+            wl = ['--points', str(N), '--dims', str(d), '--queries', str(M), '--kernel', args.kernel] + (['--f32'] if args.f32 else []) \
+                + (['--draws', str(args.draws)] if args.draws >= 0 else [])
+            tb, note = _measure_traffic(wl)
+            if tb is not None:
+                out['roofline']['traffic'] = tb
+                out['roofline']['traffic_source'] = note
+            else:                             # keep the committed figure, say why
+                out['roofline']['traffic_source'] += '; live measurement unavailable: ' + note
         print(json.dumps(out))
         if ref is not None and not out['logp_rel_err'] <= 1e-8:
             raise SystemExit('bench.py: logp %.12f differs from the oracle pin %.12f by more than 1e-8 relative'
