@@ -414,10 +414,15 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
   using acc_t = typename TO::acc_t;
   using M = MfmaT<T>;
   acc_t aW[8];
-  // Per block step: [wave k: 16 x 16 factor + inverse] B1 [waves i > k: panel tile and
-  // T_i = L(i,k) W_dd] B2 [trailing updates; wave k rebuilds its own W row meanwhile].  Buffers
-  // written by wave k+1 for the NEXT step have the other parity, so no third barrier is needed and
-  // wave k+1 (the lightest in the trailing phase) starts its diagonal tile while the others update.
+  // Per block step k (two barriers):
+  //   before B1   wave k: 16 x 16 factor + inverse of its diagonal tile (the only sequential part);
+  //               waves < k (finished): bring row k of W, parked in LDS, up to date with step k-1
+  //   B1 .. B2    waves > k: panel tile L(i,k); wave k+1 also finishes ITS diagonal tile from its own
+  //               panel tile, hands it over in S.D and parks its row of W
+  //   after B2    wave k+1 goes straight into the next tile routine; waves > k+1: T_i = L(i,k) W_dd and the
+  //               trailing updates of A and W; wave k: W(k,:) <- W_dd W_old(k,:)
+  // Everything written for step k+1 while step k's readers may still run lives in the other-parity buffers
+  // (S.D, S.Wd, S.Wr), and each S.P / S.Tt tile has a single writer, so two barriers per step are enough.
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int par = k & 1;
