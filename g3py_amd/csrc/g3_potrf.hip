@@ -43,14 +43,16 @@ __device__ __forceinline__ float fast_rcp(float p) {
 // =======================================================================================
 // MFMA-blocked diagonal kernel: one workgroup (8 waves) factors a 128 x 128 block and forms its
 // inverse with BOTH matrices resident in MFMA accumulators.  The block is an 8 x 8 grid of
-// 16 x 16 tiles; wave w owns block row w (tiles (w, 0..w)) of A and of W.  Per block step k:
-//   wave k      : diagonal tile -> LDS -> one row per lane; 16 x 16 Cholesky and triangular
-//                 inverse with scalar broadcasts (v_readlane) -- the only sequential part;
-//                 W(k, :) <- W_dd W(k, :) by MFMA; publishes W_dd and its W row through LDS
+// 16 x 16 tiles; a wave owns one block row (tiles (w, 0..w)) of A and of W.  Per block step k:
+//   wave k      : 16 x 16 Cholesky + triangular inverse of its diagonal tile (diag16s for fp64: the tile
+//                 stays in one accumulator, 4-column block steps on the matrix pipe; diag16 for fp32: a
+//                 column sweep with v_readlane broadcasts) -- the only sequential part;
+//                 afterwards W(k, :) <- W_dd W(k, :) by MFMA
 //   waves i > k : L(i,k) = A(i,k) W_dd^T (MFMA), published through LDS;
-//                 A(i,j) -= L(i,k) L(j,k)^T for k < j <= i and W(i,j) -= L(i,k) W(k,j) for j <= k
-// Three barriers per block step (24 per block) instead of one per column (128), and all O(n^3)
-// work on the matrix pipe.  FACTOR = false: A already holds L, only W is formed.
+//                 A(i,j) -= L(i,k) L(j,k)^T for k < j <= i and W(i,j) -= L(i,k) W_dd W(k,j) for j <= k
+// Two barriers per block step (16 per block) instead of one per column (128), all O(n^3) work on the matrix
+// pipe, and the next diagonal wave is never kept waiting by anything but its own panel tile (see
+// diag128_core).  FACTOR = false: A already holds L, only W is formed.
 #ifndef G3_DIAG16_MFMA
 #define G3_DIAG16_MFMA 1   // fp64: 4 x 4-blocked diagonal tiles on the matrix pipe (0: column sweep)
 #endif
