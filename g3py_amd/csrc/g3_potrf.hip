@@ -17,11 +17,13 @@
 #include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------
+// v_rsq_f64 is good to 5e-8 (24 bits); ONE third-order step  y (1 + e/2 + 3 e^2/8), e = 1 - p y^2, takes that to
+// full precision (max relative error 1.4e-16 over 2^20 arguments, scripts/rsq_probe.hip -- two Newton steps: 2.4e-16)
+// in four dependent operations instead of six: this sits on the pivot chain of every diagonal tile.
 __device__ __forceinline__ double fast_rsqrt(double p) {
-  double y = __builtin_amdgcn_rsq(p);
-  y = y * fma(-0.5 * p * y, y, 1.5);
-  y = y * fma(-0.5 * p * y, y, 1.5);
-  return y;
+  const double y = __builtin_amdgcn_rsq(p);
+  const double e = fma(-(p * y), y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
 }
 __device__ __forceinline__ float fast_rsqrt(float p) {
   float y = __builtin_amdgcn_rsqf(p);
