@@ -1,0 +1,75 @@
+"""Seeded random shapes against the CPU oracle: ragged N and M around every blocking boundary of the HIP path
+(128-wide diagonal blocks, 256-wide fused blocks, 32-row solve stripes, the panel widths of the sweep and its
+tail), several kernel expressions, with and without the fused predict rows.  What the fixed-size tests cannot
+see: an off-by-one in a padding rule or a raster table for a size nobody wrote a case for."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import g3py_amd as g3
+    return g3.Device.default()
+
+
+def _specs(rng, d):
+    rate = np.exp(rng.uniform(-0.5, 0.5, d))
+    freq = rng.uniform(0.05, 0.3, d)
+    pool = [
+        ('SE', 1.3, rate, None),
+        ('MAT32', 0.8, rate, None),
+        ('MAT52', 1.1, rate, None),
+        ('OU', 0.9, rate, None),
+        ('sum', ('SE', 0.7, rate, None), ('COS', 0.4, freq, None)),
+        ('prod', ('MAT52', 1.2, rate, None), ('RQ', 1.0, rate, 1.7, None)),
+        ('sum', ('MAT32', 0.6, rate, None), ('SM', 0.3, freq, rate * 0.2, None)),
+        ('sum', ('SE', 1.0, rate[:1], [0]), ('WN', 0.05, None)) if d > 1 else ('SE', 1.0, rate, None),
+    ]
+    return pool[int(rng.integers(len(pool)))]
+
+
+def _oracle(orc, spec_f, noise, X, y, Xs):
+    K = orc.tt_to_num(orc.kernel_cov(orc.with_noise(spec_f, noise), X))
+    L = scipy.linalg.cholesky(K, lower=True)
+    a = scipy.linalg.solve_triangular(L, y, lower=True)
+    lp = -0.5 * len(y) * np.log(2 * np.pi) - 0.5 * a.dot(a) - np.log(np.diag(L)).sum()
+    Ks = orc.tt_to_num(orc.kernel_cov(spec_f, Xs, X))
+    V = scipy.linalg.solve_triangular(L, Ks.T, lower=True)
+    prior = np.diag(orc.kernel_cov(spec_f, Xs[:1], Xs[:1]))[0]
+    return lp, V.T.dot(a), np.maximum(prior - (V ** 2).sum(0), 0.0), prior
+
+
+SIZES = [1, 2, 31, 127, 128, 129, 255, 256, 257, 383, 385, 511, 640, 767, 769, 1000, 1023, 1025, 1279, 1537,
+         2047, 2049, 2305, 3071, 3200, 4095, 4097, 4500,
+         5000, 6145, 7169, 9001]      # the wider panel rules of the sweep (256 / 512 columns) and their tails; d <= 2 (oracle memory)
+
+
+@pytest.mark.parametrize('case', range(len(SIZES)))
+def test_random_shape_matches_oracle(dev, case):
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    rng = np.random.default_rng(9000 + case)
+    N = SIZES[case]
+    d = int(rng.integers(1, 6)) if N < 4600 else int(rng.integers(1, 3))
+    M = int(rng.choice([1, 5, 127, 128, 129, 300]))
+    noise = float(rng.choice([0.05, 0.2, 1.0]))
+    X = rng.uniform(0, max(N, 2) ** (1.0 / d), (N, d))
+    Xs = rng.uniform(0, max(N, 2) ** (1.0 / d), (M, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N)
+    spec_f = _specs(rng, d) if N < 4600 else [('SE', 1.3, np.ones(d), None), ('MAT52', 1.1, np.ones(d) * 0.8, None)][case % 2]
+    lp_ref, mean_ref, var_ref, prior = _oracle(orc, spec_f, noise, X, y, Xs)
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, 128)
+    K = dev.alloc(Np + 128 + Mp, Np, np.float64)
+    W, a = dev.alloc_inverses(Np, np.float64), dev.alloc(1, Np, np.float64)
+    mu, ss = dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
+    st = dev.gp_factor_predict(compile_spec(orc.with_noise(spec_f, noise), d), compile_spec(spec_f, d), dev.upload(X), N, d,
+                               dev.upload(y), dev.upload(Xs), M, K, W, a, mu, ss)
+    lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet']
+    assert st['info'] == 0 and st['tries'] == 0
+    assert abs(lp - lp_ref) <= 1e-8 * max(1.0, abs(lp_ref)), (N, d, M, spec_f[0])
+    np.testing.assert_allclose(dev.download(mu, 1, M)[0], mean_ref, atol=1e-8, rtol=1e-8)
+    np.testing.assert_allclose(np.maximum(prior - dev.download(ss, 1, M)[0], 0), var_ref, atol=1e-8, rtol=1e-8)
