@@ -93,13 +93,14 @@ __device__ __forceinline__ void gemm_tile(T* C, int64_t ldc, const T* gA, int64_
   // applied to the per-lane SOURCE address: physical chunk c of row r receives logical chunk
   // c ^ ((r >> 1) & 7), which is what the fragment reads below expect.
   constexpr int NW = NT / 64;
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "rows per wave-instruction");
+  static_assert(((BM / 8) % NW == 0 || BM / 8 < NW) && (BN / 8) % NW == 0, "rows per wave-instruction");
   const int sr = lane >> 3, sc = lane & 7;
   auto stage = [&](int buf, int k0) {
     char* a = sA + buf * BM * ROWB;
     char* b = sB + buf * BN * ROWB;
 #pragma unroll
-    for (int i = 0; i < BM / 8 / NW; ++i) {
+    for (int i = 0; i < (BM / 8 + NW - 1) / NW; ++i) {
+      if (BM / 8 < NW && wave >= BM / 8) break;      // a tile with fewer 8-row groups than waves (16-row stripes)
       const int rb = (i * NW + wave) * 8, row = rb + sr;
       const T* src = gA + (int64_t)row * lda + k0 + ((sc ^ ((row >> 1) & 7)) * EPC);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -139,12 +140,13 @@ __device__ __forceinline__ void gemm_tile(T* C, int64_t ldc, const T* gA, int64_
   // buffers hide a memory round trip completely.  (See STAGES above for why the small tiles stay
   // at two buffers as well.)
   const int KT = K / BK;
-  constexpr int LPS = BM / 8 / NW + BN / 8 / NW;           // DMA instructions per wave and stage
+  constexpr int LPS = (BM / 8 + NW - 1) / NW + BN / 8 / NW;   // DMA instructions per wave and stage (upper bound)
+  static_assert(NSTAGE == 2 || BM / 8 >= NW, "the vmcnt bookkeeping of deeper pipelines needs the same count on every wave");
   static_assert((NSTAGE - 2) * LPS <= 63, "vmcnt range");
   // epilogue geometry (see below).  (Requesting the first chunk of C before the last K tile would
   // hide its latency too, but costs 25 VGPRs: the kernel must stay <= 224 so that the
   // critical-path diagonal kernel still fits beside one of these workgroups.)
-  constexpr int RC = 32;                                   // rows per chunk
+  constexpr int RC = BM < 32 ? BM : 32;                    // rows per chunk
   constexpr int PITCH = BN * (int)sizeof(T) + 128;         // +128 B: rows r, r+1 land in different bank halves
   constexpr int VPR = BN * (int)sizeof(T) / 16;            // 16-byte vectors per row
   constexpr int RPP = NT / VPR;                            // rows per pass of the whole workgroup
@@ -332,7 +334,7 @@ struct TrsmOps {
   } op[G3_TRSM_MAXOPS];
 };
 
-template <typename T>
+template <typename T, int BM>
 __global__ void __launch_bounds__(256, 2)
 trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const int* __restrict__ info,
                    int64_t bsX, int64_t bsL, int64_t bsW, const TrsmOps ops) {
@@ -343,11 +345,11 @@ trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const
   const int failed = (info != nullptr) ? *info : 0;
   if (failed != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int m0 = blockIdx.x * 32;
+  const int m0 = blockIdx.x * BM;
   for (int i = 0; i < ops.nops; ++i) {
     const auto o = ops.op[i];
     const T* gB = o.leaf ? W + (int64_t)o.brow * G3_LB * G3_LB : L + (int64_t)o.brow * ldl + o.bcol;
-    gemm_tile<T, 32, 128, 32, 32, STAGES>(X, ldx, X + (int64_t)m0 * ldx + o.acol, ldx, gB, o.leaf ? (int64_t)G3_LB : ldl, o.k,
+    gemm_tile<T, BM, 128, BM, 32, STAGES>(X, ldx, X + (int64_t)m0 * ldx + o.acol, ldx, gB, o.leaf ? (int64_t)G3_LB : ldl, o.k,
                                           o.leaf ? T(1) : T(-1), o.leaf ? T(0) : T(1), m0, o.col, false, G3_DENSE_OFF, 0, smem);
     __syncthreads();          // this tile's stores are visible to the workgroup's next step
   }
@@ -601,10 +603,10 @@ static void trsm_ops_rec(TrsmOps* ops, int64_t c0, int64_t n) {
   trsm_ops_rec(ops, c0 + n1, n2);
 }
 
-template <typename T>
+template <typename T, int BM>
 static int trsm_stripe_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* X, int64_t m, int64_t ldx, const T* W) {
-  constexpr int LDS = STAGES * (32 + 128) * ROWB;
-  auto kern = trsm_stripe_kernel<T>;
+  constexpr int LDS = STAGES * (BM + 128) * ROWB;
+  auto kern = trsm_stripe_kernel<T, BM>;
   static bool attr_set[G3_MAX_DEVICES] = {};
   const int dev_slot = ctx->device & (G3_MAX_DEVICES - 1);
   if (!attr_set[dev_slot]) {
@@ -615,7 +617,7 @@ static int trsm_stripe_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* X, 
   ops.nops = 0;
   trsm_ops_rec(&ops, 0, n);
   const int pr = g3i_prof_begin(ctx, G3_TAG_GEMM_SMALL, (double)m * (double)n * (double)n);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(m / 32), (unsigned)g3_nbatch(ctx)), dim3(256), LDS, ctx->stream, X, ldx, L, ldl, W,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(m / BM), (unsigned)g3_nbatch(ctx)), dim3(256), LDS, ctx->stream, X, ldx, L, ldl, W,
                      ctx->d_info, g3_bstride_of(ctx, X), g3_bstride_of(ctx, L), g3_bstride_of(ctx, W), ops);
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
@@ -629,10 +631,16 @@ int g3i_trsm_stripe(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* X,
   if (n > 1024 || n % G3_LB || m % 32 || m <= 0) return 1;
   const int64_t al = 16 / (int64_t)g3_esize(dt);
   if (ldx % al || ldl % al || (((uintptr_t)X | (uintptr_t)L | (uintptr_t)W) & 15)) return 1;
-  int rc;
-  if (dt == G3_F64) rc = trsm_stripe_t<double>(ctx, (const double*)L, n, ldl, (double*)X, m, ldx, (const double*)W);
-  else rc = trsm_stripe_t<float>(ctx, (const float*)L, n, ldl, (float*)X, m, ldx, (const float*)W);
-  return rc;
+  // A stripe's workgroup is bound by the share of its CU's matrix pipes it gets beside the bulk workgroups: a
+  // short panel (few stripes) is solved in 16-row stripes, twice the workgroups with half the products each.
+  static int64_t thin_max = -1;
+  if (thin_max < 0) { const char* e = getenv("G3_TRSM_THIN_MAX"); thin_max = e ? atoll(e) : 2048; }
+  const bool thin = m * (int64_t)g3_nbatch(ctx) <= thin_max;
+  if (dt == G3_F64)
+    return thin ? trsm_stripe_t<double, 16>(ctx, (const double*)L, n, ldl, (double*)X, m, ldx, (const double*)W)
+                : trsm_stripe_t<double, 32>(ctx, (const double*)L, n, ldl, (double*)X, m, ldx, (const double*)W);
+  return thin ? trsm_stripe_t<float, 16>(ctx, (const float*)L, n, ldl, (float*)X, m, ldx, (const float*)W)
+              : trsm_stripe_t<float, 32>(ctx, (const float*)L, n, ldl, (float*)X, m, ldx, (const float*)W);
 }
 
 // staircase: row segment s (seg_rows[s] rows, stacked) gets its first seg_cols[s] columns
