@@ -242,8 +242,10 @@ class DistributedGP:
         self.dbuf = [o.zeros(1, nb * nb + nb * pad), o.zeros(1, nb * nb + nb * pad)]
         self._perms = {}
         cmax = max(self._perm(0)[0], 1) if self.nblk > 1 else 1
-        self.send = o.zeros(max(cmax, 1) * nb, nb)
-        self.gath = o.zeros(world * max(cmax, 1) * nb, nb)
+        # panel rows on their way out / gathered from every rank (double buffers: the gather of panel k+1 runs
+        # under the update with panel k)
+        self.send = [o.zeros(max(cmax, 1) * nb, nb), o.zeros(max(cmax, 1) * nb, nb)]
+        self.gath = [o.zeros(world * max(cmax, 1) * nb, nb), o.zeros(world * max(cmax, 1) * nb, nb)]
         self.last = {}
 
     def owner(self, I):
@@ -346,58 +348,86 @@ class DistributedGP:
         o.potrf_block(L, self.nb, W)
         D.copy_(L)                                       # kept for the log-determinant
 
+    def _solve_and_gather(self, k):
+        """panel k: solve my rows below block k (right-hand-side rows included) against L_kk, then start the
+        all-gather of those rows into gath[k % 2]; returns the collective's work handle (None on the last block)"""
+        o, nb, P, A = self.ops, self.nb, self.world, self.A
+        L, W = self._LW(k)
+        c0, c1 = k * nb, (k + 1) * nb
+        r_lo = sum(1 for I in self.my_blocks if I <= k) * nb
+        o.trsm(L, nb, W, A[r_lo:, c0:c1], A.shape[0] - r_lo)
+        if self.nblk - 1 - k <= 0:
+            return None
+        cnt, _ = self._perm(k)
+        send, gath = self.send[k % 2], self.gath[k % 2]
+        mine = self.rows_mat - r_lo
+        if mine > 0:
+            send[:mine].copy_(A[r_lo:self.rows_mat, c0:c1])
+        return self._allgather(gath[:P * cnt * nb], send[:cnt * nb])
+
+    def _lookahead(self, j, panels):
+        """diagonal block j: its owner applies the updates of `panels` from its own panel rows, factors the block
+        and broadcasts factor + block inverses -- all on the look-ahead stream; the others post the receive"""
+        o, nb = self.ops, self.nb
+        if self.owner(j) != self.rank:
+            return self._bcast(self.dbuf[j % 2], self.owner(j), async_op=True)
+        with o.lookahead():
+            lo = self.loff[j]
+            for p in panels:
+                Pn = self.A[lo:lo + nb, p * nb:(p + 1) * nb]
+                o.gemm_sub(self.A[lo:lo + nb, j * nb:(j + 1) * nb], Pn, Pn, nb, nb, nb, lower_only=True)
+            self._factor_block(j)
+            return self._bcast(self.dbuf[j % 2], self.owner(j), async_op=True)
+
     def factor(self, spec, spec_cross, X, Xs, delta, jitter=0.0):
-        """returns the global potrf info (0 = success)"""
+        """returns the global potrf info (0 = success).
+
+        Software-pipelined over the row-block steps: while the trailing update with panel k runs, panel k+1 is
+        already solved and on its way through the all-gather, and diagonal block k+2 is factored and broadcast
+        on the look-ahead stream.  Step k:
+          a. update block column k+1 of everything I own below block k+1 with the gathered panel k;
+          b. solve panel k+1 (needs the broadcast factor L_{k+1,k+1}) and start its all-gather;
+          c. look-ahead: the owner of block k+2 applies panels k and k+1 to it from its own rows, factors it and
+             broadcasts it;
+          d. the rest of the update with panel k (block columns >= k+2 of the blocks >= k+3 and of the
+             right-hand-side rows) -- the bulk of the work, under which b's all-gather and c run.
+        """
         o, nb, P, A = self.ops, self.nb, self.world, self.A
         self._build(spec, spec_cross, X, Xs, delta, jitter)
         o.reset_info()
         if self.owner(0) == self.rank:
             self._factor_block(0)
-        work_b = self._bcast(self.dbuf[0], self.owner(0), async_op=False)
-        for k in range(self.nblk):
+        self._wait(self._bcast(self.dbuf[0], self.owner(0), async_op=False))
+        work_g = self._solve_and_gather(0)
+        work_b = self._lookahead(1, [0]) if self.nblk > 1 else None
+        for k in range(self.nblk - 1):
+            c0, c1, c2 = k * nb, (k + 1) * nb, (k + 2) * nb
+            nbelow = self.nblk - 1 - k
+            cnt, perm = self._perm(k)
+            self._wait(work_g)
+            G = self.gath[k % 2][:P * cnt * nb]
+            rhs = [self.rows_rhs] if self.rows_rhs > 0 else []
+            # a. block column k+1
+            mine = [I for I in self.my_blocks if I >= k + 2]
+            seg_rows = [nb] * len(mine) + rhs
+            if seg_rows:
+                lo = self.loff[mine[0]] if mine else self.rows_mat
+                o.gemm_sub_stair(A[lo:, c1:c2], A[lo:, c0:c1], G, nb, seg_rows, [nb] * len(seg_rows), nb, perm[:1])
+            # b. panel k+1
             self._wait(work_b)
             if P == 1:
                 o.join_lookahead()
-            work_b = None
-            L, W = self._LW(k)
-            c0, c1 = k * nb, (k + 1) * nb
-            t0 = sum(1 for I in self.my_blocks if I <= k)            # my blocks at or above k
-            r_lo = t0 * nb
-            # 1. panel rows of everything I own below block k, right-hand-side rows included
-            o.trsm(L, nb, W, A[r_lo:, c0:c1], A.shape[0] - r_lo)
-            nbelow = self.nblk - 1 - k                                # global blocks below k
-            cnt, perm = self._perm(k)                                 # blocks per rank (padded), global order
-            work_g = None
-            if nbelow > 0:
-                mine = self.rows_mat - r_lo
-                if mine > 0:
-                    self.send[:mine].copy_(A[r_lo:self.rows_mat, c0:c1])
-                # 2. all-gather, issued BEFORE the look-ahead work so that it only waits for the solve
-                work_g = self._allgather(self.gath[:P * cnt * nb], self.send[:cnt * nb])
-            # 3. look-ahead (own stream): factor the next diagonal block from local data and send it on
-            #    its way while the main stream goes on to the trailing update
-            if k + 1 < self.nblk:
-                if self.owner(k + 1) == self.rank:
-                    with o.lookahead():
-                        lo = self.loff[k + 1]
-                        Pn = A[lo:lo + nb, c0:c1]
-                        o.gemm_sub(A[lo:lo + nb, c1:c1 + nb], Pn, Pn, nb, nb, nb, lower_only=True)
-                        self._factor_block(k + 1)
-                        work_b = self._bcast(self.dbuf[(k + 1) % 2], self.owner(k + 1), async_op=True)
-                else:
-                    work_b = self._bcast(self.dbuf[(k + 1) % 2], self.owner(k + 1), async_op=True)
-            # 4. trailing update: ONE staircase launch over every row block this rank owns below block
-            #    k + 1 (block I is (I - k) nb wide) and its right-hand-side rows (full width); the
-            #    gathered panel stays rank-major, `perm` tells the GEMM where logical block s lives
-            if nbelow > 0:
-                self._wait(work_g)
-                G = self.gath[:P * cnt * nb]
-                mine = [I for I in self.my_blocks if I >= k + 2]
-                seg_rows = [nb] * len(mine) + ([self.rows_rhs] if self.rows_rhs > 0 else [])
-                seg_cols = [(I - k) * nb for I in mine] + ([nbelow * nb] if self.rows_rhs > 0 else [])
-                if seg_rows:
-                    lo = self.loff[mine[0]] if mine else self.rows_mat
-                    o.gemm_sub_stair(A[lo:, c1:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm)
+            work_g = self._solve_and_gather(k + 1)
+            # c. diagonal block k+2
+            work_b = self._lookahead(k + 2, [k, k + 1]) if k + 2 < self.nblk else None
+            # d. the rest of the update with panel k; block k+2 itself has nothing left here (its diagonal block
+            #    belongs to the look-ahead)
+            mine = [I for I in self.my_blocks if I >= k + 3]
+            seg_rows = [nb] * len(mine) + rhs
+            seg_cols = [(I - k - 1) * nb for I in mine] + ([(nbelow - 1) * nb] if rhs else [])
+            if seg_rows and max(seg_cols) > 0:
+                lo = self.loff[mine[0]] if mine else self.rows_mat
+                o.gemm_sub_stair(A[lo:, c2:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm[1:])
         o.join_lookahead()
         t = self._allreduce(self.torch.tensor([float(o.read_info())], dtype=self.torch.float64), 'max')
         return int(t[0])
