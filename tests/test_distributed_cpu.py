@@ -22,7 +22,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize('world,N,nb,M', [(2, 700, 256, 20), (3, 520, 128, 300), (2, 300, 512, 20), (4, 1100, 128, 130),
-                                          (1, 400, 128, 20), (8, 2100, 128, 20)])
+                                          (1, 400, 128, 20), (8, 2100, 128, 20),
+                                          (3, 256, 128, 10), (5, 640, 128, 129), (2, 1280, 128, 257)])   # fewer blocks than ranks; one block per rank; a long pipeline
 def test_block_cyclic_driver_matches_oracle(tmp_path, world, N, nb, M):
     import torch.multiprocessing as mp
     from oracle import g3_oracle as orc
