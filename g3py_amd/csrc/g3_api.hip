@@ -554,11 +554,35 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     *info = *ctx->h_info;
     return G3_OK;
   };
+  // scalars of the evaluation: log-determinant, quadratic form, guards (and mean / sum of squares per query)
+  double st4[4];
+  auto finish = [&]() -> int {
+    int r = g3i_reset_info(ctx);
+    if (r) return r;
+    G3_HIP(hipMemcpyAsync(a, rhs, (size_t)Np * es, hipMemcpyDeviceToDevice, ctx->stream));
+    const int pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 2.0 * N * M);
+    r = logp_terms_launch(ctx, K, N, ldk, a, dt);
+    if (!r && M > 0 && (mu || ss)) r = rows_dot_ss_launch(ctx, Vp, M, N, ldk, a, dt, mu, ss);
+    g3i_prof_end(ctx, pr);
+    if (r) return r;
+    return fetch_stats(ctx, st4, 4);     // the one host synchronisation of a successful evaluation
+  };
   rc = build();
   if (rc) return rc;
   int info = 0;
-  rc = factor(&info);
-  if (rc) return rc;
+  {
+    // first attempt: the pivot flag travels to the host asynchronously and is looked at only after the
+    // reductions have been fetched -- one round trip per evaluation instead of two (the reductions of a failed
+    // factorisation are simply discarded)
+    const int pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0 + (double)N * N * (1 + M));
+    rc = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, E);
+    g3i_prof_end(ctx, pr);
+    if (rc) return rc;
+    G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    rc = finish();
+    if (rc) return rc;
+    info = *ctx->h_info;
+  }
   double tries = 0, fallback = 0;
   const int info0 = info;
   if (info != 0) {
@@ -606,19 +630,10 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
       if (rc) return rc;
     }
   }
-  rc = g3i_reset_info(ctx);
-  if (rc) return rc;
-  G3_HIP(hipMemcpyAsync(a, rhs, (size_t)Np * es, hipMemcpyDeviceToDevice, ctx->stream));
-  {
-    const int pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 2.0 * N * M);
-    rc = logp_terms_launch(ctx, K, N, ldk, a, dt);
-    if (!rc && M > 0 && (mu || ss)) rc = rows_dot_ss_launch(ctx, Vp, M, N, ldk, a, dt, mu, ss);
-    g3i_prof_end(ctx, pr);
+  if (info0 != 0) {          // the jitter path produced a new factor: its scalars replace the discarded ones
+    rc = finish();
     if (rc) return rc;
   }
-  double st4[4];
-  rc = fetch_stats(ctx, st4, 4);
-  if (rc) return rc;
   out[0] = st4[0];
   out[1] = st4[1];
   out[2] = st4[2];
