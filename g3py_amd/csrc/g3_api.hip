@@ -333,6 +333,40 @@ logp_terms_kernel(const T* L, int64_t n, int64_t ld, const T* a, double* out, in
   }
 }
 
+// The tail of one evaluation in ONE launch (small problems are bound by the number of launches, ~5 us each):
+// a_dst <- a_src (the solved right-hand-side row, npad entries), the four scalars of logp_terms_kernel over its
+// first n entries, and the pivot flag handed over and cleared: out[4] = *info, *info = 0.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+logp_finish_kernel(const T* L, int64_t n, int64_t npad, int64_t ld, const T* __restrict__ a_src, T* __restrict__ a_dst,
+                   double* out, int* info) {
+  __shared__ double s0[16], s1[16], s2[16], s3[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double ld_sum = 0, ss = 0, nf = 0, bd = 0;
+  for (int64_t i = tid; i < npad; i += 1024) {
+    const T av = a_src[i];
+    a_dst[i] = av;
+    if (i < n) {
+      const double d = (double)L[i * ld + i];
+      ld_sum += log(d);
+      if (!(d > 0.0) || __builtin_isinf(d)) bd += 1;
+      const double v = (double)av;
+      ss += v * v;
+      if (v != v || __builtin_isinf(v)) nf += 1;
+    }
+  }
+  ld_sum = wave_sum(ld_sum); ss = wave_sum(ss); nf = wave_sum(nf); bd = wave_sum(bd);
+  if (lane == 0) { s0[wave] = ld_sum; s1[wave] = ss; s2[wave] = nf; s3[wave] = bd; }
+  __syncthreads();
+  if (tid == 0) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int w = 0; w < 16; ++w) { a0 += s0[w]; a1 += s1[w]; a2 += s2[w]; a3 += s3[w]; }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+    out[4] = (double)*info;
+    *info = 0;
+  }
+}
+
 // one workgroup (256 threads) per row of V: dot with a, and sum of squares
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -555,33 +589,37 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     return G3_OK;
   };
   // scalars of the evaluation: log-determinant, quadratic form, guards (and mean / sum of squares per query)
-  double st4[4];
+  double st4[5];
   auto finish = [&]() -> int {
-    int r = g3i_reset_info(ctx);
-    if (r) return r;
-    G3_HIP(hipMemcpyAsync(a, rhs, (size_t)Np * es, hipMemcpyDeviceToDevice, ctx->stream));
     const int pr = g3i_prof_begin(ctx, G3_TAG_REDUCE, 2.0 * N * M);
-    r = logp_terms_launch(ctx, K, N, ldk, a, dt);
-    if (!r && M > 0 && (mu || ss)) r = rows_dot_ss_launch(ctx, Vp, M, N, ldk, a, dt, mu, ss);
+    if (dt == G3_F64)
+      hipLaunchKernelGGL((logp_finish_kernel<double>), dim3(1), dim3(1024), 0, ctx->stream, (const double*)K, N, Np, ldk,
+                         (const double*)rhs, (double*)a, ctx->d_stats, ctx->d_info);
+    else
+      hipLaunchKernelGGL((logp_finish_kernel<float>), dim3(1), dim3(1024), 0, ctx->stream, (const float*)K, N, Np, ldk,
+                         (const float*)rhs, (float*)a, ctx->d_stats, ctx->d_info);
+    G3_LAUNCH_CHECK();
+    int r = G3_OK;
+    if (M > 0 && (mu || ss)) r = rows_dot_ss_launch(ctx, Vp, M, N, ldk, a, dt, mu, ss);
     g3i_prof_end(ctx, pr);
     if (r) return r;
-    return fetch_stats(ctx, st4, 4);     // the one host synchronisation of a successful evaluation
+    r = fetch_stats(ctx, st4, 5);        // the one host synchronisation of a successful evaluation
+    if (!r) ctx->info_clean = true;      // the kernel above left the pivot flag cleared
+    return r;
   };
   rc = build();
   if (rc) return rc;
   int info = 0;
   {
-    // first attempt: the pivot flag travels to the host asynchronously and is looked at only after the
-    // reductions have been fetched -- one round trip per evaluation instead of two (the reductions of a failed
-    // factorisation are simply discarded)
+    // first attempt: the pivot flag comes back with the reductions -- one round trip per evaluation instead of two
+    // (the reductions of a failed factorisation are simply discarded)
     const int pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0 + (double)N * N * (1 + M));
     rc = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, E);
     g3i_prof_end(ctx, pr);
     if (rc) return rc;
-    G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     rc = finish();
     if (rc) return rc;
-    info = *ctx->h_info;
+    info = (int)st4[4];
   }
   double tries = 0, fallback = 0;
   const int info0 = info;

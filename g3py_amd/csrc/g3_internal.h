@@ -18,6 +18,7 @@ struct g3_ctx {
   hipEvent_t* la_ev;       // look-ahead events (2 per panel)
   int la_nev;
   int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
+  bool info_clean;         // d_info is known to be zero (left so by the previous evaluation's last kernel)
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
   bool adopted;            // stream belongs to the caller
   // batch mode (g3_gp_factor_batched): every MFMA GEMM and diagonal-block launch of a sweep acts on

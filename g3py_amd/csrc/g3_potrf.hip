@@ -921,7 +921,9 @@ static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n) {
 // right-hand sides B: on return those rows hold B L^-T (the forward substitution rides along
 // with the panel solves and trailing updates of the factorisation -- no separate trsm pass).
 int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd, int64_t E) {
-  G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
+  if (!(ctx->info_clean && g3_nbatch(ctx) == 1))
+    G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
+  ctx->info_clean = false;
   if (n == 0) return G3_OK;
   // The one-launch 256-wide diagonal kernel shortens the dependency chain (N = 8192: 8.9 -> 8.2 ms); large
   // factorisations are bound by the bulk updates instead and measured 0.4 % slower with it.
