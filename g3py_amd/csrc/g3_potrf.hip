@@ -925,9 +925,10 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
     G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
   ctx->info_clean = false;
   if (n == 0) return G3_OK;
-  // The one-launch 256-wide diagonal kernel shortens the dependency chain (N = 8192: 8.9 -> 8.2 ms); large
-  // factorisations are bound by the bulk updates instead and measured 0.4 % slower with it.
-  ctx->fuse256 = n <= 20480;
+  // The one-launch 256-wide diagonal kernel shortens the dependency chain (N = 8192: 8.9 -> 8.2 ms when it was
+  // introduced); since the round-2 rewrite of the diagonal kernels it is no slower at any size (N = 24576: 95.2 ->
+  // 95.0 ms, 32768: equal), so it is always used.
+  ctx->fuse256 = true;
 
   int64_t NB = g3i_panel_width(ctx, n);
   if (n >= 3 * NB) {
