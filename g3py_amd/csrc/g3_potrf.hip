@@ -63,7 +63,15 @@ __device__ __forceinline__ float fast_rcp(float p) {
 #endif
 constexpr int TS = 17;   // LDS tile row stride in elements (16 + 1: conflict-free fragment reads)
 template <typename T>
+struct DiagScratch {};      // fp64: the tile routine works on S.D / S.Wd directly
+template <>
+struct DiagScratch<float> { // fp32: the 16 x 16 diagonal tile is factored in double (as the reference's dpotrf does,
+  double D[16 * TS];        // tensors.py:198,219) by the same routine as the fp64 path
+  double W[16 * TS];
+};
+template <typename T>
 struct DiagLds {
+  DiagScratch<T> x;
   T D[2][16 * TS];        // [step parity] diagonal tile, then L_dd
   T Wd[2][16 * TS];       // [step parity] W_dd = inv(L_dd)
   T P[8][16 * TS];        // panel tiles L(i,k), i = block row (also scratch for the raw A(i,k))
@@ -395,6 +403,25 @@ __device__ __noinline__ void diag16s(double* D, double* Wd, int lane, int* info,
   TileOps<double>::store(Wd, aW, lane);
 }
 
+// fp32 front end of diag16s: the tile goes through double (16 x 16 elements: four conversions per lane each way).
+// CholeskyRobust factors float32 covariances in float64 and casts back (tensors.py:198,219); doing that at least
+// for the diagonal tiles -- where the pivots are -- follows it more closely than an fp32 sweep, and the fp64 tile
+// routine is the faster one (2.65 us against 3.4).
+__device__ __forceinline__ void diag16s_f32(float* D, float* Wd, double* Dd, double* Wdd, int lane, int* info, int64_t base) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = lane + 64 * r, i = e >> 4, c = e & 15;
+    Dd[i * TS + c] = (double)D[i * TS + c];
+  }
+  diag16s(Dd, Wdd, lane, info, base);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = lane + 64 * r, i = e >> 4, c = e & 15;
+    D[i * TS + c] = (float)Dd[i * TS + c];
+    Wd[i * TS + c] = (float)Wdd[i * TS + c];
+  }
+}
+
 // The program of wave W (block row W) of the diagonal-block kernel, with W a compile-time constant:
 // every "does this wave take part" test folds away, so the register allocator sees the true
 // lifetime of each accumulator tile instead of the union over all waves.
@@ -438,6 +465,8 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
         diag16s((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
       else if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
         diag16m<FACTOR>((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
+      else if constexpr (sizeof(T) == 4 && FACTOR && G3_DIAG16_SYM)
+        diag16s_f32((float*)S.D[par], (float*)S.Wd[par], S.x.D, S.x.W, lane, info, row_base + 16 * k);
       else
         diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
       if (FACTOR) {                         // the diagonal tile of L is final: write it out
