@@ -39,9 +39,12 @@ class Kernel(Hypers):
     """covariance function = var * (something of a metric); `metric` may be a class (instantiated on
     the same columns) or a ready instance"""
 
-    def __init__(self, x=None, name=None, metric=Delta, var=None):
+    METRIC = Delta          # the metric a subclass is built on unless the caller passes one
+
+    def __init__(self, x=None, name=None, metric=None, var=None):
+        metric = type(self).METRIC if metric is None else metric
         self.metric = metric(x) if isinstance(metric, type) else metric
-        super().__init__(x, name)
+        Hypers.__init__(self, x, name)
         self.var = var
 
     def check_hypers(self, parent=''):
@@ -108,9 +111,7 @@ class Kernel(Hypers):
 class KernelStationary(Kernel):
     """cov = var * k(metric.gram) -- kernels.py:96-110"""
     kind = None
-
-    def __init__(self, x=None, name=None, metric=ARD_L2, var=None):
-        super().__init__(x, name, metric, var)
+    METRIC = ARD_L2
 
     def spec(self, values, d):
         return (self.kind, value_of(self.var, values), value_of(self.metric.rate, values),
@@ -237,9 +238,7 @@ class KernelSum(KernelComposition):
 class KernelNoise(KernelStationary):
     """var * I when square, zeros for a cross block -- kernels.py:360-371"""
     kind = 'NOISE'
-
-    def __init__(self, x=None, name=None, metric=Delta, var=None):
-        super().__init__(x, name, metric, var)
+    METRIC = Delta
 
     def spec(self, values, d):
         return ('NOISE', value_of(self.var, values))
@@ -248,9 +247,7 @@ class KernelNoise(KernelStationary):
 class WN(KernelStationary):
     """var * I when square, var * Delta.gram for a cross block -- kernels.py:374-385"""
     kind = 'WN'
-
-    def __init__(self, x=None, name=None, metric=Delta, var=None):
-        super().__init__(x, name, metric, var)
+    METRIC = Delta
 
     def spec(self, values, d):
         return ('WN', value_of(self.var, values), self.metric.dims_index(d))
@@ -260,8 +257,8 @@ class RQ(KernelStationary):
     """(1 + d/alpha)^(-alpha) -- kernels.py:388-403"""
     kind = 'RQ'
 
-    def __init__(self, x=None, name=None, metric=ARD_L2, var=None, alpha=None):
-        super().__init__(x, name, metric, var)
+    def __init__(self, x=None, name=None, metric=None, var=None, alpha=None):
+        Kernel.__init__(self, x, name, metric, var)
         self.alpha = alpha
 
     def check_hypers(self, parent=''):
@@ -294,26 +291,22 @@ class KernelStationaryExponential(KernelStationary):
 
 class OU(KernelStationaryExponential):
     kind = 'OU'
-
-    def __init__(self, x=None, name=None, metric=ARD_L1, var=None):
-        super().__init__(x, name, metric, var)
+    METRIC = ARD_L1
 
 
 class SE(KernelStationaryExponential):
     kind = 'SE'
 
-    def __init__(self, x=None, name=None, metric=ARD_L2, var=None):
-        super().__init__(x, name, metric, var)
-
 
 class KernelPeriodic(KernelStationary):
     """periodic family on the Difference metric -- kernels.py:439-459"""
-    uses_rate = True
+    uses_rate = True        # COS and SINC have no decay: their rate slot is the constant 1
+    METRIC = Difference
 
-    def __init__(self, x=None, name=None, metric=Difference, var=None, freq=None, rate=None):
-        super().__init__(x, name, metric, var)
+    def __init__(self, x=None, name=None, metric=None, var=None, freq=None, rate=None):
+        Kernel.__init__(self, x, name, metric, var)
         self.freq = freq
-        self.rate = rate
+        self.rate = rate if type(self).uses_rate else 1.0
 
     def check_hypers(self, parent=''):
         super().check_hypers(parent=parent)
@@ -346,9 +339,6 @@ class COS(KernelPeriodic):
     kind = 'COS'
     uses_rate = False
 
-    def __init__(self, x=None, name=None, metric=Difference, var=None, freq=None):
-        super().__init__(x, name, metric, var, freq, rate=1.0)
-
 
 class SIN(KernelPeriodic):
     """exp(+2 sum_k rate_k sin^2(pi dx_k f_k)) -- kernels.py:470-472 (sign as in the reference)"""
@@ -359,9 +349,6 @@ class SINC(KernelPeriodic):
     """prod_k sinc -- kernels.py:475-482"""
     kind = 'SINC'
     uses_rate = False
-
-    def __init__(self, x=None, name=None, metric=Difference, var=None, freq=None):
-        super().__init__(x, name, metric, var, freq, rate=1.0)
 
 
 class SM(KernelPeriodic):
