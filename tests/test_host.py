@@ -169,3 +169,32 @@ def test_potentials_enter_logp_prior():
     values, extra = gp._values(p)
     assert np.isclose(extra, -2.0 * 3.0)
     assert np.isclose(gp.th_logp(None, None, None, [], p, prior=True), -6.0)
+
+
+def test_hyper_slots_positional_keyword_and_supplied_values():
+    """the declarative slot table behind every hyper-parametric function: slots are filled by position or keyword
+    (the reference's constructor signatures), unknown names are refused, a supplied number stays a constant and is
+    not registered, and the registered names are `<parent><Owner><suffix>` (ARD rates: `<parent>rate`)"""
+    import g3py_amd as g3
+    from g3py_amd.processes.hypers import Hypers, HyperVar, Model
+    x = np.zeros((4, 3))
+    with Model('slots') as m:
+        a = g3.LinearMapping(x[:, 0], 'T', None, 2.5)        # positional: shift free, scale = 2.5
+        a.check_hypers('P_')
+        b = g3.BoxCoxLinear(name='B', power=1.2)
+        b.check_hypers('P_')
+        k = g3.SE(x)
+        k.check_hypers('P_')
+        per = g3.COS(x)
+        per.check_hypers('P_')
+        ou = g3.OU(x)
+    assert isinstance(a.shift, HyperVar) and a.shift.name == 'P_T_shift' and not a.shift.positive
+    assert a.scale == 2.5 and [h.name for h in a.hypers if isinstance(h, HyperVar)] == ['P_T_shift']
+    assert b.power == 1.2 and b.scale.key == 'P_B_scale_log_'
+    assert [v.key for v in m.vars if v.name.startswith('P_SE')] == ['P_SE_var_log_', 'P_SE_rate_log_']
+    assert k.metric.rate.shape == (3,) and type(k.metric).__name__ == 'ARD_L2' and type(ou.metric).__name__ == 'ARD_L1'
+    assert per.rate == 1.0 and per.freq.shape == (3,) and type(per.metric).__name__ == 'Difference'
+    with pytest.raises(TypeError):
+        g3.LinearMapping(x[:, 0], 'T', colour=1)
+    with pytest.raises(TypeError):
+        g3.Bias(x, 'b', 1.0, 2.0)                             # one slot, two values
