@@ -163,25 +163,28 @@ __device__ __forceinline__ T scrub(T v) {
   return v;
 }
 
-// Fast path: prog == var * SE(all d columns in order) [+ noise on the square diagonal].
-// D compile-time: x_j lives in registers, x_i is an LDS broadcast.
+// Fast path: prog == var * k(all d columns in order) [+ noise on the square diagonal] with k one stationary
+// kernel on an ARD metric -- SE, OU, MAT32, MAT52 or RQ, the expressions the reference's examples are built from.
+// D and the kind are compile-time: x_j lives in registers, x_i is an LDS broadcast, nothing is interpreted
+// (the run-time interpreter costs 36 % on top of the arithmetic).
 template <typename T, int D>
 struct SeParams {
-  T w[D];   // 0.5 * rate^2
-  T var, noise;
+  T w[D];   // ARD_L2 kinds: 0.5 * rate^2 ; OU (ARD_L1): rate
+  T var, noise, alpha;
 };
 
 // One workgroup (256 threads) writes a 64-row x 128-column tile; a thread owns two adjacent
 // columns (one 16-byte store per row for fp64: a wave writes 1 KiB of one row per instruction)
 // and every fourth row.
 #define GTN 128
-template <typename T, int D, bool SE_FAST>
+template <typename T, int D, int FK>   // FK: g3_kind of the fast path, -1 = generic program
 __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
             int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
             T* __restrict__ K, int64_t ldk, int64_t n1pad, int64_t n2pad, unsigned flags, int sym, int ntrig,
             int64_t kstride, int64_t diag_off) {
   // grid.z = batch member: its own program (hyper-parameters) and output matrix, same inputs
+  constexpr bool SE_FAST = FK >= 0;
   if constexpr (!SE_FAST) prog += blockIdx.z;
   K += (int64_t)blockIdx.z * kstride;
   int64_t bi = blockIdx.y, bj = blockIdx.x;
@@ -273,9 +276,22 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
 #pragma unroll
           for (int c = 0; c < D; ++c) {
             const T dx = xi[c] - (q ? xrb[c] : xra[c]);
-            dd += (dx * dx) * se.w[c];
+            if constexpr (FK == G3_K_OU) dd += fabs(dx) * se.w[c];      // metrics.py:89-91
+            else dd += (dx * dx) * se.w[c];                             // metrics.py:100-102
           }
-          v[q] = se.var * exp(-dd);
+          T kv;
+          if constexpr (FK == G3_K_MAT32) {
+            const T s3 = sqrt(T(3) * dd);
+            kv = (T(1) + s3) * exp(-s3);
+          } else if constexpr (FK == G3_K_MAT52) {
+            const T s5 = sqrt(T(5) * dd);
+            kv = (T(1) + s5 + T(5) * dd / T(3)) * exp(-s5);
+          } else if constexpr (FK == G3_K_RQ) {
+            kv = pow(T(1) + dd / se.alpha, -se.alpha);
+          } else {
+            kv = exp(-dd);
+          }
+          v[q] = se.var * kv;
           if (dg) v[q] += se.noise;
         } else {
           if (ntrig > 0)
@@ -370,43 +386,56 @@ static inline int64_t ctx_diag_off(const g3_ctx* ctx) { return ctx->gram_diag_of
 
 // recognise  var*SE(x[:, 0:d]) (+ Noise)  so the common case takes the register fast path
 template <typename T, int D>
-static bool match_se(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
-  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 2) return false;
+static int match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
+  // returns the leaf kind of a `var * k(x[:, 0..d)) [+ noise]` program, or -1
+  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 2) return -1;
   int se = -1, noise = -1;
   for (int q = 0; q < p->nprod; ++q) {
-    if (p->prod[q].nfac != 1) return false;
+    if (p->prod[q].nfac != 1) return -1;
     const g3_leaf& lf = p->leaf[p->prod[q].fac[0]];
-    if (lf.kind == G3_K_SE && se < 0) se = q;
+    const bool stat = lf.kind == G3_K_SE || lf.kind == G3_K_OU || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52 ||
+                      lf.kind == G3_K_RQ;
+    if (stat && se < 0) se = q;
     else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
-    else return false;
+    else return -1;
   }
-  if (se < 0) return false;
+  if (se < 0) return -1;
   const g3_leaf& lf = p->leaf[p->prod[se].fac[0]];
-  if (lf.ndims != D) return false;
+  if (lf.ndims != D) return -1;
   for (int k = 0; k < D; ++k) {
-    if (lf.dims[k] != k) return false;
-    out->w[k] = (T)(0.5 * lf.rate[k] * lf.rate[k]);
+    if (lf.dims[k] != k) return -1;
+    out->w[k] = lf.kind == G3_K_OU ? (T)lf.rate[k] : (T)(0.5 * lf.rate[k] * lf.rate[k]);
   }
   // (coef * var) applied once; identical to var*k when coef == 1 (the un-scaled kernel)
-  if (p->prod[se].coef != 1.0) return false;
+  if (p->prod[se].coef != 1.0) return -1;
   out->var = (T)lf.var;
+  out->alpha = (T)lf.alpha;
   out->noise = T(0);
   if (noise >= 0) {
-    if (p->prod[noise].coef != 1.0) return false;
+    if (p->prod[noise].coef != 1.0) return -1;
     out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
   }
-  return true;
+  return lf.kind;
 }
 
 template <typename T, int D>
-static int launch_gram_fast(g3_ctx* ctx, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
+static int launch_gram_fast(g3_ctx* ctx, int kind, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
                             const T* X2, int64_t n2, int64_t ldx2, T* K, int64_t ldk, int64_t n1pad,
                             int64_t n2pad, unsigned flags, int sym) {
   dim3 grid = gram_grid(n1pad, n2pad, flags);
   const size_t lds = (GT + GTN) * (D | 1) * sizeof(T);
-  hipLaunchKernelGGL((gram_kernel<T, D, true>), grid, dim3(256), lds, ctx->stream,
-                     (const g3_kernel_prog*)nullptr, se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad,
-                     n2pad, flags, sym, 0, (int64_t)0, ctx_diag_off(ctx));
+#define G3_GRAM_FAST_LAUNCH(KIND)                                                                              \
+  hipLaunchKernelGGL((gram_kernel<T, D, KIND>), grid, dim3(256), lds, ctx->stream, (const g3_kernel_prog*)nullptr, \
+                     se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad, n2pad, flags, sym, 0, (int64_t)0,           \
+                     ctx_diag_off(ctx))
+  switch (kind) {
+    case G3_K_SE: G3_GRAM_FAST_LAUNCH(G3_K_SE); break;
+    case G3_K_OU: G3_GRAM_FAST_LAUNCH(G3_K_OU); break;
+    case G3_K_MAT32: G3_GRAM_FAST_LAUNCH(G3_K_MAT32); break;
+    case G3_K_MAT52: G3_GRAM_FAST_LAUNCH(G3_K_MAT52); break;
+    default: G3_GRAM_FAST_LAUNCH(G3_K_RQ); break;
+  }
+#undef G3_GRAM_FAST_LAUNCH
   G3_LAUNCH_CHECK();
   return G3_OK;
 }
@@ -416,13 +445,14 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
                   const T* X2, int64_t n2, int64_t ldx2, int d, T* K, int64_t ldk, int64_t n1pad,
                   int64_t n2pad, unsigned flags, int sym) {
   {
+    int fk;
     SeParams<T, 1> s1; SeParams<T, 2> s2; SeParams<T, 3> s3; SeParams<T, 4> s4; SeParams<T, 8> s8; SeParams<T, 16> s16;
-    if (match_se<T, 1>(prog, d, &s1)) return launch_gram_fast<T, 1>(ctx, s1, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if (match_se<T, 2>(prog, d, &s2)) return launch_gram_fast<T, 2>(ctx, s2, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if (match_se<T, 3>(prog, d, &s3)) return launch_gram_fast<T, 3>(ctx, s3, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if (match_se<T, 4>(prog, d, &s4)) return launch_gram_fast<T, 4>(ctx, s4, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if (match_se<T, 8>(prog, d, &s8)) return launch_gram_fast<T, 8>(ctx, s8, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if (match_se<T, 16>(prog, d, &s16)) return launch_gram_fast<T, 16>(ctx, s16, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if ((fk = match_fast<T, 1>(prog, d, &s1)) >= 0) return launch_gram_fast<T, 1>(ctx, fk, s1, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if ((fk = match_fast<T, 2>(prog, d, &s2)) >= 0) return launch_gram_fast<T, 2>(ctx, fk, s2, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if ((fk = match_fast<T, 3>(prog, d, &s3)) >= 0) return launch_gram_fast<T, 3>(ctx, fk, s3, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if ((fk = match_fast<T, 4>(prog, d, &s4)) >= 0) return launch_gram_fast<T, 4>(ctx, fk, s4, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if ((fk = match_fast<T, 8>(prog, d, &s8)) >= 0) return launch_gram_fast<T, 8>(ctx, fk, s8, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+    if ((fk = match_fast<T, 16>(prog, d, &s16)) >= 0) return launch_gram_fast<T, 16>(ctx, fk, s16, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
   }
   const g3_kernel_prog* dprog;
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
@@ -439,7 +469,7 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   if (ntrig > 16 || direct) ntrig = 0;
   const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
   SeParams<T, 1> dummy{};
-  hipLaunchKernelGGL((gram_kernel<T, 1, false>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
+  hipLaunchKernelGGL((gram_kernel<T, 1, -1>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
                      ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig, (int64_t)0, ctx_diag_off(ctx));
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -457,13 +487,13 @@ int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_
   if (dt == G3_F64) {
     const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(double);
     SeParams<double, 1> dummy{};
-    hipLaunchKernelGGL((gram_kernel<double, 1, false>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
+    hipLaunchKernelGGL((gram_kernel<double, 1, -1>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
                        (const double*)X, n, ldx, (const double*)X, n, ldx, d, (double*)K, ldk, npad, npad, flags, 1,
                        ntrig, kstride, (int64_t)0);
   } else {
     const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(float);
     SeParams<float, 1> dummy{};
-    hipLaunchKernelGGL((gram_kernel<float, 1, false>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
+    hipLaunchKernelGGL((gram_kernel<float, 1, -1>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
                        (const float*)X, n, ldx, (const float*)X, n, ldx, d, (float*)K, ldk, npad, npad, flags, 1,
                        ntrig, kstride, (int64_t)0);
   }

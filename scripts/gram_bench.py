@@ -10,6 +10,9 @@ cases = [('SE+noise d=4 N=32768 lower', ('sum', ('SE', 1.0, np.ones(4), None), (
          ('SE+noise d=4 N=32768 full', ('sum', ('SE', 1.0, np.ones(4), None), ('NOISE', 0.1)), 32768, 4, False),
          ('MAT52+COS+noise d=8 N=16384 lower (config 3)', ('sum', ('sum', ('MAT52', 1.0, np.ones(8), None), ('COS', 0.5, np.full(8, 0.125), None)), ('NOISE', 0.1)), 16384, 8, True),
          ('MAT52+SIN+noise d=8 N=16384 lower', ('sum', ('sum', ('MAT52', 1.0, np.ones(8), None), ('SIN', 0.5, np.full(8, 0.125), np.full(8, 0.25), None)), ('NOISE', 0.1)), 16384, 8, True),
+         ('MAT52+noise d=8 N=16384 lower (fast path)', ('sum', ('MAT52', 1.0, np.ones(8), None), ('NOISE', 0.1)), 16384, 8, True),
+         ('RQ+noise d=4 N=16384 lower (fast path)', ('sum', ('RQ', 1.0, np.ones(4), 1.5, None), ('NOISE', 0.1)), 16384, 4, True),
+         ('OU+noise d=4 N=16384 lower (fast path)', ('sum', ('OU', 1.0, np.ones(4), None), ('NOISE', 0.1)), 16384, 4, True),
          ('SE+noise d=16 N=16384 lower', ('sum', ('SE', 1.0, np.ones(16), None), ('NOISE', 0.1)), 16384, 16, True)]
 for name, spec, N, d, lower in cases:
     X = torch.rand((N, d), dtype=torch.float64, device='cuda') * N ** (1 / d)
