@@ -67,13 +67,22 @@ def _measure_traffic(argv_workload):
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '--',
                    sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '0', '--cpu-n', '0',
                    '--skip-events'] + argv_workload
+            # the profiler and the profiled python run in their own session: on a timeout the WHOLE group is
+            # killed and reaped before tmp goes away, so no grandchild is left holding the GPU
+            import signal
+            child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp, start_new_session=True)
             try:
-                r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp, timeout=150)
+                rc = child.wait(timeout=150)
             except subprocess.TimeoutExpired:
-                return None, 'rocprofv3 --pmc %s child timed out' % counter
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                child.wait()
+                return None, 'rocprofv3 --pmc %s child timed out (process group killed)' % counter
             fs = glob.glob(os.path.join(tmp, '**', '*_counter_collection.csv'), recursive=True)
-            if r.returncode != 0 or not fs:
-                return None, 'rocprofv3 --pmc %s child failed (rc %s)' % (counter, r.returncode)
+            if rc != 0 or not fs:
+                return None, 'rocprofv3 --pmc %s child failed (rc %s)' % (counter, rc)
             n, kb = 0, 0.0
             for row in csv.DictReader(open(fs[0])):
                 name = row['Kernel_Name']
@@ -102,6 +111,53 @@ def _golden_logp(N, d, M, seed, kernel):
         if (g['N'], g['d'], g['M'], g['seed'], g['kernel']) == (N, d, M, seed, kernel):
             return float(g['logp'])
     return None
+
+
+def _golden_c5(N, d, M, seed, S):
+    """the fp64 oracle's pin of BASELINE config 5 (tests/golden/fullsize.json: c5 / c5mini), or None"""
+    try:
+        gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fullsize.json')))
+    except Exception:
+        return None
+    for g in gold.values():
+        if 'draw_values' in g and (g['N'], g['d'], g['M'], g['seed'], g['draws']) == (N, d, M, seed, S):
+            return g
+    return None
+
+
+def _api_timing(g3, X, y, Xs, d, kernel, npdt):
+    """What the user calls: GaussianProcess.logp and .predict through the public API from HOST
+    NumPy inputs -- parameter dict -> kernel program, H2D of X / y / Xs, Gram, Cholesky, solves, D2H of the
+    statistics.  A fresh parameter vector per call, so the factor cache never hits; reported beside the
+    device-resident step, never part of `value`."""
+    import time as _t
+    kern = g3.SE(X) if kernel == 'se' else g3.MAT52(X) + g3.COS(X)
+    gp = g3.GaussianProcess(space=Xs, location=g3.Zero(), kernel=kern)
+    t0 = _t.perf_counter()
+    gp.observed(X.astype(npdt), y.astype(npdt))
+    t_obs = _t.perf_counter() - t0
+    res = {'observed_ms': t_obs * 1e3}
+    for rep in range(2):                      # rep 0 allocates the device workspace; rep 1 is the steady state
+        params = dict(gp.params)
+        for k_ in params:
+            if k_.endswith('_var_log_') and 'Noise' not in k_:
+                params[k_] = np.log(1.0 + 1e-3 * (rep + 1))
+            elif k_.endswith('_rate_log_'):
+                params[k_] = np.log(np.ones(d))
+            elif 'Noise' in k_:
+                params[k_] = np.log(0.1)
+            elif k_.endswith('_freq_log_') or k_.endswith('_freq'):
+                params[k_] = np.log(np.full(d, 0.125)) if k_.endswith('_log_') else np.full(d, 0.125)
+        t0 = _t.perf_counter()
+        lp = gp.logp(params)
+        t1 = _t.perf_counter()
+        pr = gp.predict(params, mean=True, var=True, std=False)
+        t2 = _t.perf_counter()
+        res.update(logp_ms=(t1 - t0) * 1e3, predict_ms=(t2 - t1) * 1e3, logp=float(lp),
+                   mean0=float(np.asarray(pr.mean)[0]), var0=float(np.asarray(pr.variance)[0]))
+    res['note'] = ('public API, host NumPy in / out, second of two evaluations with distinct hyper-parameters; predict = '
+                   'posterior mean + variance at the M test points re-using the factor of the logp call (one cross solve)')
+    return res
 
 
 def synth(N, d, M, seed):
@@ -190,9 +246,14 @@ def main():
                                                         'after the timed region; reported under "dlogp", never part of value')
     ap.add_argument('--draws', type=int, default=-1, help='posterior draws S through the warped-GP path (BASELINE config 5: posterior '
                                                           'covariance + second Cholesky + L Z + mapping); default 16 with --f32, else 0')
+    ap.add_argument('--api', action='store_true', default=None, help='also time GaussianProcess.logp + predict through the public API '
+                                                                     'from host NumPy inputs ("api_ms"; default: on for the one-GPU run)')
+    ap.add_argument('--no-api', dest='api', action='store_false')
     ap.add_argument('--panel', dest='nb', type=int, default=0, help='row-block height of the multi-GPU distribution (0 = 1024 up to 4 GPUs, 512 beyond)')
     args = ap.parse_args()
 
+    if args.api is None:
+        args.api = args.gpus == 1 and not args.no_prof
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` typed directly: start one FRESH child process per GPU through
         # torch.distributed.run and exit with its status.  Nothing in this process has touched the GPU
@@ -229,7 +290,17 @@ def main():
                          'several ranks on one GPU)' % (world, world, ndev))
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # G3_FORCE_DIST=1 G3_DIST_COLLECTIVES=1 on one GPU: the multi-rank driver with ONE rank whose collectives
+    # really go through ProcessGroupNCCL = RCCL (stream semantics, work handles, the second communicator)
+    solo_pg = world == 1 and os.environ.get('G3_FORCE_DIST', '0') == '1' and os.environ.get('G3_DIST_COLLECTIVES', '0') == '1'
+    if solo_pg:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
+    if world > 1 or solo_pg:
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
@@ -361,7 +432,17 @@ def main():
         t = torch.tensor([elapsed], dtype=tdt, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm_all = None
+    if use_dist:
+        # per-rank collective counts, bytes over the fabric (sent + received) and host seconds spent waiting
+        mine = dgp.comm_stats()
+        if world > 1:
+            comm_all = [None] * world
+            dist.all_gather_object(comm_all, mine)
+        else:
+            comm_all = [mine]
 
+    failed = None
     if rank == 0:
         sec = elapsed / args.steps
         flops = step_flops(N, M, S)
@@ -375,8 +456,16 @@ def main():
                                    % (N, d, M, M), 'N': N, 'd': d, 'M': M, 'parallelism': parallelism},
             'e2e_sec': sec, 'logp': float(result['logp']),
         }
+        if comm_all is not None:
+            out['comm'] = {'per_rank': [{k: {'calls_per_step': v['calls'] / args.steps, 'bytes_per_step': v['bytes'] / args.steps,
+                                             'host_wait_s_per_step': v['wait_s'] / args.steps} for k, v in r.items()}
+                                        for r in comm_all],
+                           'collectives_forced_at_world_1': bool(solo_pg), 'backend': backend,
+                           'note': 'bytes = sent + received by the rank; host_wait = host time inside work.wait() / blocking '
+                                   'all-reduces (RCCL waits are stream dependencies: ~0 unless the host is the bottleneck)'}
         if S > 0:
             dr = result['draws']
+            out['metric'] += ' (+ posterior covariance, its Cholesky and %d draws)' % S
             out['config']['workload'] = ('warped ' + out['config']['workload'] + ' + posterior covariance + its Cholesky + %d draws '
                                          'L Z + BoxCoxLinear mapping' % S)
             out['config']['draws'] = S
@@ -440,9 +529,22 @@ def main():
         # full-size pin: the CPU oracle's logp at this exact configuration (tests/golden/fullsize.json,
         # written once by oracle/gen_fullsize.py in the build container; data, not code)
         ref = _golden_logp(N, d, M, seed, args.kernel) if not (args.f32 or S > 0) else None
+        tol = 1e-8
         if ref is not None:
             out['logp_ref'] = ref
             out['logp_rel_err'] = abs(out['logp'] - ref) / abs(ref)
+        elif S > 0:
+            # config 5 (warped GP + draws): the fp64 oracle's full-size pin, compared at the fp32 tolerance
+            g5 = _golden_c5(N, d, M, seed, S)
+            if g5 is not None:
+                ref, tol = float(g5['logp']), (1e-4 if args.f32 else 1e-8)
+                out['logp_ref'] = ref
+                out['logp_rel_err'] = abs(out['logp'] - ref) / abs(ref)
+                rows = g5['draw_rows']
+                got = np.asarray(result['draws'])[rows]
+                want = np.asarray(g5['draw_values'])
+                out['draws']['max_abs_err_vs_oracle_rows'] = float(np.max(np.abs(got - want)))
+                out['draws']['oracle_rows'] = rows
         if args.measure_traffic is None:      # default: the headline line carries a traffic figure measured in the run itself
             profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
             args.measure_traffic = (world == 1 and not args.f32 and N == 32768 and not args.no_prof and not profiled
@@ -456,14 +558,24 @@ def main():
                 out['roofline']['traffic_source'] = note
             else:                             # keep the committed figure, say why
                 out['roofline']['traffic_source'] += '; live measurement unavailable: ' + note
+        if args.api and world == 1 and not use_dist and S == 0:
+            out['api_ms'] = _api_timing(g3, X, y, Xs, d, args.kernel, npdt)
         print(json.dumps(out))
-        if ref is not None and not out['logp_rel_err'] <= 1e-8:
-            raise SystemExit('bench.py: logp %.12f differs from the oracle pin %.12f by more than 1e-8 relative'
-                             % (out['logp'], ref))
+        if ref is not None and not out['logp_rel_err'] <= tol:
+            failed = 'bench.py: logp %.12f differs from the oracle pin %.12f by more than %g relative' % (out['logp'], ref, tol)
+    # every rank learns the verdict BEFORE the group is torn down, so a failed pin ends all ranks at once
+    # instead of leaving the others to the launcher's timeout
     if world > 1:
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=tdev)
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) and not failed:
+            failed = 'bench.py: rank 0 reported a failed oracle pin'
+    if world > 1 or solo_pg:
         dist.destroy_process_group()
     # explicit teardown while the HIP runtime is alive (streams, events, pinned buffers, workspaces)
     g3.Device.close_all()
+    if failed:
+        raise SystemExit(failed)
 
 
 if __name__ == '__main__':

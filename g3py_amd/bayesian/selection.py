@@ -14,7 +14,17 @@ import time
 from datetime import datetime
 
 import numpy as np
-import pandas as pd
+
+def _pandas():
+    """the result tables are pandas frames, as in the reference; nothing else in g3py_amd needs pandas, so it is
+    imported only when an Experiment is created"""
+    try:
+        import pandas
+    except ImportError as e:
+        raise ImportError('g3py_amd.Experiment keeps its simulation / result tables in pandas DataFrames '
+                          '(boundary: g3py/bayesian/selection.py:43-60): install pandas to use it') from e
+    return pandas
+
 
 SIM_COLUMNS = ('obs', 'valid', 'test', 'datetime')
 RESULT_COLUMNS = ('n_sim', 'model', 'selected', 'start', 'params', 'scores_obs', 'scores_valid', 'scores_test',
@@ -60,6 +70,7 @@ class Experiment:
         self.data_limit, self.data_min, self.data_method = 1, True, random_obs
         self.scores_mean = self.scores_median = self.scores_variance = self.scores_logpred = True
         self.find_MAP, self.selector, self.holdout, self.holdout_p = False, None, None, 0
+        pd = _pandas()
         self.simulations_raw = pd.DataFrame(columns=list(SIM_COLUMNS))
         self.results_raw = pd.DataFrame(columns=list(RESULT_COLUMNS))
 
@@ -182,7 +193,7 @@ class Experiment:
             else:
                 row['params'] = r.params
             rows.append(row)
-        df = pd.DataFrame(rows)
+        df = _pandas().DataFrame(rows)
         if like is not None:
             df = df[[c for c in df.columns if like in c or c in ('n_sim', 'model')]]
         return df

@@ -16,6 +16,8 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   if (!ctx) return G3_ERR_NOMEM;
   memset(ctx, 0, sizeof(*ctx));
   ctx->device = device;
+  int prev_dev = -1;                       // like every other entry: the caller's current device is restored
+  if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
   if (e == hipSuccess) {
@@ -34,10 +36,12 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, G3_MAX_BATCH * sizeof(int));
   if (e != hipSuccess) {
     g3_ctx_destroy(ctx);
+    if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     return G3_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
   *out = ctx;
+  if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
   return G3_OK;
 }
 
@@ -75,6 +79,11 @@ extern "C" int g3_ctx_set_stream(g3_ctx* ctx, void* s) {
   if (!ctx) return -1;
   g3_dev_guard _dg(ctx);
   G3_HIP(hipStreamSynchronize(ctx->stream));
+  // the old stream is drained: every slot of the program ring is free, and nothing may be recorded on (or
+  // waited for from) a stream the caller is about to destroy
+  for (int i = 0; i < G3_PROG_SLOTS; ++i) ctx->prog_busy[i] = false;
+  ctx->prog_last = -1;
+  ctx->prog_stream = nullptr;
   ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
   ctx->adopted = (s != nullptr);
   return G3_OK;

@@ -43,6 +43,27 @@ def block_ranges(Np, nb):
     return [(a, min(nb, Np - a)) for a in r]
 
 
+def stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, limit):
+    """cut a staircase update into launches of at most `limit` row segments and `limit` blocks of B.
+    Yields (first row, segment rows, first column, segment columns, block table) per launch; columns are cut at
+    multiples of b_block_rows (the whole width when B has no block table and fits)"""
+    nseg = len(seg_rows)
+    width = max(seg_cols)
+    cstep = limit * b_block_rows if b_block_rows > 0 else width
+    r0 = 0
+    for s0 in range(0, nseg, limit):
+        rows = list(seg_rows[s0:s0 + limit])
+        for c0 in range(0, width, max(cstep, 1)):
+            cols = [max(min(c - c0, cstep), 0) for c in seg_cols[s0:s0 + limit]]
+            if sum(rows) > 0 and max(cols) > 0:
+                perm = None
+                if b_perm is not None:
+                    b0 = c0 // b_block_rows
+                    perm = list(b_perm[b0:b0 + limit])
+                yield r0, rows, c0, cols, perm
+        r0 += sum(rows)
+
+
 class HipPanelOps:
     """Tile operations on torch CUDA tensors through the C ABI (no CPU fallback)."""
 
@@ -62,6 +83,12 @@ class HipPanelOps:
         self.dev_side = type(dev)(dev.index)
         self.side = torch.cuda.Stream(device=device, priority=-1)
         self.dev_side.set_stream(self.side.cuda_stream)
+        # the bulk of every trailing update runs on a third, low-priority stream (as in the one-GPU sweep,
+        # g3_potrf.hip::potrf_lookahead): the panel solve, the next block column and the collectives of step
+        # k + 1 are issued on the caller's stream and overlap it
+        self.dev_bulk = type(dev)(dev.index)
+        self.bulk_s = torch.cuda.Stream(device=device, priority=0)
+        self.dev_bulk.set_stream(self.bulk_s.cuda_stream)
         self.info_dev = torch.zeros(1, dtype=torch.int32, device=device)
 
     def _chk(self, rc, what):
@@ -148,6 +175,35 @@ class HipPanelOps:
     def join_lookahead(self):
         self.torch.cuda.current_stream(self.device).wait_stream(self.side)
 
+    def bulk(self):
+        """context: work issued inside runs on the bulk stream, after everything queued so far on the caller's"""
+        import contextlib
+        torch, ops = self.torch, self
+
+        @contextlib.contextmanager
+        def cm():
+            ops.bulk_s.wait_stream(torch.cuda.current_stream(ops.device))
+            with torch.cuda.stream(ops.bulk_s):
+                prev, ops.dev = ops.dev, ops.dev_bulk
+                try:
+                    yield
+                finally:
+                    ops.dev = prev
+        return cm()
+
+    def mark(self):
+        """an event behind everything queued so far on the current stream"""
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait_event(self, ev):
+        if ev is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def join_bulk(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self.bulk_s)
+
     def trsm(self, L, nb, W, B, m):
         """B[m x nb] <- B L^-T"""
         if m > 0:
@@ -163,10 +219,20 @@ class HipPanelOps:
     def gemm_sub_stair(self, C_, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None):
         """stacked row segments of C: C[rows_s, :seg_cols[s]] -= A[rows_s, :k] B[:seg_cols[s], :k]^T in one launch;
         logical row block s of B (b_block_rows rows) is stored at block b_perm[s]"""
-        if sum(seg_rows) > 0 and max(seg_cols) > 0:
-            self.dev.gemm_nt_stair(C_.data_ptr(), C_.stride(0), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), k,
-                                   seg_rows, seg_cols, self.dtype, alpha=-1.0, beta=1.0,
-                                   b_block_rows=b_block_rows, b_perm=b_perm)
+        if sum(seg_rows) <= 0 or max(seg_cols) <= 0:
+            return
+        # one launch describes at most STAIR_MAX row segments and STAIR_MAX blocks of B (the raster table travels
+        # in the kernel arguments, g3_gemm.hip::RasterTab): longer staircases -- N / nb > 160 row blocks -- are
+        # cut into row chunks and column chunks, each its own launch on the same stream
+        es = C_.element_size()
+        for (r0, rows, c0, cols, perm) in stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, self.STAIR_MAX):
+            self.dev.gemm_nt_stair(C_.data_ptr() + (r0 * C_.stride(0) + c0) * es, C_.stride(0),
+                                   A.data_ptr() + r0 * A.stride(0) * es, A.stride(0),
+                                   B.data_ptr() + (0 if perm is not None else c0 * B.stride(0) * es), B.stride(0), k,
+                                   rows, cols, self.dtype, alpha=-1.0, beta=1.0, b_block_rows=b_block_rows, b_perm=perm)
+
+    import os as _os
+    STAIR_MAX = int(_os.environ.get('G3_STAIR_MAX', '160'))     # tests lower it to exercise the chunking
 
     def fill_zero(self, t):
         t.zero_()
@@ -245,8 +311,20 @@ class DistributedGP:
         # panel rows on their way out / gathered from every rank (double buffers: the gather of panel k+1 runs
         # under the update with panel k)
         self.send = [o.zeros(max(cmax, 1) * nb, nb), o.zeros(max(cmax, 1) * nb, nb)]
-        self.gath = [o.zeros(world * max(cmax, 1) * nb, nb), o.zeros(world * max(cmax, 1) * nb, nb)]
+        # three gather buffers: the bulk update with panel k (bulk stream) may still be reading its buffer
+        # while panel k + 2 is already being gathered
+        self.gath = [o.zeros(world * max(cmax, 1) * nb, nb) for _ in range(3)]
         self.last = {}
+        # G3_DIST_COLLECTIVES=1: do not short-circuit the collectives of a one-rank run -- every broadcast,
+        # all-gather and all-reduce then really passes through the process group (RCCL stream semantics and
+        # work handles exercised on the one GPU a development box has)
+        import os
+        self.use_coll = world > 1 or os.environ.get('G3_DIST_COLLECTIVES', '0') == '1'
+        # The diagonal-factor broadcast (critical path, <= 9 MiB) gets its OWN process group = its own RCCL
+        # communicator and stream: on one communicator it would queue behind the panel all-gather (up to
+        # 134 MB) issued just before it.  Both are issued in the same order on every rank.
+        self.g_bcast = dist.new_group(ranks=list(range(world))) if (self.use_coll and dist is not None) else None
+        self.comm = {k: {'calls': 0, 'bytes': 0, 'wait_s': 0.0} for k in ('bcast', 'allgather', 'allreduce')}
 
     def owner(self, I):
         """row blocks are dealt in boustrophedon order (0..P-1, P-1..0, ...): the trailing-update work
@@ -306,25 +384,38 @@ class DistributedGP:
                 if nv > 0:
                     o.diag_add(self._diag(I), nv, add)
 
+    def _count(self, kind, t, peers):
+        """bytes this rank moves over the fabric for one collective on tensor t (sent + received)"""
+        c = self.comm[kind]
+        c['calls'] += 1
+        c['bytes'] += int(t.numel() * t.element_size() * peers)
+
     def _allreduce(self, t, op='sum'):
         dist = self.dist
-        if self.world == 1:
+        if not self.use_coll:
             return t
+        import time
         opmap = {'sum': dist.ReduceOp.SUM, 'min': dist.ReduceOp.MIN, 'max': dist.ReduceOp.MAX}
         dev_t = t.to(self.A.device) if self.A.is_cuda else t
+        t0 = time.perf_counter()
         dist.all_reduce(dev_t, op=opmap[op])
-        return dev_t.cpu()
+        out = dev_t.cpu()
+        self.comm['allreduce']['wait_s'] += time.perf_counter() - t0
+        self._count('allreduce', dev_t, 2 * (self.world - 1) / max(self.world, 1))
+        return out
 
     def _bcast(self, t, src, async_op):
-        if self.world == 1:
+        if not self.use_coll:
             return None
-        return self.dist.broadcast(t, src=src, async_op=async_op)
+        self._count('bcast', t, 1 if self.world > 1 else 0)
+        return self.dist.broadcast(t, src=src, group=self.g_bcast, async_op=async_op)
 
     def _allgather(self, out, inp):
         """out (world * rows x nb) <- every rank's inp (rows x nb); asynchronous"""
-        if self.world == 1:
+        if not self.use_coll:
             out.copy_(inp)
             return None
+        self._count('allgather', inp, 2 * (self.world - 1))
         if hasattr(self.dist, 'all_gather_into_tensor'):
             try:
                 return self.dist.all_gather_into_tensor(out, inp, async_op=True)
@@ -333,10 +424,23 @@ class DistributedGP:
         chunks = list(out.view(self.world, inp.shape[0], inp.shape[1]).unbind(0))
         return self.dist.all_gather(chunks, inp, async_op=True)
 
-    @staticmethod
-    def _wait(work):
+    def _wait(self, work, kind=None):
+        """make the current stream wait for the collective (RCCL: a stream dependency, the host does not block;
+        gloo: the host blocks); the host time spent here is kept per kind"""
         if work is not None and hasattr(work, 'wait'):
+            import time
+            t0 = time.perf_counter()
             work.wait()
+            if kind:
+                self.comm[kind]['wait_s'] += time.perf_counter() - t0
+
+    def comm_stats(self):
+        """per-rank collective counts, bytes moved (sent + received over the fabric) and host seconds spent
+        waiting in them since the last call"""
+        out = {k: dict(v) for k, v in self.comm.items()}
+        for v in self.comm.values():
+            v.update(calls=0, bytes=0, wait_s=0.0)
+        return out
 
     # ---------------------------------------------------------------- factorisation + solves in one sweep
     def _factor_block(self, k):
@@ -359,75 +463,94 @@ class DistributedGP:
         if self.nblk - 1 - k <= 0:
             return None
         cnt, _ = self._perm(k)
-        send, gath = self.send[k % 2], self.gath[k % 2]
+        send, gath = self.send[k % 2], self.gath[k % 3]
         mine = self.rows_mat - r_lo
         if mine > 0:
             send[:mine].copy_(A[r_lo:self.rows_mat, c0:c1])
         return self._allgather(gath[:P * cnt * nb], send[:cnt * nb])
 
-    def _lookahead(self, j, panels):
-        """diagonal block j: its owner applies the updates of `panels` from its own panel rows, factors the block
-        and broadcasts factor + block inverses -- all on the look-ahead stream; the others post the receive"""
+    def _lookahead(self, j, ev):
+        """diagonal block j: its owner applies the update with panel j - 1 from its own panel rows (the
+        updates with the panels before it arrived with the bulk stream's column launches, event `ev`), factors
+        the block and broadcasts factor + block inverses -- all on the look-ahead stream; the others post the
+        receive"""
         o, nb = self.ops, self.nb
         if self.owner(j) != self.rank:
             return self._bcast(self.dbuf[j % 2], self.owner(j), async_op=True)
         with o.lookahead():
+            o.wait_event(ev)
             lo = self.loff[j]
-            for p in panels:
-                Pn = self.A[lo:lo + nb, p * nb:(p + 1) * nb]
-                o.gemm_sub(self.A[lo:lo + nb, j * nb:(j + 1) * nb], Pn, Pn, nb, nb, nb, lower_only=True)
+            Pn = self.A[lo:lo + nb, (j - 1) * nb:j * nb]
+            o.gemm_sub(self.A[lo:lo + nb, j * nb:(j + 1) * nb], Pn, Pn, nb, nb, nb, lower_only=True)
             self._factor_block(j)
             return self._bcast(self.dbuf[j % 2], self.owner(j), async_op=True)
 
     def factor(self, spec, spec_cross, X, Xs, delta, jitter=0.0):
         """returns the global potrf info (0 = success).
 
-        Software-pipelined over the row-block steps: while the trailing update with panel k runs, panel k+1 is
-        already solved and on its way through the all-gather, and diagonal block k+2 is factored and broadcast
-        on the look-ahead stream.  Step k:
-          a. update block column k+1 of everything I own below block k+1 with the gathered panel k;
-          b. solve panel k+1 (needs the broadcast factor L_{k+1,k+1}) and start its all-gather;
-          c. look-ahead: the owner of block k+2 applies panels k and k+1 to it from its own rows, factors it and
-             broadcasts it;
-          d. the rest of the update with panel k (block columns >= k+2 of the blocks >= k+3 and of the
-             right-hand-side rows) -- the bulk of the work, under which b's all-gather and c run.
+        Software-pipelined over the row-block steps on three streams, the schedule of the one-GPU sweep
+        (g3_potrf.hip::potrf_lookahead) with the collectives in it.  With G_k the gathered panel k, step k is
+
+          bulk stream   d1. block column k+2 of everything I own from block k+2 down (right-hand-side rows
+                            included) -= P_k G_k^T; its completion is event B_k
+                        d2. block columns >= k+3 of my blocks >= k+3 and of the right-hand-side rows: the
+                            bulk of the work, ONE staircase launch
+          caller's      a.  (after B_{k-1}) block column k+1 of my blocks >= k+2 -= P_k G_k^T
+          stream        b.  (after the broadcast of L_{k+1,k+1}) solve my rows of panel k+1, start their
+                            all-gather
+          look-ahead    c.  (after B_k) the owner of block k+2 applies panel k+1 to its diagonal block from
+          stream            its own rows, factors it and broadcasts it (on the broadcast's own communicator)
+
+        so while d2 of step k streams through the chip, a - c of step k+1 and the collectives run beside it.
         """
         o, nb, P, A = self.ops, self.nb, self.world, self.A
         self._build(spec, spec_cross, X, Xs, delta, jitter)
         o.reset_info()
         if self.owner(0) == self.rank:
             self._factor_block(0)
-        self._wait(self._bcast(self.dbuf[0], self.owner(0), async_op=False))
+        self._wait(self._bcast(self.dbuf[0], self.owner(0), async_op=False), 'bcast')
         work_g = self._solve_and_gather(0)
-        work_b = self._lookahead(1, [0]) if self.nblk > 1 else None
+        work_b = self._lookahead(1, None) if self.nblk > 1 else None
+        ev_prev = None                                   # B_{k-1}
+        rhs = [self.rows_rhs] if self.rows_rhs > 0 else []
         for k in range(self.nblk - 1):
-            c0, c1, c2 = k * nb, (k + 1) * nb, (k + 2) * nb
-            nbelow = self.nblk - 1 - k
+            c0, c1, c2, c3 = k * nb, (k + 1) * nb, (k + 2) * nb, (k + 3) * nb
             cnt, perm = self._perm(k)
-            self._wait(work_g)
-            G = self.gath[k % 2][:P * cnt * nb]
-            rhs = [self.rows_rhs] if self.rows_rhs > 0 else []
-            # a. block column k+1
+            self._wait(work_g, 'allgather')
+            G = self.gath[k % 3][:P * cnt * nb]
+            ev_k = None
+            with o.bulk():
+                if k + 2 < self.nblk:
+                    # d1. block column k+2 (block k+2's diagonal block included: the look-ahead adds panel k+1 only)
+                    mine = [I for I in self.my_blocks if I >= k + 2]
+                    seg_rows = [nb] * len(mine) + rhs
+                    if seg_rows:
+                        lo = self.loff[mine[0]] if mine else self.rows_mat
+                        o.gemm_sub_stair(A[lo:, c2:c3], A[lo:, c0:c1], G, nb, seg_rows, [nb] * len(seg_rows), nb, perm[1:2])
+                    ev_k = o.mark()
+                    # d2. the rest
+                    mine = [I for I in self.my_blocks if I >= k + 3]
+                    seg_rows = [nb] * len(mine) + rhs
+                    seg_cols = [(I - k - 2) * nb for I in mine] + ([(self.nblk - k - 3) * nb] if rhs else [])
+                    if seg_rows and max(seg_cols) > 0:
+                        lo = self.loff[mine[0]] if mine else self.rows_mat
+                        o.gemm_sub_stair(A[lo:, c3:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm[2:])
+            # a. block column k+1 (it carries the updates up to panel k-1 once B_{k-1} has fired)
+            o.wait_event(ev_prev)
             mine = [I for I in self.my_blocks if I >= k + 2]
             seg_rows = [nb] * len(mine) + rhs
             if seg_rows:
                 lo = self.loff[mine[0]] if mine else self.rows_mat
                 o.gemm_sub_stair(A[lo:, c1:c2], A[lo:, c0:c1], G, nb, seg_rows, [nb] * len(seg_rows), nb, perm[:1])
             # b. panel k+1
-            self._wait(work_b)
-            if P == 1:
+            self._wait(work_b, 'bcast')
+            if self.owner(k + 1) == self.rank:
                 o.join_lookahead()
             work_g = self._solve_and_gather(k + 1)
             # c. diagonal block k+2
-            work_b = self._lookahead(k + 2, [k, k + 1]) if k + 2 < self.nblk else None
-            # d. the rest of the update with panel k; block k+2 itself has nothing left here (its diagonal block
-            #    belongs to the look-ahead)
-            mine = [I for I in self.my_blocks if I >= k + 3]
-            seg_rows = [nb] * len(mine) + rhs
-            seg_cols = [(I - k - 1) * nb for I in mine] + ([(nbelow - 1) * nb] if rhs else [])
-            if seg_rows and max(seg_cols) > 0:
-                lo = self.loff[mine[0]] if mine else self.rows_mat
-                o.gemm_sub_stair(A[lo:, c2:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm[1:])
+            work_b = self._lookahead(k + 2, ev_k) if k + 2 < self.nblk else None
+            ev_prev = ev_k
+        o.join_bulk()
         o.join_lookahead()
         t = self._allreduce(self.torch.tensor([float(o.read_info())], dtype=self.torch.float64), 'max')
         return int(t[0])

@@ -125,6 +125,7 @@ class EllipticalProcess(StochasticProcess):
         st['delta_finite'] = bool(finite)
         c['stats'], c['which'] = st, which
         c['grad'] = None            # K^-1 / alpha pieces of th_dlogp belong to this factorisation
+        c['cross'] = None           # so does the last cross solve
         return st
 
     def _cross(self, c, values, space, noise, kernel=None):
@@ -133,13 +134,22 @@ class EllipticalProcess(StochasticProcess):
         S = self._x(space)
         M = S.shape[0]
         Mp = _lib.roundup(M, _lib.G3_RHS_PAD)
+        # predict() asks for mean, variance, quantiles ... one after the other (the reference compiles and runs one
+        # function per statistic, each with its own solves, elliptical.py:81-91): the N^2 M cross solve is shared
+        # between them while factor, right-hand side, space and kernel stay the same
+        kid = (bool(noise), id(kernel) if kernel is not None else None)
+        cc = c.get('cross')
+        if cc is not None and cc['kid'] == kid and cc['S'].shape == S.shape and np.array_equal(cc['S'], S):
+            return cc['out']
         Sd = dev.upload(S)
         V = dev.alloc(Mp, c['Np'], self.dtype)
         mu = dev.alloc(1, Mp, self.dtype)
         ss = dev.alloc(1, Mp, self.dtype)
         kern = kernel if kernel is not None else (self.f_kernel_noise if noise else self.f_kernel)
         dev.gp_cross(self._prog(kern, values, c['d']), Sd, M, c['Xd'], c['N'], c['d'], c['Kd'], c['Wd'], c['ad'], V, mu, ss)
-        return V, dev.download(mu, 1, M)[0], dev.download(ss, 1, M)[0], M, Mp
+        out = (V, dev.download(mu, 1, M)[0], dev.download(ss, 1, M)[0], M, Mp)
+        c['cross'] = dict(kid=kid, S=S.copy(), out=out)
+        return out
 
     def _prior_gram(self, values, space, noise, pad=False):
         """prior_kernel_space = tt_to_cov(K_noise(space)) / prior_kernel_f_space = K_f(space)

@@ -84,6 +84,19 @@ class NumpyPanelOps:
     def join_lookahead(self):
         pass
 
+    def bulk(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def mark(self):
+        return None
+
+    def wait_event(self, ev):
+        pass
+
+    def join_bulk(self):
+        pass
+
     def trsm(self, L, nb, W, B, m):
         # like the device kernels, everything after a failed pivot is skipped (the info flag)
         if m > 0 and not getattr(self, '_info', 0):
@@ -182,7 +195,8 @@ def worker(rank, world, port, N, d, M, nb, backend, use_gpu, spec_f, noise, out_
             prior = np.diag(orc.kernel_cov(spec_f, Xs))
             np.savez(out_path, logp=lp, mean=dgp.last['mean'], var=np.maximum(prior - dgp.last['ss'], 0),
                      tries=dgp.last['tries'], fallback=dgp.last['fallback'],
-                     draws=dgp.last['draws'] if draws else np.zeros(0))
+                     draws=dgp.last['draws'] if draws else np.zeros(0),
+                     comm_calls=sum(v['calls'] for v in dgp.comm_stats().values()))
     finally:
         dist.destroy_process_group()
 

@@ -100,3 +100,39 @@ def test_block_ranges_and_ownership():
     from g3py_amd.distributed import block_ranges
     assert block_ranges(640, 256) == [(0, 256), (256, 256), (512, 128)]
     assert block_ranges(128, 512) == [(0, 128)]
+
+
+@pytest.mark.parametrize('limit', [1, 2, 3, 160])
+def test_stair_chunks_cover_the_staircase_once(limit):
+    """a staircase with more row blocks than one launch can describe (N / nb > 160: ADVICE r2) is cut into
+    row / column chunks; applying the chunks equals applying the whole staircase, with and without a block table"""
+    from g3py_amd.distributed import stair_chunks
+    rng = np.random.default_rng(11)
+    nbr, k = 4, 3
+    seg_rows = [4, 4, 8, 4, 0, 4, 12]
+    seg_cols = [4, 8, 12, 16, 16, 24, 28]
+    nblk = max(seg_cols) // nbr
+    perm = list(rng.permutation(nblk + 2)[:nblk])
+    A = rng.standard_normal((sum(seg_rows), k))
+    Bl = rng.standard_normal((nblk * nbr, k))                      # logical order
+    Bp = np.zeros(((nblk + 2) * nbr, k))
+    for s_, p_ in enumerate(perm):
+        Bp[p_ * nbr:(p_ + 1) * nbr] = Bl[s_ * nbr:(s_ + 1) * nbr]
+    ref = np.zeros((sum(seg_rows), max(seg_cols)))
+    r = 0
+    for rows, cols in zip(seg_rows, seg_cols):
+        ref[r:r + rows, :cols] -= A[r:r + rows] @ Bl[:cols].T
+        r += rows
+    for table in (perm, None):
+        got = np.zeros_like(ref)
+        for (r0, rows, c0, cols, pm) in stair_chunks(seg_rows, seg_cols, nbr if table is not None else 0, table, limit):
+            assert len(rows) <= limit and (pm is None or len(pm) <= limit)
+            if pm is not None:
+                b = np.concatenate([Bp[q * nbr:(q + 1) * nbr] for q in pm])
+            else:
+                b = Bl[c0:]
+            rr = r0
+            for rws, cls in zip(rows, cols):
+                got[rr:rr + rws, c0:c0 + cls] -= A[rr:rr + rws] @ b[:cls].T
+                rr += rws
+        np.testing.assert_allclose(got, ref, atol=1e-13)

@@ -30,6 +30,49 @@ def test_hip_block_cyclic_matches_oracle(tmp_path, world, N, nb):
     np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
 
 
+def test_hip_one_rank_through_rccl(tmp_path, monkeypatch):
+    """G3_DIST_COLLECTIVES=1, backend nccl, world 1: every diagonal-factor broadcast (on its own communicator),
+    every panel all-gather (all_gather_into_tensor, asynchronous work handles waited on from two streams) and the
+    closing all-reduces really pass through ProcessGroupNCCL = RCCL instead of being short-circuited -- the
+    stream semantics of the 8-GPU run, exercised on the one GPU a development box has"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    monkeypatch.setenv('G3_DIST_COLLECTIVES', '1')
+    N, d, M, nb = 3000, 4, 200, 256
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(1, _free_port(), N, d, M, nb, 'nccl', True, spec_f, 0.1, out), nprocs=1, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    gp = orc.GP(spec_f, 0.1)
+    ref = gp.logp(X, y)
+    assert abs(float(r['logp']) - ref) <= 1e-10 * abs(ref)
+    np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-8)
+    np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
+    assert int(r['comm_calls']) > 3 * (N // nb)          # broadcasts + all-gathers + all-reduces were really issued
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_hip_staircase_longer_than_one_launch(tmp_path, monkeypatch, world):
+    """more row blocks than one staircase launch may describe (N / nb > 160; here the limit is
+    lowered to 3): the update is cut into row and column chunks, same result"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    monkeypatch.setenv('G3_STAIR_MAX', '3')
+    N, d, M, nb = 2300, 4, 300, 128
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(worker, args=(world, _free_port(), N, d, M, nb, 'gloo', True, spec_f, 0.1, out, False, 5), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    gp = orc.GP(spec_f, 0.1)
+    ref = gp.logp(X, y)
+    assert abs(float(r['logp']) - ref) <= 1e-9 * abs(ref)
+    np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
+    Z = np.random.default_rng(5).standard_normal((M, 5))
+    np.testing.assert_allclose(r['draws'], gp.sampler(Xs, X, y, rand=Z), atol=1e-7)
+
+
 @pytest.mark.parametrize('world', [1, 2])
 def test_hip_exhausted_jitter_falls_back(tmp_path, world):
     """indefinite matrix: the distributed driver installs the reference's 1e-10 * I fallback

@@ -289,3 +289,43 @@ def test_new_entry_points_reject_bad_arguments(dev):
     assert lib.g3_gram_rows(ctx, C.byref(prog), a.ptr, 100, 2, 2, 0, 128, 0, a.ptr, 64, 0) == -11                  # ldk < row0 + nrows
     assert lib.g3_gram_rows(ctx, C.byref(prog), a.ptr, 100, 2, 2, 0, 128, 0, a.ptr, 128, _lib.G3_GRAM_LOWER) == -12
     assert lib.g3_potrf_nowait(ctx, a.ptr, 128, 256, 0, a.ptr, None) == -7
+
+
+def test_device_close_is_idempotent_and_final():
+    """teardown contract (g3py_amd/device.py): close() twice is fine, DeviceArray.free() after it is a no-op,
+    every other call raises instead of touching a destroyed context; a second context is unaffected"""
+    import g3py_amd as g3
+    from g3py_amd._lib import G3Error
+    other = g3.Device(0)
+    d = g3.Device(0)
+    a = d.alloc(256, 256, np.float64, zero=True)
+    b = d.upload(np.arange(12.0).reshape(3, 4))
+    assert a.ptr and b.ptr
+    d.close()
+    assert d.ctx is None and a.ptr == 0 and b.ptr == 0      # owned buffers were released with the context
+    d.close()                                               # idempotent
+    a.free()                                                # no-op, no call into HIP
+    b.free()
+    for call in (lambda: d.sync(), lambda: d.alloc(8, 8, np.float64), lambda: d.upload(np.zeros((2, 2))),
+                 lambda: d.prof_reset()):
+        with pytest.raises((G3Error, Exception)):
+            call()
+    x = other.upload(np.eye(128))                           # the other context still works
+    assert other.potrf(x, 128) == 0
+    other.close()
+
+
+def test_interpreter_exit_without_explicit_close(tmp_path):
+    """a process that never calls close(): the atexit hook tears the contexts down while HIP is alive (the
+    round-1 exit-time SIGSEGV under a profiler); exit status 0, no fault"""
+    import subprocess
+    import sys
+    code = ("import numpy as np, g3py_amd as g3\n"
+            "d = g3.Device(0); e = g3.Device(0)\n"
+            "a = d.upload(np.eye(256) * 2.0); b = e.alloc(128, 128, np.float32, zero=True)\n"
+            "assert d.potrf(a, 256) == 0\n"
+            "print('done')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    assert 'done' in r.stdout
