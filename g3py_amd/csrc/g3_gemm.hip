@@ -34,6 +34,9 @@ constexpr int GROUP_M = 4;
 // (N = 16384: 36.2 -> 38.1 ms; 8192: 8.8 -> 9.2 ms), while the uncontended latency of a tiny product
 // barely moves (12.0 -> 11.6 us).  The kernel keeps the general NSTAGE loop.
 constexpr int STAGES = 2;
+#ifndef G3_GEMM_ORDER
+#define G3_GEMM_ORDER 1   // 1: fragment reads before the DMA issue in the K loop (0: the round-2 order, kept for A/B builds)
+#endif
 
 // ---- tile raster.  The host describes the ACTIVE tiles of a launch as a list of row groups (a few
 // consecutive row tiles each) with a column-tile count per group; the table travels by value in the
@@ -116,23 +119,24 @@ __device__ __forceinline__ void gemm_tile(T* C, int64_t ldc, const T* gA, int64_
   };
 
   const int frow = lane & 15, kq = lane >> 4, swz = (frow >> 1) & 7;
-  auto compute = [&](int buf, int s) {   // s = 0, 1: the two 8-deep halves of a K tile
+  // s = 0, 1: the two 8-deep halves of a K tile.  Fragment reads and MFMAs are separate steps so that the
+  // K loop can put the reads of a freshly published tile in front of the DMA issue for the next one
+  auto load_frags = [&](int buf, int s, chunk_t (&fa)[TM], chunk_t (&fb)[TN]) {
     const char* a = sA + buf * BM * ROWB + (wm + frow) * ROWB;
     const char* b = sB + buf * BN * ROWB + (wn + frow) * ROWB;
-    {
-      const int off = (((s * 4 + kq) ^ swz) << 4);
-      chunk_t fa[TM], fb[TN];
+    const int off = (((s * 4 + kq) ^ swz) << 4);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const chunk_t*>(a + i * 16 * ROWB + off);
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const chunk_t*>(a + i * 16 * ROWB + off);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const chunk_t*>(b + j * 16 * ROWB + off);
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const chunk_t*>(b + j * 16 * ROWB + off);
+  };
+  auto mfma_frags = [&](const chunk_t (&fa)[TM], const chunk_t (&fb)[TN]) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e)
+    for (int e = 0; e < EPC; ++e)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = M::mfma(fa[i][e], fb[j][e], acc[i][j]);
-    }
+        for (int j = 0; j < TN; ++j) acc[i][j] = M::mfma(fa[i][e], fb[j][e], acc[i][j]);
   };
 
   // NSTAGE LDS buffers, NSTAGE - 1 K tiles of DMA in flight.  The big tile is matrix-pipe bound
@@ -183,9 +187,19 @@ __device__ __forceinline__ void gemm_tile(T* C, int64_t ldc, const T* gA, int64_
     }
     __syncthreads();          // tile kt is published; everyone has finished tile kt - 1, whose buffer is refilled next
     const int nxt = kt + NSTAGE - 1;
+    chunk_t fa[TM], fb[TN];
+#if G3_GEMM_ORDER
+    // the first fragments are requested before the ~40 scalar / vector instructions that issue the next
+    // tile's DMA: the LDS round trip of the one hides under the address arithmetic of the other
+    load_frags(buf, 0, fa, fb);
     if (nxt < KT) stage(buf == 0 ? NSTAGE - 1 : buf - 1, nxt * BK);
-    compute(buf, 0);
-    compute(buf, 1);
+#else
+    if (nxt < KT) stage(buf == 0 ? NSTAGE - 1 : buf - 1, nxt * BK);
+    load_frags(buf, 0, fa, fb);
+#endif
+    mfma_frags(fa, fb);
+    load_frags(buf, 1, fa, fb);
+    mfma_frags(fa, fb);
     buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
   }
   __syncthreads();            // the epilogue re-uses the staging LDS

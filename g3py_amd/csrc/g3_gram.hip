@@ -23,6 +23,42 @@ __host__ __device__ __forceinline__ bool leaf_has_trig(int kind) {
   return kind == G3_K_COS || kind == G3_K_SIN || kind == G3_K_SM;
 }
 
+// exp(x) for the compile-time fast paths.  fp64: n = rint(x / ln 2), r = x - n ln 2 in two pieces (|r| <= ln2 / 2),
+// degree-13 Taylor polynomial of exp(r) (truncation 4e-18 relative), one v_ldexp_f64 -- about half the
+// instructions of the library routine, whose special-case handling the Gram does not need: NaN propagates,
+// arguments below -746 give 0 (through a correctly rounded subnormal range), above 709.78 +Inf.
+// Measured against the CPU oracle in tests/test_gpu_gram.py (<= 2 ulp).  fp32 keeps the library exp.
+#ifndef G3_FAST_EXP
+#define G3_FAST_EXP 1
+#endif
+__device__ __forceinline__ double g3_exp(double x) {
+#if G3_FAST_EXP
+  double xc = x < -746.0 ? -746.0 : x;        // (comparisons keep a NaN)
+  xc = xc > 746.0 ? 746.0 : xc;
+  const double n = __builtin_rint(xc * 1.44269504088896338700e+00);
+  double r = __builtin_fma(-n, 6.93147180369123816490e-01, xc);
+  r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;          // 1 / 13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);
+  p = __builtin_fma(p, r, 2.505210838544172e-08);
+  p = __builtin_fma(p, r, 2.755731922398589e-07);
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);
+  p = __builtin_fma(p, r, 2.48015873015873e-05);
+  p = __builtin_fma(p, r, 1.984126984126984e-04);
+  p = __builtin_fma(p, r, 1.3888888888888889e-03);
+  p = __builtin_fma(p, r, 8.333333333333333e-03);
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+#else
+  return exp(x);
+#endif
+}
+__device__ __forceinline__ float g3_exp(float x) { return exp(x); }
+
 template <typename T>
 __device__ __forceinline__ T leaf_eval(const g3_leaf& lf, const T* xi, const T* xj, bool diag_sym,
                                        bool sym, const T* ti, const T* tj) {
@@ -171,13 +207,18 @@ template <typename T, int D>
 struct SeParams {
   T w[D];   // ARD_L2 kinds: 0.5 * rate^2 ; OU (ARD_L1): rate
   T var, noise, alpha;
+  // optional second term  pvar * prod_k cos(2 pi freq_k dx_k)  (COS, kernels.py:466-467): f = 2 pi freq
+  T f[D];
+  T pvar;
 };
 
 // One workgroup (256 threads) writes a 64-row x 128-column tile; a thread owns two adjacent
 // columns (one 16-byte store per row for fp64: a wave writes 1 KiB of one row per instruction)
 // and every fourth row.
 #define GTN 128
-template <typename T, int D, int FK>   // FK: g3_kind of the fast path, -1 = generic program
+// FK: g3_kind of the fast path's stationary term, -1 = generic program; PK: g3_kind of its periodic second term
+// (G3_K_COS) or -1.  The sum  stationary + periodic (+ noise)  is the shape of BASELINE config 3's kernel.
+template <typename T, int D, int FK, int PK = -1>
 __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
             int64_t n1, int64_t ldx1, const T* __restrict__ X2, int64_t n2, int64_t ldx2, int d,
@@ -245,6 +286,17 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
       trig_s[pnt * tstride + 2 * t + 1] = sn;
     }
   }
+  constexpr int FTS = 2 * D + 1;        // fast path: [cos, sin] of 2 pi freq_k x_k per point, odd row stride
+  if constexpr (SE_FAST && PK >= 0) {
+    __syncthreads();
+    for (int e = tid; e < (GT + GTN) * D; e += 256) {
+      const int pnt = e / D, k = e - pnt * D;
+      const T x = pnt < GT ? xi_s[pnt * dp + k] : xj_s[(pnt - GT) * dp + k];
+      const T th = se.f[k] * x;
+      trig_s[pnt * FTS + 2 * k] = cos(th);
+      trig_s[pnt * FTS + 2 * k + 1] = sin(th);
+    }
+  }
   __syncthreads();
   const int tx = tid & 63, ty = tid >> 6;  // column pair within tile, row phase
   const int64_t ja = j0 + 2 * tx;
@@ -253,9 +305,18 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
   const T* xja = xj_s + (2 * tx) * dp;
   const T* xjb = xja + dp;
   T xra[D], xrb[D];
+  T cja[D], sja[D], cjb[D], sjb[D];
   if (SE_FAST) {
 #pragma unroll
     for (int c = 0; c < D; ++c) { xra[c] = xja[c]; xrb[c] = xjb[c]; }
+    if constexpr (PK >= 0) {
+      const T* ta = trig_s + (GT + 2 * tx) * FTS;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        cja[c] = ta[2 * c]; sja[c] = ta[2 * c + 1];
+        cjb[c] = ta[FTS + 2 * c]; sjb[c] = ta[FTS + 2 * c + 1];
+      }
+    }
   }
   const bool scr = (flags & G3_GRAM_SCRUB) != 0;
   const bool eye = (flags & G3_GRAM_PAD_EYE) != 0;
@@ -282,16 +343,24 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
           T kv;
           if constexpr (FK == G3_K_MAT32) {
             const T s3 = sqrt(T(3) * dd);
-            kv = (T(1) + s3) * exp(-s3);
+            kv = (T(1) + s3) * g3_exp(-s3);
           } else if constexpr (FK == G3_K_MAT52) {
             const T s5 = sqrt(T(5) * dd);
-            kv = (T(1) + s5 + T(5) * dd / T(3)) * exp(-s5);
+            kv = (T(1) + s5 + dd * T(5.0 / 3.0)) * g3_exp(-s5);
           } else if constexpr (FK == G3_K_RQ) {
             kv = pow(T(1) + dd / se.alpha, -se.alpha);
           } else {
-            kv = exp(-dd);
+            kv = g3_exp(-dd);
           }
           v[q] = se.var * kv;
+          if constexpr (PK == G3_K_COS) {
+            const T* ti = trig_s + rr * FTS;
+            T pr = T(1);
+#pragma unroll
+            for (int c = 0; c < D; ++c)   // cos(theta_i - theta_j), angle-difference identity (as the generic path)
+              pr *= ti[2 * c] * (q ? cjb[c] : cja[c]) + ti[2 * c + 1] * (q ? sjb[c] : sja[c]);
+            v[q] += se.pvar * pr;
+          }
           if (dg) v[q] += se.noise;
         } else {
           if (ntrig > 0)
@@ -384,19 +453,23 @@ static dim3 gram_grid(int64_t n1pad, int64_t n2pad, unsigned flags) {
 // row offset of the block being built by g3_gram_rows (0 for every other entry point)
 static inline int64_t ctx_diag_off(const g3_ctx* ctx) { return ctx->gram_diag_off; }
 
-// recognise  var*SE(x[:, 0:d]) (+ Noise)  so the common case takes the register fast path
+// recognise  var * k(x[:, 0:d]) [+ pvar * COS(x[:, 0:d])] [+ Noise]  so the common cases take the register fast
+// path.  Returns the stationary leaf's kind (-1: no match) and the periodic term's kind in *pk (-1: none)
 template <typename T, int D>
-static int match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
-  // returns the leaf kind of a `var * k(x[:, 0..d)) [+ noise]` program, or -1
-  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 2) return -1;
-  int se = -1, noise = -1;
+static int match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out, int* pk) {
+  *pk = -1;
+  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 3) return -1;
+  int se = -1, noise = -1, per = -1;
   for (int q = 0; q < p->nprod; ++q) {
     if (p->prod[q].nfac != 1) return -1;
+    // (coef * var) applied once; identical to var * k only when coef == 1 (the un-scaled kernel)
+    if (p->prod[q].coef != 1.0) return -1;
     const g3_leaf& lf = p->leaf[p->prod[q].fac[0]];
     const bool stat = lf.kind == G3_K_SE || lf.kind == G3_K_OU || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52 ||
                       lf.kind == G3_K_RQ;
     if (stat && se < 0) se = q;
     else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
+    else if (lf.kind == G3_K_COS && per < 0) per = q;
     else return -1;
   }
   if (se < 0) return -1;
@@ -405,35 +478,55 @@ static int match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out) {
   for (int k = 0; k < D; ++k) {
     if (lf.dims[k] != k) return -1;
     out->w[k] = lf.kind == G3_K_OU ? (T)lf.rate[k] : (T)(0.5 * lf.rate[k] * lf.rate[k]);
+    out->f[k] = T(0);
   }
-  // (coef * var) applied once; identical to var*k when coef == 1 (the un-scaled kernel)
-  if (p->prod[se].coef != 1.0) return -1;
   out->var = (T)lf.var;
   out->alpha = (T)lf.alpha;
   out->noise = T(0);
-  if (noise >= 0) {
-    if (p->prod[noise].coef != 1.0) return -1;
-    out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
+  out->pvar = T(0);
+  if (noise >= 0) out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
+  if (per >= 0) {
+    const g3_leaf& pl = p->leaf[p->prod[per].fac[0]];
+    // instantiated for the stationary kinds and widths below (compile time); everything else is interpreted
+    const bool have = (lf.kind == G3_K_SE || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52) &&
+                      (D == 1 || D == 2 || D == 4 || D == 8);
+    if (!have || pl.ndims != D) return -1;
+    for (int k = 0; k < D; ++k) {
+      if (pl.dims[k] != k) return -1;
+      out->f[k] = T(2 * G3_PI) * (T)pl.freq[k];     // the generic path's  (2 pi * freq) * x
+    }
+    out->pvar = (T)pl.var;
+    *pk = G3_K_COS;
   }
   return lf.kind;
 }
 
 template <typename T, int D>
-static int launch_gram_fast(g3_ctx* ctx, int kind, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
+static int launch_gram_fast(g3_ctx* ctx, int kind, int pk, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
                             const T* X2, int64_t n2, int64_t ldx2, T* K, int64_t ldk, int64_t n1pad,
                             int64_t n2pad, unsigned flags, int sym) {
   dim3 grid = gram_grid(n1pad, n2pad, flags);
-  const size_t lds = (GT + GTN) * (D | 1) * sizeof(T);
-#define G3_GRAM_FAST_LAUNCH(KIND)                                                                              \
-  hipLaunchKernelGGL((gram_kernel<T, D, KIND>), grid, dim3(256), lds, ctx->stream, (const g3_kernel_prog*)nullptr, \
+  const size_t lds = (GT + GTN) * ((D | 1) + (pk >= 0 ? 2 * D + 1 : 0)) * sizeof(T);
+#define G3_GRAM_FAST_LAUNCH(KIND, PKIND)                                                                            \
+  hipLaunchKernelGGL((gram_kernel<T, D, KIND, PKIND>), grid, dim3(256), lds, ctx->stream, (const g3_kernel_prog*)nullptr, \
                      se, X1, n1, ldx1, X2, n2, ldx2, D, K, ldk, n1pad, n2pad, flags, sym, 0, (int64_t)0,           \
                      ctx_diag_off(ctx))
-  switch (kind) {
-    case G3_K_SE: G3_GRAM_FAST_LAUNCH(G3_K_SE); break;
-    case G3_K_OU: G3_GRAM_FAST_LAUNCH(G3_K_OU); break;
-    case G3_K_MAT32: G3_GRAM_FAST_LAUNCH(G3_K_MAT32); break;
-    case G3_K_MAT52: G3_GRAM_FAST_LAUNCH(G3_K_MAT52); break;
-    default: G3_GRAM_FAST_LAUNCH(G3_K_RQ); break;
+  if (pk >= 0) {
+    if constexpr (D == 1 || D == 2 || D == 4 || D == 8) {
+      switch (kind) {
+        case G3_K_SE: G3_GRAM_FAST_LAUNCH(G3_K_SE, G3_K_COS); break;
+        case G3_K_MAT32: G3_GRAM_FAST_LAUNCH(G3_K_MAT32, G3_K_COS); break;
+        default: G3_GRAM_FAST_LAUNCH(G3_K_MAT52, G3_K_COS); break;
+      }
+    }
+  } else {
+    switch (kind) {
+      case G3_K_SE: G3_GRAM_FAST_LAUNCH(G3_K_SE, -1); break;
+      case G3_K_OU: G3_GRAM_FAST_LAUNCH(G3_K_OU, -1); break;
+      case G3_K_MAT32: G3_GRAM_FAST_LAUNCH(G3_K_MAT32, -1); break;
+      case G3_K_MAT52: G3_GRAM_FAST_LAUNCH(G3_K_MAT52, -1); break;
+      default: G3_GRAM_FAST_LAUNCH(G3_K_RQ, -1); break;
+    }
   }
 #undef G3_GRAM_FAST_LAUNCH
   G3_LAUNCH_CHECK();
@@ -445,14 +538,20 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
                   const T* X2, int64_t n2, int64_t ldx2, int d, T* K, int64_t ldk, int64_t n1pad,
                   int64_t n2pad, unsigned flags, int sym) {
   {
-    int fk;
+    static int nofast = -1;      // G3_GRAM_NOFAST=1: always interpret (development comparison)
+    if (nofast < 0) { const char* e = getenv("G3_GRAM_NOFAST"); nofast = (e && atoi(e)) ? 1 : 0; }
+    int fk, pk;
     SeParams<T, 1> s1; SeParams<T, 2> s2; SeParams<T, 3> s3; SeParams<T, 4> s4; SeParams<T, 8> s8; SeParams<T, 16> s16;
-    if ((fk = match_fast<T, 1>(prog, d, &s1)) >= 0) return launch_gram_fast<T, 1>(ctx, fk, s1, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if ((fk = match_fast<T, 2>(prog, d, &s2)) >= 0) return launch_gram_fast<T, 2>(ctx, fk, s2, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if ((fk = match_fast<T, 3>(prog, d, &s3)) >= 0) return launch_gram_fast<T, 3>(ctx, fk, s3, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if ((fk = match_fast<T, 4>(prog, d, &s4)) >= 0) return launch_gram_fast<T, 4>(ctx, fk, s4, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if ((fk = match_fast<T, 8>(prog, d, &s8)) >= 0) return launch_gram_fast<T, 8>(ctx, fk, s8, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
-    if ((fk = match_fast<T, 16>(prog, d, &s16)) >= 0) return launch_gram_fast<T, 16>(ctx, fk, s16, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym);
+#define G3_TRY_FAST(DD, SS)                                                                                   \
+    if (!nofast && (fk = match_fast<T, DD>(prog, d, &SS, &pk)) >= 0)                                          \
+      return launch_gram_fast<T, DD>(ctx, fk, pk, SS, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym)
+    G3_TRY_FAST(1, s1);
+    G3_TRY_FAST(2, s2);
+    G3_TRY_FAST(3, s3);
+    G3_TRY_FAST(4, s4);
+    G3_TRY_FAST(8, s8);
+    G3_TRY_FAST(16, s16);
+#undef G3_TRY_FAST
   }
   const g3_kernel_prog* dprog;
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
@@ -469,7 +568,7 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   if (ntrig > 16 || direct) ntrig = 0;
   const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
   SeParams<T, 1> dummy{};
-  hipLaunchKernelGGL((gram_kernel<T, 1, -1>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
+  hipLaunchKernelGGL((gram_kernel<T, 1, -1, -1>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,
                      ldx1, X2, n2, ldx2, d, K, ldk, n1pad, n2pad, flags, sym, ntrig, (int64_t)0, ctx_diag_off(ctx));
   G3_LAUNCH_CHECK();
   return G3_OK;
@@ -487,13 +586,13 @@ int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_
   if (dt == G3_F64) {
     const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(double);
     SeParams<double, 1> dummy{};
-    hipLaunchKernelGGL((gram_kernel<double, 1, -1>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
+    hipLaunchKernelGGL((gram_kernel<double, 1, -1, -1>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
                        (const double*)X, n, ldx, (const double*)X, n, ldx, d, (double*)K, ldk, npad, npad, flags, 1,
                        ntrig, kstride, (int64_t)0);
   } else {
     const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(float);
     SeParams<float, 1> dummy{};
-    hipLaunchKernelGGL((gram_kernel<float, 1, -1>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
+    hipLaunchKernelGGL((gram_kernel<float, 1, -1, -1>), grid, dim3(256), lds, ctx->stream, dprogs, dummy,
                        (const float*)X, n, ldx, (const float*)X, n, ldx, d, (float*)K, ldk, npad, npad, flags, 1,
                        ntrig, kstride, (int64_t)0);
   }

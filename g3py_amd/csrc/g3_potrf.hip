@@ -13,6 +13,7 @@
 // flat right-looking sweep over panels with one-panel look-ahead on two streams.
 #include "g3_internal.h"
 #include <vector>
+#include "g3_host.h"
 #include "g3_mfma.h"
 #include <stdlib.h>
 
@@ -829,103 +830,113 @@ int g3i_ensure_work(g3_ctx* ctx, size_t bytes) {
   return G3_OK;
 }
 
-// ---- flat right-looking sweep over NB-wide panels with one-panel look-ahead.
-// Stream A (the context's stream) carries the critical path: for panel k+1 the update of its
-// own block column (U^a), the recursive factorisation of its diagonal block and its panel
-// solve.  Stream B (low priority) carries the bulk trailing update with panel k (U^b), so the
-// latency-bound panel work of k+1 overlaps the throughput-bound update of k.  U^b(k) is two
-// launches: block column k+2 first (its completion event is what stream A waits for before
-// it touches that column), then the rest.
+// ---- flat right-looking sweep over NB-wide panels, grouped into super-panels of G panels, with one
+// super-panel of look-ahead on two streams.
+//
+// The chain (stream A, the context's stream) factors panel after panel; WITHIN a super-panel a finished
+// panel is applied at once to the remaining columns of its super-panel only (U_in, K = NB).  Everything to
+// the right of the super-panel receives the update of all G panels together, K = G * NB, on the bulk
+// stream B (low priority): the dominant launches of the factorisation run at twice / four times the K of the
+// chain's granularity -- fewer read-modify-write passes over C per flop and half / a quarter as many
+// launches -- while the chain keeps the narrow panels that make it short.  G = 1 is the plain
+// look-ahead sweep of rounds 1-2.  Per super-panel s (columns [c0, c1), panels g0 .. g1-1):
+//
+//   A:  wait B2a(s-1) . Ua(s-1): first panel column of s  -= S_{s-1} S_{s-1}^T   (K of super-panel s-1)
+//       panel(g0) . [wait B1(s-1)] . U_in(g0) . panel(g0+1) . U_in(g0+1) ...      -> event G(s)
+//   B:  wait G(s) . P1(s):  the other columns of super-panel s+1               -> event B1(s)
+//                   P2a(s): first panel column of super-panel s+2               -> event B2a(s)
+//                   P2b(s): everything to the right of that                     (the bulk)
+//
+// so the chain of super-panel s+1 runs beside P2b(s) (and P2b(s-1) while it lasts).  The appended E
+// right-hand-side rows are simply more rows of every update and panel solve.
 template <typename T>
-static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t NB, g3_dtype dt, int64_t E) {
+static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t NB, int G, g3_dtype dt, int64_t E) {
   const int64_t R = n + E;   // rows: the square part plus E appended right-hand-side rows
-  // panel boundaries: NB-wide panels while the trailing matrix is large, narrower ones near the
-  // end, where the bulk stream runs out of work and the latency of the critical-path chain
-  // (diagonal-block kernels, small GEMMs) is what is left -- narrow panels shorten that chain
-  // exactly as they do for a small stand-alone problem (G3_NB_TAIL=0 keeps NB throughout)
   std::vector<int64_t> bnd;
-  {
-    static int taper = -1;
-    if (taper < 0) {
-      const char* e = getenv("G3_NB_TAIL");
-      taper = e ? atoi(e) : 10;   // halve the width while the remaining size is <= taper * width
-    }
-    int64_t r0 = 0;
-    while (r0 < n) {
-      int64_t w = NB;
-      if (taper) {
-        const int64_t rem = n - r0;
-        static int wmin = -1;
-        if (wmin < 0) { const char* e = getenv("G3_NB_MIN"); wmin = e ? atoi(e) : 128; }
-        const int64_t wlo = ctx->batch > 1 && wmin < 256 ? 256 : wmin;   // batched sweeps: work per launch matters more
-        while (w > wlo && rem <= (int64_t)taper * w) w /= 2;
-      }
-      w = g3_roundup(w, LB);
-      bnd.push_back(r0);
-      r0 += w;
-    }
-    bnd.push_back(n);
-  }
-  const int nblk = (int)bnd.size() - 1;
-  if (ctx->la_nev < 2 * nblk) {
+  std::vector<int> gb;
+  g3h_panel_bounds(n, NB, G, ctx->batch, &bnd, &gb);
+  const int nblk = (int)bnd.size() - 1, ngrp = (int)gb.size() - 1;
+  const int nev = 4 * ngrp + 1;
+  if (ctx->la_nev < nev) {
     if (ctx->la_ev) {
       for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
       free(ctx->la_ev);
     }
-    ctx->la_nev = 2 * nblk;
+    ctx->la_nev = nev;
     ctx->la_ev = (hipEvent_t*)calloc(ctx->la_nev, sizeof(hipEvent_t));
     if (!ctx->la_ev) return G3_ERR_NOMEM;
     for (int i = 0; i < ctx->la_nev; ++i) G3_HIP(hipEventCreateWithFlags(&ctx->la_ev[i], hipEventDisableTiming));
   }
-  hipEvent_t* evP = ctx->la_ev;           // panel k final (stream A)
-  hipEvent_t* evB = ctx->la_ev + nblk;    // block column k+2 carries the update with panel k (stream B)
+  hipEvent_t* evG = ctx->la_ev;                // super-panel s final (stream A)
+  hipEvent_t* evB1 = ctx->la_ev + ngrp;        // P1(s) done (stream B)
+  hipEvent_t* evB2a = ctx->la_ev + 2 * ngrp;   // P2a(s) done (stream B)
+  hipEvent_t evJoin = ctx->la_ev[4 * ngrp];
   hipStream_t sA = ctx->stream, sB = ctx->side_stream;
-  auto r = [&](int k) { return k < nblk ? bnd[k] : n; };
-  auto nbk = [&](int k) { return r(k + 1) - r(k); };
+  auto r = [&](int k) { return k < nblk ? bnd[k] : n; };                 // first column of panel k
+  auto c = [&](int s) { return s < ngrp ? bnd[gb[s]] : n; };             // first column of super-panel s
   int rc = G3_OK;
   // B must not start before everything already queued on A (Gram, memsets) is done
-  G3_HIP(hipEventRecord(evB[nblk - 1], sA));
-  G3_HIP(hipStreamWaitEvent(sB, evB[nblk - 1], 0));
+  G3_HIP(hipEventRecord(evJoin, sA));
+  G3_HIP(hipStreamWaitEvent(sB, evJoin, 0));
   auto panel = [&](int k) -> int {   // D_k and P_k on stream A
     T* Akk = A + r(k) * ld + r(k);
-    int e = potrf_rec<T>(ctx, Akk, nbk(k), ld, W + (r(k) / LB) * LB * LB, r(k), dt);
+    const int64_t w = r(k + 1) - r(k);
+    int e = potrf_rec<T>(ctx, Akk, w, ld, W + (r(k) / LB) * LB * LB, r(k), dt);
     if (e) return e;
-    if (r(k + 1) < R) e = trsm_rec<T>(ctx, Akk, nbk(k), ld, A + r(k + 1) * ld + r(k), R - r(k + 1), ld,
+    if (r(k + 1) < R) e = trsm_rec<T>(ctx, Akk, w, ld, A + r(k + 1) * ld + r(k), R - r(k + 1), ld,
                                       W + (r(k) / LB) * LB * LB, dt);
     return e;
   };
-  rc = panel(0);
-  if (rc) return rc;
-  G3_HIP(hipEventRecord(evP[0], sA));
-  for (int k = 0; k + 1 < nblk; ++k) {
-    const int64_t r0 = r(k), r1 = r(k + 1), r2 = r(k + 2), r3 = r(k + 3), kk = nbk(k);
-    // stream B: bulk update with panel k
-    G3_HIP(hipStreamWaitEvent(sB, evP[k], 0));
-    ctx->stream = sB;
-    if (r2 < n) {
-      rc = g3i_gemm_nt(ctx, A + r2 * ld + r2, ld, A + r2 * ld + r0, ld, A + r2 * ld + r0, ld, R - r2, r3 - r2, kk,
-                       -1.0, 1.0, dt, 1);
-      if (!rc && hipEventRecord(evB[k], sB) != hipSuccess) rc = G3_ERR_HIP;
-      if (!rc && r3 < n)
-        rc = g3i_gemm_nt(ctx, A + r3 * ld + r3, ld, A + r3 * ld + r0, ld, A + r3 * ld + r0, ld, R - r3, n - r3, kk,
-                         -1.0, 1.0, dt, 1);
-    } else if (hipEventRecord(evB[k], sB) != hipSuccess) {
-      rc = G3_ERR_HIP;
+  // C[rows >= row0, cols [col0, col1)] -= A[rows, [k0, k1)] A[[col0, col1), [k0, k1)]^T, lower trapezoid
+  // (col <= row; the block starts on the diagonal when row0 == col0)
+  auto update = [&](int64_t row0, int64_t col0, int64_t col1, int64_t k0, int64_t k1) -> int {
+    if (col1 <= col0 || row0 >= R || k1 <= k0) return G3_OK;
+    return g3i_gemm_nt_trap(ctx, A + row0 * ld + col0, ld, A + row0 * ld + k0, ld, A + col0 * ld + k0, ld, R - row0,
+                            col1 - col0, k1 - k0, -1.0, 1.0, dt, row0 - col0);
+  };
+  for (int s = 0; s < ngrp; ++s) {
+    const int g0 = gb[s], g1 = gb[s + 1];
+    // ---- stream A: the chain of super-panel s
+    if (s >= 1) {
+      if (s >= 2) G3_HIP(hipStreamWaitEvent(sA, evB2a[s - 2], 0));
+      rc = update(r(g0), r(g0), r(g0 + 1), c(s - 1), c(s));          // Ua(s-1)
+      if (rc) return rc;
     }
-    ctx->stream = sA;
-    if (rc) return rc;
-    // stream A: look-ahead on block column k+1
-    if (k >= 1) G3_HIP(hipStreamWaitEvent(sA, evB[k - 1], 0));
-    rc = g3i_gemm_nt(ctx, A + r1 * ld + r1, ld, A + r1 * ld + r0, ld, A + r1 * ld + r0, ld, R - r1, r2 - r1, kk,
-                     -1.0, 1.0, dt, 1);
-    if (rc) return rc;
-    rc = panel(k + 1);
-    if (rc) return rc;
-    G3_HIP(hipEventRecord(evP[k + 1], sA));
+    for (int j = g0; j < g1; ++j) {
+      rc = panel(j);
+      if (rc) return rc;
+      if (j + 1 < g1) {
+        if (j == g0 && s >= 1) G3_HIP(hipStreamWaitEvent(sA, evB1[s - 1], 0));
+        // U_in(j): the rest of this super-panel.  The next panel's column first (it is all the chain
+        // needs to go on), the columns behind it in a second launch
+        rc = update(r(j + 1), r(j + 1), r(j + 2), r(j), r(j + 1));
+        if (!rc && j + 2 < g1) rc = update(r(j + 2), r(j + 2), c(s + 1), r(j), r(j + 1));
+        if (rc) return rc;
+      }
+    }
+    G3_HIP(hipEventRecord(evG[s], sA));
+    // ---- stream B: the update with super-panel s of everything to its right
+    if (c(s + 1) < n) {
+      G3_HIP(hipStreamWaitEvent(sB, evG[s], 0));
+      ctx->stream = sB;
+      const int h0 = gb[s + 1];                                       // first panel of super-panel s+1
+      rc = update(r(h0 + 1), r(h0 + 1), c(s + 2), c(s), c(s + 1));    // P1(s)
+      if (!rc && hipEventRecord(evB1[s], sB) != hipSuccess) rc = G3_ERR_HIP;
+      if (!rc && c(s + 2) < n) {
+        const int q0 = gb[s + 2];
+        rc = update(c(s + 2), c(s + 2), r(q0 + 1), c(s), c(s + 1));   // P2a(s)
+        if (!rc && hipEventRecord(evB2a[s], sB) != hipSuccess) rc = G3_ERR_HIP;
+        if (!rc) rc = update(r(q0 + 1), r(q0 + 1), n, c(s), c(s + 1));   // P2b(s)
+      } else if (!rc && hipEventRecord(evB2a[s], sB) != hipSuccess) {
+        rc = G3_ERR_HIP;
+      }
+      ctx->stream = sA;
+      if (rc) return rc;
+    }
   }
   // join: A continues only after B has drained
-  G3_HIP(hipEventRecord(evB[nblk - 1], sB));
-  G3_HIP(hipStreamWaitEvent(sA, evB[nblk - 1], 0));
+  G3_HIP(hipEventRecord(evJoin, sB));
+  G3_HIP(hipStreamWaitEvent(sA, evJoin, 0));
   return G3_OK;
 }
 
@@ -933,8 +944,10 @@ int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* in
   return g3i_potrf_tall(ctx, A, n, ld, dt, invd, 0);
 }
 
-static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n) {
+static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n, int* G) {
   int64_t NB = ctx->nb_lookahead;
+  const char* eg = getenv("G3_SB");          // panels per super-panel (development override)
+  *G = eg ? atoi(eg) : 1;
   if (NB <= 0) {
     const char* e = getenv("G3_NB");
     // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
@@ -943,6 +956,8 @@ static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n) {
     // a batched sweep is bound by work per launch, not by the chain: wider panels again
     if (!e && ctx->batch > 1 && NB < 256) NB = 256;
   }
+  if (*G < 1) *G = 1;
+  if (*G > 8) *G = 8;
   return g3_roundup(NB < LB ? LB : NB, LB);
 }
 
@@ -959,10 +974,11 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
   // 95.0 ms, 32768: equal), so it is always used.
   ctx->fuse256 = true;
 
-  int64_t NB = g3i_panel_width(ctx, n);
+  int G = 1;
+  int64_t NB = g3i_panel_width(ctx, n, &G);
   if (n >= 3 * NB) {
-    if (dt == G3_F64) return potrf_lookahead<double>(ctx, (double*)A, n, ld, (double*)invd, NB, dt, E);
-    return potrf_lookahead<float>(ctx, (float*)A, n, ld, (float*)invd, NB, dt, E);
+    if (dt == G3_F64) return potrf_lookahead<double>(ctx, (double*)A, n, ld, (double*)invd, NB, G, dt, E);
+    return potrf_lookahead<float>(ctx, (float*)A, n, ld, (float*)invd, NB, G, dt, E);
   }
   int rc;
   if (dt == G3_F64) rc = potrf_rec<double>(ctx, (double*)A, n, ld, (double*)invd, 0, dt);

@@ -194,3 +194,58 @@ def test_gram_grad_many_slots_and_ragged(dev):
         assert abs(out[slot] - want) < 1e-10 * scale
     out2 = dev.gram_grad(prog, gmap, dev.upload(X), N, d, dev.upload(np.tril(G)), dev.upload(alpha))
     assert np.array_equal(out, out2)              # fixed-order reduction: bitwise reproducible
+
+
+@pytest.mark.parametrize('d', [1, 2, 4, 8])
+@pytest.mark.parametrize('stat', ['SE', 'MAT32', 'MAT52'])
+@pytest.mark.parametrize('noise', [None, 0.1])
+def test_gram_fast_path_stationary_plus_periodic(dev, d, stat, noise):
+    """round 3: compile-time Gram variants for  stationary + COS (+ noise)  -- the shape of BASELINE config 3's
+    kernel (kernels.py:406-426, 466-467; sum: 240-241; noise on the square diagonal only: 367-371) -- against the
+    live oracle, square and cross, at ragged sizes"""
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(100 * d + len(stat))
+    n, m = 197, 75
+    X = rng.uniform(0, n ** (1.0 / d), (n, d))
+    Xs = rng.uniform(0, n ** (1.0 / d), (m, d))
+    rate = rng.uniform(0.5, 1.5, d)
+    freq = rng.uniform(0.05, 0.4, d)
+    spec = ('sum', (stat, 1.3, rate, None), ('COS', 0.5, freq, None))
+    if noise is not None:
+        spec = orc.with_noise(spec, noise)
+    ref = orc.kernel_cov(spec, X)
+    got = _gram(dev, spec, X)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+    got = _gram(dev, spec, Xs, X)
+    np.testing.assert_allclose(got, orc.kernel_cov(spec, Xs, X), rtol=1e-12, atol=1e-13)     # cross: no noise term
+
+
+def test_fast_exp_accuracy_and_range(dev):
+    """the fast paths' own fp64 exp (range reduction + degree-13 polynomial + ldexp) against NumPy's over the whole
+    range an SE / Matern exponent can take: <= 4 ulp down to the subnormal range, exact zeros below it, NaN / Inf
+    inputs scrubbed exactly as tt_to_num prescribes (tensors.py:90-92)"""
+    import g3py_amd._lib as lib
+    from oracle import g3_oracle as orc
+    n = 4096
+    # d = 1, rate = sqrt(2): D_ij = (x_i - x_j)^2; x_j = 0 for the first column
+    t = np.concatenate([np.linspace(0, 27.4, n - 8), [26.0, 27.2, 27.29, 27.3, 27.31, 27.5, 30.0, 40.0]])
+    X = t[:, None].copy()
+    spec = ('SE', 1.0, np.array([np.sqrt(2.0)]), None)
+    got = _gram(dev, spec, X)[:, 0]
+    w = 0.5 * np.sqrt(2.0) ** 2
+    ref = np.exp(-(t * t) * w)
+    big = ref > 1e-300
+    rel = np.abs(got[big] - ref[big]) / ref[big]
+    assert rel.max() <= 4 * np.finfo(np.float64).eps, rel.max()
+    np.testing.assert_allclose(got[~big], ref[~big], rtol=1e-9, atol=5e-324)      # subnormal results: a few units in the last place
+    assert got[-1] == 0.0 and got[-2] == 0.0                                       # exp(-900), exp(-1600)
+    # MAT52 through the same exp
+    spec5 = ('MAT52', 1.0, np.array([1.0]), None)
+    np.testing.assert_allclose(_gram(dev, spec5, X)[:, 0], orc.kernel_cov(spec5, X)[:, 0], rtol=2e-15, atol=1e-300)
+    # non-finite inputs: NaN -> 0 and an infinite distance -> exp(-inf) = 0 after the scrub
+    Xb = X[:130].copy()
+    Xb[3, 0] = np.nan
+    Xb[5, 0] = np.inf
+    K = _gram(dev, spec, Xb, flags=lib.G3_GRAM_SCRUB)
+    Kr = orc.tt_to_num(orc.kernel_cov(spec, Xb))
+    np.testing.assert_allclose(K, Kr, rtol=1e-14, atol=0)

@@ -295,3 +295,59 @@ def test_config5_full_size_fp32_draws_properties(dev):
     np.testing.assert_allclose(g12 - loc[:, None], (g1 - loc[:, None]) + (g2 - loc[:, None]), atol=2e-3)   # (4)
     for b in (K, W, a, mu, ss, Kss, Lp):
         b.free()
+
+
+def _config5_through_hip(dev, g, dtype):
+    """BASELINE config 5's path exactly as bench.py --f32 runs it: warped delta -> Gram + tall Cholesky ->
+    logp (+ log-det of the warping) -> posterior covariance -> its robust Cholesky -> loc + L Z -> mapping"""
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    from g3py_amd.processes.hypers.mappings import BoxCoxLinear
+    N, d, M, S, seed = g['N'], g['d'], g['M'], g['draws'], g['seed']
+    X, y, Xs = _synth(N, d, M, seed)
+    warp = BoxCoxLinear(shift=g['mapping'][1], scale=g['mapping'][2], power=g['mapping'][3])
+    yw = (y - y.min() + 1.0).astype(dtype)
+    Z = np.random.Generator(np.random.PCG64(seed + 100)).standard_normal((M, S))
+    delta = np.asarray(warp.inv(yw), dtype=dtype)
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    spec_n = ('sum', spec_f, ('NOISE', g['noise']))
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, 128)
+    K = dev.alloc(Np + 128 + Mp, Np, dtype)
+    W, a = dev.alloc_inverses(Np, dtype), dev.alloc(1, Np, dtype)
+    mu, ss = dev.alloc(1, Mp, dtype), dev.alloc(1, Mp, dtype)
+    Xd, Xsd = dev.upload(X.astype(dtype)), dev.upload(Xs.astype(dtype))
+    st = dev.gp_factor_predict(compile_spec(spec_n, d), compile_spec(spec_f, d), Xd, N, d, dev.upload(delta), Xsd, M, K, W, a, mu, ss)
+    assert st['info'] == 0 and st['nonfinite'] == 0
+    lp = -0.5 * N * np.log(2 * np.pi) - 0.5 * st['quad'] - st['logdet'] + float(warp.logdet_dinv(yw))
+    V = dev.wrap(K.offset(Np + 128), Mp, Np, K.ld, dtype, keep=K)
+    Kss = dev.alloc(Mp, Mp, dtype)
+    dev.gram(compile_spec(spec_f, d), Xsd, None, d, Kss, Mp, Mp, 0)
+    dev.gemm_nt(Kss, V, V, Mp, Mp, Np, alpha=-1.0, beta=1.0, lower_only=True)
+    Lp = dev.alloc(Mp, Mp, dtype, zero=True)
+    tries, fb, _ = dev.potrf_robust(dev.wrap(Kss.ptr, M, M, Kss.ld, dtype, keep=Kss), dev.wrap(Lp.ptr, M, M, Lp.ld, dtype, keep=Lp), M)
+    loc = dev.download(mu, 1, M)[0].astype(np.float64)
+    var = np.maximum(1.0 - dev.download(ss, 1, M)[0].astype(np.float64), 0.0)
+    draws = np.asarray(warp(dev.gp_sample(Lp, M, loc.astype(dtype), Z.astype(dtype))), dtype=np.float64)
+    for b in (K, W, a, mu, ss, Kss, Lp):
+        b.free()
+    return lp, loc, var, draws, tries, fb
+
+
+@pytest.mark.parametrize('name,dtype,rtol,atol', [('c5mini', np.float64, 1e-8, 1e-8), ('c5mini', np.float32, 1e-4, 2e-3),
+                                                  ('c5', np.float32, 1e-4, 3e-3)])
+def test_config5_matches_oracle_pin(dev, golden_dir, name, dtype, rtol, atol):
+    """BASELINE config 5 (warped GP BoxCoxLinear, SE, d=16, draws) against the fp64 oracle's pins written by
+    oracle/gen_fullsize.py -- gaussian.py:75-97,127-174,208-232; elliptical.py:81-97.  `c5` is the FULL size
+    (N=65536, M=4096) in fp32, the arithmetic BASELINE.json names for it, at the stated fp32 tolerance (logp 1e-4
+    relative); `c5mini` is the same path at N=4096 in both precisions"""
+    import json
+    import os
+    g = json.load(open(os.path.join(golden_dir, 'fullsize.json')))[name]
+    lp, loc, var, draws, tries, fb = _config5_through_hip(dev, g, dtype)
+    assert abs(lp - g['logp']) <= rtol * abs(g['logp']), (lp, g['logp'])
+    nq = len(g['mean'])
+    np.testing.assert_allclose(loc[:nq], g['mean'], atol=atol)               # latent location (elliptical.py:81-84)
+    np.testing.assert_allclose(var[:nq], g['variance'], atol=atol)           # latent variance (elliptical.py:94-97)
+    assert not fb and tries == g['cov_tries']
+    np.testing.assert_allclose(draws[g['draw_rows']], np.asarray(g['draw_values']), atol=10 * atol)
+    assert abs(draws.mean() - g['draws_mean']) <= 10 * atol and abs(draws.std() - g['draws_std']) <= 10 * atol
