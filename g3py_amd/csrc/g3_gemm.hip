@@ -541,6 +541,8 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   if (forced == 2 && all128)
     return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 3) return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 5 && all128)    // 8 waves per 128 x 128 tile (64 x 32 each): four waves per SIMD with two tiles per CU
+    return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 4 && sh.kind != 2 && sh.n % 128 == 0)
     return launch_cfg<T, 32, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   // Tile choice (measured on MI355X, scripts/gemm_bench.py):
@@ -558,8 +560,21 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
              (long long)sh.m, (long long)sh.n);
     return G3_ERR_HIP;
   }
-  if (all128 && blocks128 >= big_tile_min())
+  // The 128 x 128 tile runs with EIGHT waves (64 x 32 each, 118 VGPRs) since round 3: two tiles per CU are then
+  // four waves per SIMD instead of two, and the matrix pipe finds a ready wave more often -- stand-alone
+  // 30720^2 x 1024 lower update 66.3 -> 68.0 TFLOP/s, x 2048: 68.2 -> 69.4, 16384^2 x 512: 60.2 -> 64.4; the
+  // N = 32768 step 208.3 -> 203.3 ms, config 3 33.7 -> 33.4 (profiles/r03_gemm_variants.md).  A retiring
+  // workgroup still leaves room for the fused 256-wide diagonal kernel (2 x 136 <= 512 - 2 x 120 VGPRs per
+  // SIMD).  G3_GEMM_BULK8=0 selects the four-wave tile (64 x 64 per wave) again.
+  static int bulk8 = -1;
+  if (bulk8 < 0) {
+    const char* e = getenv("G3_GEMM_BULK8");
+    bulk8 = e ? atoi(e) : 1;
+  }
+  if (all128 && blocks128 >= big_tile_min()) {
+    if (bulk8) return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
     return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  }
   return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
 }
 

@@ -54,10 +54,10 @@ CONFIGS = {
     'c3': (16384, 8, 1024, 1003, 'mat52cos'),
     'c4': (32768, 4, 1024, 1004, 'se'),
     'c5': (65536, 16, 4096, 1005, 'se'),       # warped (BoxCoxLinear), draws: see WARPED below
-    'c5mini': (4096, 16, 512, 1005, 'se'),     # the same path at a size every test run can afford
+    'c5mini': (2048, 16, 256, 1005, 'se'),     # the same path at a size every test run can afford
 }
 _W5 = dict(mapping=('BoxCoxLinear', 1.0, 1.0, 1.2), draws=16)
-WARPED = {'c5': dict(_W5, draw_rows=(0, 1, 2047, 4095)), 'c5mini': dict(_W5, draw_rows=(0, 1, 255, 511))}
+WARPED = {'c5': dict(_W5, draw_rows=(0, 1, 2047, 4095)), 'c5mini': dict(_W5, draw_rows=(0, 1, 127, 255))}
 
 
 def spec_of(kind, d):

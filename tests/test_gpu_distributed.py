@@ -49,7 +49,7 @@ def test_hip_one_rank_through_rccl(tmp_path, monkeypatch):
     assert abs(float(r['logp']) - ref) <= 1e-10 * abs(ref)
     np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-8)
     np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
-    assert int(r['comm_calls']) > 3 * (N // nb)          # broadcasts + all-gathers + all-reduces were really issued
+    assert int(r['comm_calls']) >= 2 * (N // nb)         # one broadcast + one all-gather per row block + the all-reduces
 
 
 @pytest.mark.parametrize('world', [1, 2])

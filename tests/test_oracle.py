@@ -377,3 +377,30 @@ def test_tkernel_oracle_posterior_is_the_gp_posterior():
     np.testing.assert_allclose(t.posterior(Xs, z, X, y), gp.mean(Xs, X, y) + Lp.dot(z), atol=1e-8)
     np.testing.assert_allclose(t.inv(X, t(X, y, noise=True), noise=True), y, atol=1e-10)
     assert abs(t.logdet_dinv(X, y) + 0.5 * np.linalg.slogdet(orc.kernel_cov(t.kn, X))[1]) < 1e-10
+
+
+def test_fullsize_generator_equals_the_literal_oracle_at_c5mini(golden_dir):
+    """oracle/gen_fullsize.py factors in blocks and shares solves so that N=65536 fits in memory; at `c5mini`
+    (the same warped-GP path, N=2048) its committed numbers must equal the oracle's literal restatement -- GP.logp,
+    location, kernel_diag, sampler with the same normals (gaussian.py:75-97,208-232; elliptical.py:81-97)"""
+    import json
+    from oracle import g3_oracle as orc
+    g = json.load(open(os.path.join(golden_dir, 'fullsize.json')))['c5mini']
+    N, d, M, seed, S = g['N'], g['d'], g['M'], g['seed'], g['draws']
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Lbox = N ** (1.0 / d)
+    X = rng.uniform(0, Lbox, (N, d))
+    Xs = rng.uniform(0, Lbox, (M, d))
+    y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.standard_normal(N)
+    yw = y - y.min() + 1.0
+    gp = orc.GP(('SE', 1.0, np.ones(d), None), g['noise'], mapping=tuple(g['mapping']))
+    lp = gp.logp(X, yw)
+    assert abs(lp - g['logp']) <= 1e-10 * abs(g['logp'])
+    nq = len(g['mean'])
+    np.testing.assert_allclose(gp.location(Xs[:nq], X, yw), g['mean'], atol=1e-9)
+    np.testing.assert_allclose(gp.kernel_diag(Xs[:nq], X), g['variance'], atol=1e-9)
+    np.testing.assert_allclose(gp.mean(Xs[:nq], X, yw), g['gh_mean'], atol=1e-9)
+    np.testing.assert_allclose(gp.variance(Xs[:nq], X, yw), g['gh_variance'], atol=1e-9)
+    Z = np.random.Generator(np.random.PCG64(seed + 100)).standard_normal((M, S))
+    draws = gp.sampler(Xs, X, yw, rand=Z)
+    np.testing.assert_allclose(draws[g['draw_rows']], np.asarray(g['draw_values']), atol=1e-8)
