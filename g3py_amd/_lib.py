@@ -45,6 +45,18 @@ class GradMap(C.Structure):
 
 _P = C.c_void_p
 _I64 = C.c_int64
+
+G3_DIST_ID_BYTES = 128
+DIST_BCAST_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+DIST_ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+DIST_ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+class DistCallbacks(C.Structure):
+    """g3_dist_callbacks: the three collectives as blocking host callbacks on device buffers (test transport)"""
+    _fields_ = [('user', C.c_void_p), ('bcast', DIST_BCAST_CB), ('allgather', DIST_ALLGATHER_CB),
+                ('allreduce', DIST_ALLREDUCE_CB)]
+
 _SIGS = {
     'g3_version': ([], C.c_int),
     'g3_ctx_create': ([C.c_int, C.POINTER(_P)], C.c_int),
@@ -95,6 +107,18 @@ _SIGS = {
                      C.c_int, _P, _I64, _P, _I64, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_dlogp_batched': ([_P, C.POINTER(KernelProg), C.c_int, C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64,
                              _I64, _P, _P, C.c_int, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_dist_unique_id': ([_P], C.c_int),
+    'g3_dist_create': ([_P, _P, _P, C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
+    'g3_dist_create_callbacks': ([_P, C.POINTER(DistCallbacks), C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
+    'g3_dist_destroy': ([_P], C.c_int),
+    'g3_dist_last_error': ([_P], C.c_char_p),
+    'g3_dist_plan': ([_P, _I64, C.c_int, _I64, _I64, C.c_int], C.c_int),
+    'g3_dist_gp_factor_predict': ([_P, C.POINTER(KernelProg), C.POINTER(KernelProg), _P, _I64, _P, _P, _I64,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
+    'g3_dist_posterior_draws': ([_P, C.POINTER(KernelProg), _P, _I64, _P, _P, _I64, _P, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int)], C.c_int),
+    'g3_dist_comm_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
+    'g3_dist_local_rows': ([_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)], C.c_int),
     'g3_prof_enable': ([_P, C.c_int], C.c_int),
     'g3_prof_reset': ([_P], C.c_int),
     'g3_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),

@@ -450,6 +450,21 @@ extern "C" int g3_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype
   return g3i_diag_add(ctx, A, n, ld, dt, value);
 }
 
+template <typename T>
+__global__ void scale_kernel(T* A, int64_t rows, int64_t cols, int64_t ld, T f) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j < cols && i < rows) A[i * ld + j] *= f;
+}
+int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_dtype dt, double factor) {
+  if (rows <= 0 || cols <= 0) return G3_OK;
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows);
+  if (dt == G3_F64) hipLaunchKernelGGL((scale_kernel<double>), grid, dim3(256), 0, ctx->stream, (double*)A, rows, cols, ld, factor);
+  else hipLaunchKernelGGL((scale_kernel<float>), grid, dim3(256), 0, ctx->stream, (float*)A, rows, cols, ld, (float)factor);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
 // stream-ordered; in batch mode every member gets the same increment
 int g3i_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value) {
   const dim3 grid((unsigned)((n + 255) / 256), (unsigned)g3_nbatch(ctx));

@@ -1,0 +1,949 @@
+// Multi-GPU GP hot path behind the C ABI: the N x N covariance block-partitioned over the GPUs of one
+// node, one process per GPU, RCCL over xGMI owned by the library (dlopen: a single-GPU user never needs
+// librccl).  The reference has no distributed code at all (its only parallelism is a process pool,
+// g3py/processes/stochastic.py:773-783); the algebra is the Gram + Cholesky + triangular solves of
+// g3py/libs/tensors.py:197-222, g3py/processes/gaussian.py:208-224 and elliptical.py:81-97.
+//
+// Layout: ROW-block-cyclic, boustrophedon dealing.  A rank stacks its nb-row blocks in
+// one full-width local matrix, followed by its share of the right-hand-side rows [delta^T; K(Xs, X)]
+// (128-row chunks), which ride through the factorisation as on one GPU.  Only the nb x nb diagonal factor
+// travels on the critical path (broadcast, on its OWN communicator and on the look-ahead stream); a panel is
+// solved by all ranks at once and exchanged by an all-gather in which every GPU talks to all peers -- the
+// pattern a point-to-point xGMI mesh is good at.
+//
+// Three HIP streams per rank, the schedule of the one-GPU sweep (g3_potrf.hip::potrf_lookahead) with the
+// collectives in it.  With G_k the gathered panel k, step k is
+//   bulk stream   d1. block column k+2 of everything the rank owns from block k+2 down -= P_k G_k^T   -> event B_k
+//                 d2. block columns >= k+3 of its blocks >= k+3 and of the right-hand-side rows (ONE staircase launch)
+//   chain stream  a.  (after B_{k-1}) block column k+1 of its blocks >= k+2 -= P_k G_k^T
+//   (the ctx's)   b.  (after the broadcast of L_{k+1,k+1}) solve its rows of panel k+1; all-gather them
+//   look-ahead    c.  (after B_k) the owner of block k+2 applies panel k+1 to its diagonal block from its own
+//   stream            rows, factors it and broadcasts factor + 128 x 128 block inverses
+//
+// Transports: RCCL (the product) or caller-supplied host callbacks (tests: several ranks sharing ONE GPU over
+// gloo -- RCCL refuses two ranks on one device -- so the schedule is checked for P > 1 on a one-GPU box).
+#include "g3_internal.h"
+#include "g3_host.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------- transports
+enum { G3_COLL_BCAST = 0, G3_COLL_ALLGATHER = 1, G3_COLL_ALLREDUCE = 2, G3_NCOLL = 3 };
+
+struct Transport {
+  virtual ~Transport() {}
+  // stream-ordered after everything queued on s; the result is visible to work queued on s afterwards
+  virtual int bcast(void* buf, size_t bytes, int root, hipStream_t s) = 0;
+  virtual int allgather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s) = 0;
+  // host values in / out; synchronises s.  op: 0 sum, 1 min, 2 max
+  virtual int allreduce(double* host, int n, int op, hipStream_t s) = 0;
+  virtual const char* name() const = 0;
+  char err[256] = {0};
+};
+
+struct RcclApi {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi* rccl_api(char* err, size_t errlen) {
+  static RcclApi api;
+  static int state = 0;   // 0 untried, 1 ok, -1 failed
+  if (state == 1) return &api;
+  if (state == -1) return nullptr;
+  // a copy already loaded into the process (e.g. the one PyTorch ships) is reused; G3_RCCL_PATH overrides
+  const char* names[] = {getenv("G3_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (int pass = 0; pass < 2 && !api.h; ++pass)
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      if (api.h) break;
+    }
+  if (!api.h) {
+    snprintf(err, errlen, "librccl not found (set G3_RCCL_PATH): %s", dlerror());
+    state = -1;
+    return nullptr;
+  }
+#define G3_SYM(f)                                                        \
+  api.f = (decltype(api.f))dlsym(api.h, "nccl" #f);                      \
+  if (!api.f) {                                                          \
+    snprintf(err, errlen, "librccl lacks nccl" #f);                      \
+    state = -1;                                                          \
+    return nullptr;                                                      \
+  }
+  G3_SYM(GetUniqueId) G3_SYM(CommInitRank) G3_SYM(CommDestroy) G3_SYM(Broadcast) G3_SYM(AllGather) G3_SYM(AllReduce)
+  G3_SYM(GetErrorString)
+#undef G3_SYM
+  state = 1;
+  return &api;
+}
+
+struct RcclTransport : Transport {
+  RcclApi* api = nullptr;
+  ncclComm_t comm_gather = nullptr;   // panel all-gathers, scalar all-reduces (chain stream)
+  ncclComm_t comm_bcast = nullptr;    // diagonal-factor broadcasts (look-ahead stream): never queues behind a gather
+  double* scratch = nullptr;          // device scratch of the scalar all-reduces
+  double* hscratch = nullptr;         // pinned
+  static const int SCR = 16384;
+  ~RcclTransport() override {
+    if (api && comm_gather) api->CommDestroy(comm_gather);
+    if (api && comm_bcast) api->CommDestroy(comm_bcast);
+    if (scratch) (void)hipFree(scratch);
+    if (hscratch) (void)hipHostFree(hscratch);
+  }
+  int chk(ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return G3_OK;
+    snprintf(err, sizeof(err), "%s: %s", what, api->GetErrorString(r));
+    return G3_ERR_HIP;
+  }
+  int bcast(void* buf, size_t bytes, int root, hipStream_t s) override {
+    return chk(api->Broadcast(buf, buf, bytes, ncclChar, root, comm_bcast, s), "ncclBroadcast");
+  }
+  int allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+    return chk(api->AllGather(send, recv, bytes, ncclChar, comm_gather, s), "ncclAllGather");
+  }
+  int allreduce(double* host, int n, int op, hipStream_t s) override {
+    for (int off = 0; off < n; off += SCR) {
+      const int c = n - off < SCR ? n - off : SCR;
+      memcpy(hscratch, host + off, c * sizeof(double));
+      if (hipMemcpyAsync(scratch, hscratch, c * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return G3_ERR_HIP;
+      const ncclRedOp_t o = op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax);
+      int rc = chk(api->AllReduce(scratch, scratch, c, ncclDouble, o, comm_gather, s), "ncclAllReduce");
+      if (rc) return rc;
+      if (hipMemcpyAsync(hscratch, scratch, c * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return G3_ERR_HIP;
+      if (hipStreamSynchronize(s) != hipSuccess) return G3_ERR_HIP;
+      memcpy(host + off, hscratch, c * sizeof(double));
+    }
+    return G3_OK;
+  }
+  const char* name() const override { return "rccl"; }
+};
+
+struct CallbackTransport : Transport {
+  g3_dist_callbacks cb;
+  int bcast(void* buf, size_t bytes, int root, hipStream_t s) override {
+    if (hipStreamSynchronize(s) != hipSuccess) return G3_ERR_HIP;
+    return cb.bcast(cb.user, buf, bytes, root) ? G3_ERR_HIP : G3_OK;
+  }
+  int allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+    if (hipStreamSynchronize(s) != hipSuccess) return G3_ERR_HIP;
+    return cb.allgather(cb.user, send, recv, bytes) ? G3_ERR_HIP : G3_OK;
+  }
+  int allreduce(double* host, int n, int op, hipStream_t s) override {
+    if (hipStreamSynchronize(s) != hipSuccess) return G3_ERR_HIP;
+    return cb.allreduce(cb.user, host, n, op) ? G3_ERR_HIP : G3_OK;
+  }
+  const char* name() const override { return "callbacks"; }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- the driver object
+struct g3_dist {
+  g3_ctx* ctx = nullptr;        // chain stream (the caller's context)
+  g3_ctx* ctx_look = nullptr;   // look-ahead stream: its own context, so no scratch / info flag is shared
+  g3_ctx* ctx_bulk = nullptr;   // bulk stream
+  hipStream_t s_look = nullptr, s_bulk = nullptr;
+  int rank = 0, world = 1;
+  Transport* tr = nullptr;
+  // plan
+  bool planned = false;
+  int64_t N = 0, M = 0, nb = 0, Np = 0, Mp = 0;
+  int d = 0, nblk = 0, nchunk = 0;
+  g3_dtype dt = G3_F64;
+  size_t es = 8;
+  std::vector<int> my_blocks, my_chunks;
+  std::vector<int64_t> loff;    // local row offset of an owned block, -1 otherwise
+  int64_t rows_mat = 0, rows_rhs = 0, cmax = 1;
+  char* A = nullptr;            // (rows_mat + rows_rhs) x Np local rows, full width
+  char* dbuf[2] = {nullptr, nullptr};   // nb x nb diagonal factor + nb x 128 block inverses
+  char* send[2] = {nullptr, nullptr};
+  char* gath[3] = {nullptr, nullptr, nullptr};
+  char* avec = nullptr;         // 1 x Np: a = L^-1 delta, broadcast for the mean
+  char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss
+  int* info_dev = nullptr;
+  std::vector<hipEvent_t> ev;   // B_k events + stream joins
+  // accounting: per collective kind calls, bytes (sent + received by this rank), device milliseconds
+  double n_calls[G3_NCOLL] = {0, 0, 0}, n_bytes[G3_NCOLL] = {0, 0, 0};
+  std::vector<hipEvent_t> tev;  // timing event pairs
+  std::vector<int> tkind;
+  size_t tused = 0;
+  // outcome of the last evaluation
+  int last_info = 0, last_tries = 0, last_fallback = 0;
+  char err[512] = {0};
+};
+
+#define G3D_HIP(call)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      snprintf(D->err, sizeof(D->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      return G3_ERR_HIP;                                                                           \
+    }                                                                                              \
+  } while (0)
+// a failing library call: keep its context's message
+#define G3D_RC(cx, call)                                                                           \
+  do {                                                                                             \
+    int _rc = (call);                                                                              \
+    if (_rc) {                                                                                     \
+      snprintf(D->err, sizeof(D->err), "%s:%d %s -> %d %s", __FILE__, __LINE__, #call, _rc, (cx) ? (cx)->err : ""); \
+      return _rc < 0 ? _rc : G3_ERR_HIP;                                                           \
+    }                                                                                              \
+  } while (0)
+
+static int owner_of(const g3_dist* D, int I) {
+  // boustrophedon dealing 0..P-1, P-1..0, ...: the trailing work of block I grows like I^2 and the snake keeps
+  // the ranks' shares within a few per cent (plain round-robin leaves the last rank at 1.4x the mean)
+  const int P = D->world, r = I % (2 * P);
+  return r < P ? r : 2 * P - 1 - r;
+}
+
+// blocks per rank in the padded gather of step k, and the position of global block k+1+s in the rank-major
+// gather buffer
+static int perm_of(const g3_dist* D, int k, std::vector<int32_t>* idx) {
+  const int P = D->world;
+  std::vector<int> cnt(P, 0), seen(P, 0);
+  for (int I = k + 1; I < D->nblk; ++I) cnt[owner_of(D, I)]++;
+  int c = 0;
+  for (int q = 0; q < P; ++q) c = cnt[q] > c ? cnt[q] : c;
+  idx->clear();
+  for (int I = k + 1; I < D->nblk; ++I) {
+    const int q = owner_of(D, I);
+    idx->push_back(q * c + seen[q]++);
+  }
+  return c;
+}
+
+static inline char* Aat(const g3_dist* D, int64_t row, int64_t col) { return D->A + ((size_t)row * D->Np + col) * D->es; }
+static inline char* Lof(const g3_dist* D, int k) { return D->dbuf[k % 2]; }
+static inline char* Wof(const g3_dist* D, int k) { return D->dbuf[k % 2] + (size_t)D->nb * D->nb * D->es; }
+static inline size_t dbuf_bytes(const g3_dist* D) { return ((size_t)D->nb * D->nb + (size_t)D->nb * 128) * D->es; }
+
+static int coll_begin(g3_dist* D, int kind, hipStream_t s, double bytes) {
+  D->n_calls[kind] += 1;
+  D->n_bytes[kind] += bytes;
+  if (D->tused + 2 > D->tev.size()) {
+    for (int i = 0; i < 64; ++i) {
+      hipEvent_t e;
+      G3D_HIP(hipEventCreate(&e));
+      D->tev.push_back(e);
+    }
+  }
+  if (D->tused / 2 >= D->tkind.size()) D->tkind.resize(D->tused / 2 + 64);
+  D->tkind[D->tused / 2] = kind;
+  G3D_HIP(hipEventRecord(D->tev[D->tused], s));
+  return G3_OK;
+}
+static int coll_end(g3_dist* D, hipStream_t s) {
+  G3D_HIP(hipEventRecord(D->tev[D->tused + 1], s));
+  D->tused += 2;
+  return G3_OK;
+}
+#define G3D_TR(call)                                                                        \
+  do {                                                                                      \
+    int _rc = (call);                                                                       \
+    if (_rc) {                                                                              \
+      snprintf(D->err, sizeof(D->err), "%s transport: %s", D->tr->name(), D->tr->err);      \
+      return _rc;                                                                           \
+    }                                                                                       \
+  } while (0)
+
+static int do_bcast(g3_dist* D, void* buf, size_t bytes, int root, hipStream_t s) {
+  int rc = coll_begin(D, G3_COLL_BCAST, s, D->world > 1 ? (double)bytes : 0.0);
+  if (rc) return rc;
+  G3D_TR(D->tr->bcast(buf, bytes, root, s));
+  return coll_end(D, s);
+}
+static int do_allgather(g3_dist* D, const void* sendb, void* recvb, size_t bytes, hipStream_t s) {
+  int rc = coll_begin(D, G3_COLL_ALLGATHER, s, 2.0 * (D->world - 1) * (double)bytes);
+  if (rc) return rc;
+  G3D_TR(D->tr->allgather(sendb, recvb, bytes, s));
+  return coll_end(D, s);
+}
+static int do_allreduce(g3_dist* D, double* host, int n, int op) {
+  int rc = coll_begin(D, G3_COLL_ALLREDUCE, D->ctx->stream, 2.0 * (D->world - 1) / D->world * n * 8.0);
+  if (rc) return rc;
+  G3D_TR(D->tr->allreduce(host, n, op, D->ctx->stream));
+  return coll_end(D, D->ctx->stream);
+}
+
+// ---------------------------------------------------------------------------------------- create / destroy
+extern "C" int g3_dist_unique_id(void* id_out) {
+  if (!id_out) return -1;
+  char err[256];
+  RcclApi* api = rccl_api(err, sizeof(err));
+  if (!api) return G3_ERR_HIP;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return G3_ERR_HIP;
+  static_assert(sizeof(id) == G3_DIST_ID_BYTES, "ncclUniqueId size");
+  memcpy(id_out, &id, sizeof(id));
+  return G3_OK;
+}
+
+static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
+  g3_dist* D = new (std::nothrow) g3_dist();
+  if (!D) return G3_ERR_NOMEM;
+  D->ctx = ctx;
+  D->rank = rank;
+  D->world = world;
+  int rc = g3_ctx_create(ctx->device, &D->ctx_look);
+  if (!rc) rc = g3_ctx_create(ctx->device, &D->ctx_bulk);
+  if (rc) {
+    if (D->ctx_look) g3_ctx_destroy(D->ctx_look);
+    delete D;
+    return rc;
+  }
+  g3_dev_guard _dg(ctx);
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority, hi = greatest
+  hipError_t e = hipStreamCreateWithPriority(&D->s_look, hipStreamNonBlocking, hi);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&D->s_bulk, hipStreamNonBlocking, lo);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->info_dev, sizeof(int));
+  if (e != hipSuccess) {
+    g3_ctx_destroy(D->ctx_look);
+    g3_ctx_destroy(D->ctx_bulk);
+    delete D;
+    return G3_ERR_HIP;
+  }
+  g3_ctx_set_stream(D->ctx_look, D->s_look);
+  g3_ctx_set_stream(D->ctx_bulk, D->s_bulk);
+  *out = D;
+  return G3_OK;
+}
+
+extern "C" int g3_dist_create(g3_ctx* ctx, const void* id_gather, const void* id_bcast, int rank, int world, g3_dist** out) {
+  if (!ctx) return -1;
+  if (!id_gather) return -2;
+  if (!id_bcast) return -3;
+  if (world < 1 || rank < 0 || rank >= world) return -4;
+  if (!out) return -6;
+  *out = nullptr;
+  RcclApi* api = rccl_api(ctx->err, sizeof(ctx->err));
+  if (!api) return G3_ERR_HIP;
+  g3_dist* D = nullptr;
+  int rc = dist_common(ctx, rank, world, &D);
+  if (rc) return rc;
+  g3_dev_guard _dg(ctx);
+  RcclTransport* t = new (std::nothrow) RcclTransport();
+  if (!t) { g3_dist_destroy(D); return G3_ERR_NOMEM; }
+  t->api = api;
+  D->tr = t;
+  ncclUniqueId a, b;
+  memcpy(&a, id_gather, sizeof(a));
+  memcpy(&b, id_bcast, sizeof(b));
+  // two communicators (same order on every rank): the broadcast of a diagonal factor must never wait in the
+  // queue of the communicator that carries a 100 MB panel all-gather
+  ncclResult_t r = api->CommInitRank(&t->comm_gather, world, a, rank);
+  if (r == ncclSuccess) r = api->CommInitRank(&t->comm_bcast, world, b, rank);
+  if (r != ncclSuccess) {
+    snprintf(ctx->err, sizeof(ctx->err), "ncclCommInitRank: %s", api->GetErrorString(r));
+    g3_dist_destroy(D);
+    return G3_ERR_HIP;
+  }
+  if (hipMalloc((void**)&t->scratch, RcclTransport::SCR * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&t->hscratch, RcclTransport::SCR * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    g3_dist_destroy(D);
+    return G3_ERR_HIP;
+  }
+  *out = D;
+  return G3_OK;
+}
+
+extern "C" int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb, int rank, int world, g3_dist** out) {
+  if (!ctx) return -1;
+  if (!cb || !cb->bcast || !cb->allgather || !cb->allreduce) return -2;
+  if (world < 1 || rank < 0 || rank >= world) return -3;
+  if (!out) return -5;
+  *out = nullptr;
+  g3_dist* D = nullptr;
+  int rc = dist_common(ctx, rank, world, &D);
+  if (rc) return rc;
+  CallbackTransport* t = new (std::nothrow) CallbackTransport();
+  if (!t) { g3_dist_destroy(D); return G3_ERR_NOMEM; }
+  t->cb = *cb;
+  D->tr = t;
+  *out = D;
+  return G3_OK;
+}
+
+static void free_plan(g3_dist* D) {
+  void* bufs[] = {D->A, D->dbuf[0], D->dbuf[1], D->send[0], D->send[1], D->gath[0], D->gath[1], D->gath[2], D->avec, D->dots};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  D->A = D->dbuf[0] = D->dbuf[1] = D->send[0] = D->send[1] = D->gath[0] = D->gath[1] = D->gath[2] = D->avec = D->dots = nullptr;
+  for (hipEvent_t e : D->ev) (void)hipEventDestroy(e);
+  D->ev.clear();
+  D->planned = false;
+}
+
+extern "C" int g3_dist_destroy(g3_dist* D) {
+  if (!D) return -1;
+  g3_dev_guard _dg(D->ctx);
+  (void)hipStreamSynchronize(D->ctx->stream);
+  if (D->s_look) (void)hipStreamSynchronize(D->s_look);
+  if (D->s_bulk) (void)hipStreamSynchronize(D->s_bulk);
+  delete D->tr;            // communicators first: their kernels are done
+  free_plan(D);
+  for (hipEvent_t e : D->tev) (void)hipEventDestroy(e);
+  if (D->info_dev) (void)hipFree(D->info_dev);
+  if (D->ctx_look) g3_ctx_destroy(D->ctx_look);
+  if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
+  if (D->s_look) (void)hipStreamDestroy(D->s_look);
+  if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
+  delete D;
+  return G3_OK;
+}
+
+extern "C" const char* g3_dist_last_error(g3_dist* D) { return D ? D->err : "null g3_dist"; }
+
+extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb, g3_dtype dt) {
+  if (!D) return -1;
+  if (N <= 0) return -2;
+  if (d < 1 || d > G3_MAXCOLS) return -3;
+  if (M < 0) return -4;
+  if (nb < 128 || nb % 128) return -5;
+  g3_dev_guard _dg(D->ctx);
+  G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+  free_plan(D);
+  D->N = N; D->d = d; D->M = M; D->nb = nb; D->dt = dt; D->es = g3_esize(dt);
+  D->Np = g3_roundup(N, nb);
+  D->nblk = (int)(D->Np / nb);
+  D->Mp = g3_roundup(M, 128);
+  D->nchunk = 1 + (int)(D->Mp / 128);
+  D->my_blocks.clear(); D->my_chunks.clear();
+  D->loff.assign(D->nblk, -1);
+  for (int I = 0; I < D->nblk; ++I)
+    if (owner_of(D, I) == D->rank) { D->loff[I] = (int64_t)D->my_blocks.size() * nb; D->my_blocks.push_back(I); }
+  for (int c = 0; c < D->nchunk; ++c)
+    if (c % D->world == D->rank) D->my_chunks.push_back(c);
+  D->rows_mat = (int64_t)D->my_blocks.size() * nb;
+  D->rows_rhs = (int64_t)D->my_chunks.size() * 128;
+  std::vector<int32_t> idx;
+  D->cmax = D->nblk > 1 ? perm_of(D, 0, &idx) : 1;
+  if (D->cmax < 1) D->cmax = 1;
+  const size_t rows = (size_t)(D->rows_mat + D->rows_rhs);
+  G3D_HIP(hipMalloc((void**)&D->A, (rows ? rows : 1) * D->Np * D->es));
+  G3D_HIP(hipMemsetAsync(D->A, 0, (rows ? rows : 1) * D->Np * D->es, D->ctx->stream));
+  for (int i = 0; i < 2; ++i) {
+    G3D_HIP(hipMalloc((void**)&D->dbuf[i], dbuf_bytes(D)));
+    G3D_HIP(hipMalloc((void**)&D->send[i], (size_t)D->cmax * nb * nb * D->es));
+    G3D_HIP(hipMemsetAsync(D->send[i], 0, (size_t)D->cmax * nb * nb * D->es, D->ctx->stream));
+  }
+  // three gather buffers: the bulk update with panel k may still be reading its buffer while panel k + 2 arrives
+  for (int i = 0; i < 3; ++i) G3D_HIP(hipMalloc((void**)&D->gath[i], (size_t)D->world * D->cmax * nb * nb * D->es));
+  G3D_HIP(hipMalloc((void**)&D->avec, (size_t)D->Np * D->es));
+  G3D_HIP(hipMalloc((void**)&D->dots, 2 * 128 * D->es));
+  D->ev.resize(D->nblk + 4);
+  for (auto& e : D->ev) G3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+  D->planned = true;
+  return G3_OK;
+}
+
+// ---------------------------------------------------------------------------------------- build
+// stream `to` waits for everything queued so far on `from`
+static int stream_after(g3_dist* D, hipStream_t to, hipStream_t from, hipEvent_t ev) {
+  G3D_HIP(hipEventRecord(ev, from));
+  G3D_HIP(hipStreamWaitEvent(to, ev, 0));
+  return G3_OK;
+}
+
+static int rhs_rows(g3_dist* D, int t, int chunk, const g3_kernel_prog* prog_cross, const void* X, int64_t ldx, const void* Xs,
+                    int64_t ldxs, const void* delta) {
+  // chunk 0 = [delta; 0 ...]; chunk c >= 1 = tt_to_num(K(Xs[(c-1)*128 : c*128], X)), zero padded
+  char* out = Aat(D, D->rows_mat + (int64_t)t * 128, 0);
+  G3D_HIP(hipMemsetAsync(out, 0, (size_t)128 * D->Np * D->es, D->ctx->stream));
+  if (chunk == 0) {
+    G3D_HIP(hipMemcpyAsync(out, delta, (size_t)D->N * D->es, hipMemcpyDeviceToDevice, D->ctx->stream));
+    return G3_OK;
+  }
+  const int64_t s0 = (int64_t)(chunk - 1) * 128;
+  const int64_t m = D->M - s0 < 128 ? D->M - s0 : 128;
+  if (m > 0)
+    G3D_RC(D->ctx, g3_gram(D->ctx, prog_cross, (const char*)Xs + (size_t)s0 * ldxs * D->es, m, ldxs, X, D->N, ldx, D->d, D->dt, out,
+                           D->Np, m, D->N, G3_GRAM_SCRUB));
+  return G3_OK;
+}
+
+static int build(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X, int64_t ldx,
+                 const void* Xs, int64_t ldxs, const void* delta, double jitter) {
+  const int64_t nb = D->nb;
+  double lmin = INFINITY;
+  for (int I : D->my_blocks) {
+    G3D_RC(D->ctx, g3_gram_rows(D->ctx, prog, X, D->N, ldx, D->d, (int64_t)I * nb, nb, D->dt, Aat(D, D->loff[I], 0), D->Np,
+                                G3_GRAM_SCRUB | G3_GRAM_PAD_EYE));
+    const int64_t nv = D->N - (int64_t)I * nb < nb ? D->N - (int64_t)I * nb : nb;
+    if (nv > 0) {
+      double st[3];
+      G3D_RC(D->ctx, g3_diag_stats(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, D->Np, D->dt, st));
+      if (st[0] < lmin || st[0] != st[0]) lmin = st[0];
+    }
+  }
+  for (size_t t = 0; t < D->my_chunks.size(); ++t) {
+    int rc = rhs_rows(D, (int)t, D->my_chunks[t], prog_cross, X, ldx, Xs, ldxs, delta);
+    if (rc) return rc;
+  }
+  // tt_to_cov (tensors.py:95-98): min over the WHOLE diagonal
+  double g = isfinite(lmin) ? lmin : 1e300;
+  int rc = do_allreduce(D, &g, 1, 1);
+  if (rc) return rc;
+  double add = jitter;
+  if (!(g > 0)) add += (double)1e-6f - g;
+  if (add != 0.0)
+    for (int I : D->my_blocks) {
+      const int64_t nv = D->N - (int64_t)I * nb < nb ? D->N - (int64_t)I * nb : nb;
+      if (nv > 0) G3D_RC(D->ctx, g3_diag_add(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, D->Np, D->dt, add));
+    }
+  return G3_OK;
+}
+
+// ---------------------------------------------------------------------------------------- the sweep
+static int factor_block(g3_dist* D, g3_ctx* cx, int k) {
+  // owner only: factor diagonal block k into the broadcast buffer; keep the factor in place for the log-determinant
+  char* Dk = Aat(D, D->loff[k], (int64_t)k * D->nb);
+  G3D_RC(cx, g3_copy2d(cx, Lof(D, k), D->nb, Dk, D->Np, D->nb, D->nb, D->dt));
+  G3D_RC(cx, g3_potrf_nowait(cx, Lof(D, k), D->nb, D->nb, D->dt, Wof(D, k), D->info_dev));
+  G3D_RC(cx, g3_copy2d(cx, Dk, D->Np, Lof(D, k), D->nb, D->nb, D->nb, D->dt));
+  return G3_OK;
+}
+
+static int64_t rows_done(const g3_dist* D, int k) {   // local rows of the blocks <= k
+  int64_t c = 0;
+  for (int I : D->my_blocks) if (I <= k) c += D->nb;
+  return c;
+}
+
+// panel k: solve my rows below block k (right-hand-side rows included) against L_kk, then all-gather them into
+// gath[k % 3] -- all on the chain stream, which has nothing else to do until the panel is there
+static int solve_and_gather(g3_dist* D, int k) {
+  const int64_t nb = D->nb, c0 = (int64_t)k * nb;
+  const int64_t r_lo = rows_done(D, k);
+  const int64_t m = D->rows_mat + D->rows_rhs - r_lo;
+  if (m > 0) G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), m, D->Np, D->dt, Wof(D, k)));
+  if (D->nblk - 1 - k <= 0) return G3_OK;
+  std::vector<int32_t> idx;
+  const int cnt = perm_of(D, k, &idx);
+  const int64_t mine = D->rows_mat - r_lo;
+  if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, D->send[k % 2], nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
+  return do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * D->es, D->ctx->stream);
+}
+
+// diagonal block j on the look-ahead stream: its owner applies the update with panel j-1 from its own panel rows
+// (the earlier panels arrived with the bulk stream's column launches: event `after`), factors and broadcasts;
+// the others post the receive.  `joined`: event recorded behind the broadcast, the chain waits for it before
+// it uses dbuf[j % 2]
+static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_tmp, hipEvent_t joined) {
+  const int64_t nb = D->nb;
+  int rc = stream_after(D, D->s_look, D->ctx->stream, ev_tmp);
+  if (rc) return rc;
+  if (owner_of(D, j) == D->rank) {
+    if (after) G3D_HIP(hipStreamWaitEvent(D->s_look, after, 0));
+    const int64_t lo = D->loff[j];
+    char* Pn = Aat(D, lo, (int64_t)(j - 1) * nb);
+    G3D_RC(D->ctx_look, g3_gemm_nt(D->ctx_look, Aat(D, lo, (int64_t)j * nb), D->Np, Pn, D->Np, Pn, D->Np, nb, nb, nb, -1.0, 1.0, D->dt, 1));
+    rc = factor_block(D, D->ctx_look, j);
+    if (rc) return rc;
+  }
+  rc = do_bcast(D, D->dbuf[j % 2], dbuf_bytes(D), owner_of(D, j), D->s_look);
+  if (rc) return rc;
+  G3D_HIP(hipEventRecord(joined, D->s_look));
+  return G3_OK;
+}
+
+static int stair(g3_dist* D, g3_ctx* cx, int64_t row0, int64_t col0, int64_t kcol, const char* G, const std::vector<int64_t>& seg_rows,
+                 const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm) {
+  // C[rows_s, col0 : col0 + seg_cols[s]) -= A[rows_s, kcol : kcol + nb) G[block table]^T, cut into launches of at
+  // most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
+  std::vector<G3hStairChunk> ch;
+  g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch);
+  for (const auto& c : ch) {
+    G3D_RC(cx, g3_gemm_nt_stair(cx, Aat(D, row0 + c.row0, col0 + c.col0), D->Np, Aat(D, row0 + c.row0, kcol), D->Np, G, D->nb, D->nb,
+                                c.rows.data(), c.cols.data(), (int)c.rows.size(), -1.0, 1.0, D->dt, D->nb, perm + c.blk0, c.nblk));
+  }
+  return G3_OK;
+}
+
+static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X, int64_t ldx, const void* Xs,
+                  int64_t ldxs, const void* delta, double jitter, int* info_out) {
+  const int64_t nb = D->nb;
+  const int nblk = D->nblk;
+  hipStream_t sA = D->ctx->stream, sB = D->s_bulk;
+  hipEvent_t ev_tmp = D->ev[nblk], ev_join = D->ev[nblk + 1], ev_bc[2] = {D->ev[nblk + 2], D->ev[nblk + 3]};
+  int rc = build(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, jitter);
+  if (rc) return rc;
+  G3D_HIP(hipMemsetAsync(D->info_dev, 0, sizeof(int), sA));
+  if (owner_of(D, 0) == D->rank) {
+    rc = factor_block(D, D->ctx, 0);
+    if (rc) return rc;
+  }
+  rc = do_bcast(D, D->dbuf[0], dbuf_bytes(D), owner_of(D, 0), sA);
+  if (rc) return rc;
+  rc = solve_and_gather(D, 0);
+  if (rc) return rc;
+  if (nblk > 1) {
+    rc = lookahead(D, 1, nullptr, ev_tmp, ev_bc[1]);
+    if (rc) return rc;
+  }
+  hipEvent_t ev_prev = nullptr;
+  std::vector<int32_t> perm;
+  std::vector<int64_t> seg_rows, seg_cols;
+  for (int k = 0; k + 1 < nblk; ++k) {
+    const int64_t c0 = (int64_t)k * nb, c1 = c0 + nb, c2 = c1 + nb, c3 = c2 + nb;
+    perm_of(D, k, &perm);
+    const char* G = D->gath[k % 3];
+    hipEvent_t ev_k = nullptr;
+    // ---- bulk stream: everything beyond block column k+1 (after the gather of panel k, queued on the chain)
+    rc = stream_after(D, sB, sA, ev_tmp);
+    if (rc) return rc;
+    if (k + 2 < nblk) {
+      // d1. block column k+2 (block k+2's diagonal block included: the look-ahead adds panel k+1 only)
+      seg_rows.clear(); seg_cols.clear();
+      int64_t lo = -1;
+      for (int I : D->my_blocks) if (I >= k + 2) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back(nb); }
+      if (D->rows_rhs > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back(nb); }
+      if (!seg_rows.empty()) {
+        rc = stair(D, D->ctx_bulk, lo, c2, c0, G, seg_rows, seg_cols, perm.data() + 1, 1);
+        if (rc) return rc;
+      }
+      ev_k = D->ev[k];
+      G3D_HIP(hipEventRecord(ev_k, sB));
+      // d2. the rest: block columns >= k+3 of my blocks >= k+3 and of the right-hand-side rows
+      seg_rows.clear(); seg_cols.clear();
+      lo = -1;
+      for (int I : D->my_blocks) if (I >= k + 3) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back((int64_t)(I - k - 2) * nb); }
+      if (D->rows_rhs > 0 && nblk - k - 3 > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back((int64_t)(nblk - k - 3) * nb); }
+      if (!seg_rows.empty()) {
+        rc = stair(D, D->ctx_bulk, lo, c3, c0, G, seg_rows, seg_cols, perm.data() + 2, (int)perm.size() - 2);
+        if (rc) return rc;
+      }
+    }
+    // ---- chain: a. block column k+1 (it carries the updates up to panel k-1 once B_{k-1} has fired)
+    if (ev_prev) G3D_HIP(hipStreamWaitEvent(sA, ev_prev, 0));
+    {
+      seg_rows.clear(); seg_cols.clear();
+      int64_t lo = -1;
+      for (int I : D->my_blocks) if (I >= k + 2) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back(nb); }
+      if (D->rows_rhs > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back(nb); }
+      if (!seg_rows.empty()) {
+        rc = stair(D, D->ctx, lo, c1, c0, G, seg_rows, seg_cols, perm.data(), 1);
+        if (rc) return rc;
+      }
+    }
+    // b. panel k+1: needs the broadcast factor
+    G3D_HIP(hipStreamWaitEvent(sA, ev_bc[(k + 1) % 2], 0));
+    rc = solve_and_gather(D, k + 1);
+    if (rc) return rc;
+    // c. diagonal block k+2
+    if (k + 2 < nblk) {
+      rc = lookahead(D, k + 2, ev_k, ev_tmp, ev_bc[k % 2]);
+      if (rc) return rc;
+    }
+    ev_prev = ev_k;
+  }
+  rc = stream_after(D, sA, sB, ev_join);
+  if (rc) return rc;
+  rc = stream_after(D, sA, D->s_look, ev_join);
+  if (rc) return rc;
+  int info = 0;
+  G3D_HIP(hipMemcpyAsync(D->ctx->h_info, D->info_dev, sizeof(int), hipMemcpyDeviceToHost, sA));
+  G3D_HIP(hipStreamSynchronize(sA));
+  info = D->ctx->h_info[0];
+  double v = (double)info;
+  rc = do_allreduce(D, &v, 1, 2);
+  if (rc) return rc;
+  *info_out = (int)v;
+  return G3_OK;
+}
+
+// CholeskyRobust's schedule (tensors.py:197-222) around the distributed factorisation
+static int factor_robust(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X, int64_t ldx,
+                         const void* Xs, int64_t ldxs, const void* delta) {
+  int info = 0;
+  int rc = factor(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, 0.0, &info);
+  if (rc) return rc;
+  int tries = 0, fallback = 0;
+  if (info != 0) {
+    // jitter from the diagonal of the (lifted) covariance: rebuild and reduce mean / min
+    rc = build(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, 0.0);
+    if (rc) return rc;
+    double acc[2] = {0.0, 0.0}, mn = INFINITY;
+    for (int I : D->my_blocks) {
+      const int64_t nv = D->N - (int64_t)I * D->nb < D->nb ? D->N - (int64_t)I * D->nb : D->nb;
+      if (nv > 0) {
+        double st[3];
+        G3D_RC(D->ctx, g3_diag_stats(D->ctx, Aat(D, D->loff[I], (int64_t)I * D->nb), nv, D->Np, D->dt, st));
+        if (st[0] < mn) mn = st[0];
+        acc[0] += st[1] * (double)nv;
+        acc[1] += (double)nv;
+      }
+    }
+    rc = do_allreduce(D, acc, 2, 0);
+    if (rc) return rc;
+    double gmin = isfinite(mn) ? mn : 1e300;
+    rc = do_allreduce(D, &gmin, 1, 1);
+    if (rc) return rc;
+    const double mean = acc[0] / (acc[1] > 1.0 ? acc[1] : 1.0);
+    const double c6 = (double)1e-6f, c10 = (double)10.0f;
+    double dK = mean * c6, lift = 0.0;
+    if (gmin <= 0.0) lift = mean * c6 - gmin;
+    bool ok = false;
+    for (int t = 0; t < 20; ++t) {
+      ++tries;
+      int inf2 = 0;
+      rc = factor(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, lift + dK, &inf2);
+      if (rc) return rc;
+      if (inf2 == 0) { ok = true; break; }
+      dK *= c10;
+    }
+    if (!ok) {
+      // CholeskyRobust.perform never raises: the factor becomes 1e-10 * I (tensors.py:215-222), identity on the
+      // padding; the right-hand-side rows are rebuilt and solved against it (a division)
+      fallback = 1;
+      const double c = (double)1e-10f;
+      if (D->rows_mat > 0) G3D_HIP(hipMemsetAsync(D->A, 0, (size_t)D->rows_mat * D->Np * D->es, D->ctx->stream));
+      for (int I : D->my_blocks) {
+        const int64_t nv0 = D->N - (int64_t)I * D->nb;
+        const int64_t nv = nv0 < 0 ? 0 : (nv0 < D->nb ? nv0 : D->nb);
+        char* Dg = Aat(D, D->loff[I], (int64_t)I * D->nb);
+        if (nv > 0) G3D_RC(D->ctx, g3_diag_add(D->ctx, Dg, nv, D->Np, D->dt, c));
+        if (nv < D->nb) G3D_RC(D->ctx, g3_diag_add(D->ctx, Dg + ((size_t)nv * D->Np + nv) * D->es, D->nb - nv, D->Np, D->dt, 1.0));
+      }
+      for (size_t t = 0; t < D->my_chunks.size(); ++t) {
+        rc = rhs_rows(D, (int)t, D->my_chunks[t], prog_cross, X, ldx, Xs, ldxs, delta);
+        if (rc) return rc;
+      }
+      if (D->rows_rhs > 0)
+        G3D_RC(D->ctx, g3i_scale(D->ctx, Aat(D, D->rows_mat, 0), D->rows_rhs, D->N, D->Np, D->dt, 1.0 / c));
+    }
+  }
+  D->last_info = info;
+  D->last_tries = tries;
+  D->last_fallback = fallback;
+  return G3_OK;
+}
+
+// (logdet, quad, mean pieces[M], ss[M]) summed over all ranks
+static int stats(g3_dist* D, double* logdet, double* quad, double* mean, double* ss) {
+  const int64_t nb = D->nb, M = D->M, Np = D->Np;
+  std::vector<double> acc(2 + 2 * M, 0.0);
+  for (int I : D->my_blocks) {
+    const int64_t nv0 = D->N - (int64_t)I * nb;
+    const int64_t nv = nv0 < 0 ? 0 : (nv0 < nb ? nv0 : nb);
+    if (nv > 0) {
+      double o[4];
+      G3D_RC(D->ctx, g3_logp_terms(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, Np, nullptr, D->dt, o));
+      acc[0] += o[0];
+    }
+  }
+  // a = L^-1 delta is row 0 of right-hand-side chunk 0 (rank 0 holds it); everyone needs it for V a
+  const int own0 = 0 % D->world;
+  if (D->rank == own0) G3D_HIP(hipMemcpyAsync(D->avec, Aat(D, D->rows_mat, 0), (size_t)Np * D->es, hipMemcpyDeviceToDevice, D->ctx->stream));
+  int rc = do_bcast(D, D->avec, (size_t)Np * D->es, own0, D->ctx->stream);
+  if (rc) return rc;
+  if (D->rank == own0) {     // a^T a in double on the host (Np <= a few 10^5 values)
+    std::vector<char> ha((size_t)Np * D->es);
+    G3D_HIP(hipMemcpyAsync(ha.data(), D->avec, (size_t)Np * D->es, hipMemcpyDeviceToHost, D->ctx->stream));
+    G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+    double q = 0.0;
+    for (int64_t i = 0; i < Np; ++i) {
+      const double v = D->dt == G3_F64 ? ((const double*)ha.data())[i] : (double)((const float*)ha.data())[i];
+      q += v * v;
+    }
+    acc[1] = q;
+  }
+  std::vector<char> hb(2 * 128 * D->es);
+  for (size_t t = 0; t < D->my_chunks.size(); ++t) {
+    const int c = D->my_chunks[t];
+    if (c == 0) continue;
+    const int64_t s0 = (int64_t)(c - 1) * 128;
+    const int64_t m = M - s0 < 128 ? M - s0 : 128;
+    if (m <= 0) continue;
+    G3D_RC(D->ctx, g3_rows_dot_ss(D->ctx, Aat(D, D->rows_mat + (int64_t)t * 128, 0), m, Np, Np, D->avec, D->dt, D->dots, D->dots + 128 * D->es));
+    G3D_HIP(hipMemcpyAsync(hb.data(), D->dots, 2 * 128 * D->es, hipMemcpyDeviceToHost, D->ctx->stream));
+    G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+    for (int64_t i = 0; i < m; ++i) {
+      if (D->dt == G3_F64) {
+        acc[2 + s0 + i] += ((const double*)hb.data())[i];
+        acc[2 + M + s0 + i] += ((const double*)hb.data())[128 + i];
+      } else {
+        acc[2 + s0 + i] += (double)((const float*)hb.data())[i];
+        acc[2 + M + s0 + i] += (double)((const float*)hb.data())[128 + i];
+      }
+    }
+  }
+  rc = do_allreduce(D, acc.data(), (int)acc.size(), 0);
+  if (rc) return rc;
+  *logdet = acc[0];
+  *quad = acc[1];
+  for (int64_t i = 0; i < M; ++i) { mean[i] = acc[2 + i]; ss[i] = acc[2 + M + i]; }
+  return G3_OK;
+}
+
+extern "C" int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X_dev,
+                                         int64_t ldx, const void* delta_dev, const void* Xs_dev, int64_t ldxs, double out_host[5],
+                                         double* mean_host, double* ss_host) {
+  if (!D) return -1;
+  if (!D->planned) return -1;
+  if (!prog) return -2;
+  if (!prog_cross) return -3;
+  if (!X_dev) return -4;
+  if (ldx < D->d) return -5;
+  if (!delta_dev) return -6;
+  if (D->M > 0 && !Xs_dev) return -7;
+  if (D->M > 0 && ldxs < D->d) return -8;
+  if (!out_host) return -9;
+  if (D->M > 0 && (!mean_host || !ss_host)) return -10;
+  if (g3i_validate_prog(prog, D->d) || g3i_validate_prog(prog_cross, D->d)) return -2;
+  g3_dev_guard _dg(D->ctx);
+  int rc = factor_robust(D, prog, prog_cross, X_dev, ldx, Xs_dev, ldxs, delta_dev);
+  if (rc) return rc;
+  std::vector<double> mm(D->M > 0 ? D->M : 1), sv(D->M > 0 ? D->M : 1);
+  double logdet = 0, quad = 0;
+  rc = stats(D, &logdet, &quad, mm.data(), sv.data());
+  if (rc) return rc;
+  out_host[0] = logdet;
+  out_host[1] = quad;
+  out_host[2] = (double)D->last_info;
+  out_host[3] = (double)D->last_tries;
+  out_host[4] = (double)D->last_fallback;
+  for (int64_t i = 0; i < D->M; ++i) { mean_host[i] = mm[i]; ss_host[i] = sv[i]; }
+  return G3_OK;
+}
+
+// ---------------------------------------------------------------------------------------- posterior covariance + draws
+// BASELINE config 5's extra work: K(Xs, Xs) - V V^T (elliptical.py:86-91), its robust Cholesky (elliptical.py:88,92;
+// tensors.py:197-222) and loc + L_post Z (gaussian.py:75-97, before the mapping).  V = K(Xs, X) L^-T sits in the
+// right-hand-side chunks, full rows per chunk.  All-gather V (M x N: 1 GiB at config 5), every rank forms the
+// covariance rows of ITS chunks with one staircase launch against the gathered V (rank-major: block table), the
+// M x M covariance is all-gathered (64 MiB) and factored redundantly on every rank -- M^3/3 flops, nothing to
+// exchange -- so all ranks hold the same draws.
+extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f, const void* Xs_dev, int64_t ldxs,
+                                       const void* loc_host, const void* Z_host, int64_t S, void* out_host, int* tries_host,
+                                       int* fallback_host) {
+  if (!D) return -1;
+  if (!D->planned || D->M <= 0) return -1;
+  if (!prog_f) return -2;
+  if (!Xs_dev) return -3;
+  if (ldxs < D->d) return -4;
+  if (!loc_host) return -5;
+  if (!Z_host) return -6;
+  if (S <= 0) return -7;
+  if (!out_host) return -8;
+  if (g3i_validate_prog(prog_f, D->d)) return -2;
+  g3_dev_guard _dg(D->ctx);
+  const int P = D->world;
+  const int64_t M = D->M, Mp = D->Mp, Np = D->Np, pad = 128;
+  const int nch = (int)(Mp / pad);
+  std::vector<int> own(nch), cntq(P, 0), mine;
+  for (int c = 0; c < nch; ++c) { own[c] = (c + 1) % P; cntq[own[c]]++; if (own[c] == D->rank) mine.push_back(c); }
+  int cmax = 1;
+  for (int q = 0; q < P; ++q) cmax = cntq[q] > cmax ? cntq[q] : cmax;
+  hipStream_t s = D->ctx->stream;
+  char *sendb = nullptr, *Vall = nullptr, *rows = nullptr, *call = nullptr, *cov = nullptr, *Lp = nullptr;
+  int rc = G3_OK;
+  auto cleanup = [&]() {
+    void* b[] = {sendb, Vall, rows, call, cov, Lp};
+    (void)hipStreamSynchronize(s);
+    for (void* p : b) if (p) (void)hipFree(p);
+  };
+#define G3D_TRY(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
+#define G3D_TRYH(x) do { if ((x) != hipSuccess) { snprintf(D->err, sizeof(D->err), "%s:%d %s", __FILE__, __LINE__, #x); cleanup(); return G3_ERR_HIP; } } while (0)
+  const size_t es = D->es;
+  G3D_TRYH(hipMalloc((void**)&sendb, (size_t)cmax * pad * Np * es));
+  G3D_TRYH(hipMalloc((void**)&Vall, (size_t)P * cmax * pad * Np * es));
+  G3D_TRYH(hipMalloc((void**)&rows, (size_t)cmax * pad * Mp * es));
+  G3D_TRYH(hipMalloc((void**)&call, (size_t)P * cmax * pad * Mp * es));
+  G3D_TRYH(hipMalloc((void**)&cov, (size_t)Mp * Mp * es));
+  G3D_TRYH(hipMalloc((void**)&Lp, (size_t)Mp * Mp * es));
+  G3D_TRYH(hipMemsetAsync(sendb, 0, (size_t)cmax * pad * Np * es, s));
+  G3D_TRYH(hipMemsetAsync(rows, 0, (size_t)cmax * pad * Mp * es, s));
+  G3D_TRYH(hipMemsetAsync(Lp, 0, (size_t)Mp * Mp * es, s));
+  // my V chunks, in chunk order (chunk c of Xs = right-hand-side chunk c + 1)
+  for (size_t i = 0; i < mine.size(); ++i) {
+    size_t t = 0;
+    while (t < D->my_chunks.size() && D->my_chunks[t] != mine[i] + 1) ++t;
+    G3D_TRYH(hipMemcpyAsync(sendb + i * pad * Np * es, Aat(D, D->rows_mat + (int64_t)t * pad, 0), (size_t)pad * Np * es,
+                            hipMemcpyDeviceToDevice, s));
+  }
+  G3D_TRY(do_allgather(D, sendb, Vall, (size_t)cmax * pad * Np * es, s));
+  std::vector<int32_t> perm(nch);
+  {
+    std::vector<int> seen(P, 0);
+    for (int c = 0; c < nch; ++c) perm[c] = own[c] * cmax + seen[own[c]]++;
+  }
+  // covariance rows of my chunks: K(Xs_c, Xs) - V_c Vall^T  (prior part: the plain f_kernel.cov, not scrubbed)
+  for (size_t i = 0; i < mine.size(); ++i) {
+    const int64_t c = mine[i];
+    const int64_t m = M - c * pad < pad ? M - c * pad : pad;
+    if (m > 0)
+      G3D_TRY(g3_gram(D->ctx, prog_f, (const char*)Xs_dev + (size_t)c * pad * ldxs * es, m, ldxs, Xs_dev, M, ldxs, D->d, D->dt,
+                      rows + i * pad * Mp * es, Mp, m, M, 0));
+  }
+  if (!mine.empty()) {
+    std::vector<int64_t> sr{(int64_t)mine.size() * pad}, sc{Mp};
+    std::vector<G3hStairChunk> ch;
+    g3h_stair_chunks(sr, sc, pad, nch, &ch);
+    for (const auto& cc : ch)
+      G3D_TRY(g3_gemm_nt_stair(D->ctx, rows + (size_t)cc.col0 * es, Mp, sendb, Np, Vall, Np, Np, cc.rows.data(), cc.cols.data(),
+                               (int)cc.rows.size(), -1.0, 1.0, D->dt, pad, perm.data() + cc.blk0, cc.nblk));
+  }
+  G3D_TRY(do_allgather(D, rows, call, (size_t)cmax * pad * Mp * es, s));
+  for (int c = 0; c < nch; ++c)
+    G3D_TRYH(hipMemcpyAsync(cov + (size_t)c * pad * Mp * es, call + (size_t)perm[c] * pad * Mp * es, (size_t)pad * Mp * es,
+                            hipMemcpyDeviceToDevice, s));
+  int tries = 0, fb = 0;
+  double jit = 0;
+  G3D_TRY(g3_potrf_robust(D->ctx, cov, Mp, Lp, Mp, M, D->dt, 20, &tries, &fb, &jit));
+  G3D_TRY(g3_gp_sample(D->ctx, Lp, M, Mp, loc_host, Z_host, S, D->dt, out_host));
+  if (tries_host) *tries_host = tries;
+  if (fallback_host) *fallback_host = fb;
+  cleanup();
+#undef G3D_TRY
+#undef G3D_TRYH
+  return G3_OK;
+}
+
+// per kind (broadcast, all-gather, all-reduce): calls, bytes sent + received by this rank, device milliseconds of
+// the collective calls themselves (HIP events on the stream each was enqueued on); counters reset
+extern "C" int g3_dist_comm_stats(g3_dist* D, double out_host[9]) {
+  if (!D) return -1;
+  if (!out_host) return -2;
+  g3_dev_guard _dg(D->ctx);
+  G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+  G3D_HIP(hipStreamSynchronize(D->s_look));
+  G3D_HIP(hipStreamSynchronize(D->s_bulk));
+  double ms[G3_NCOLL] = {0, 0, 0};
+  for (size_t i = 0; i + 1 < D->tused; i += 2) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, D->tev[i], D->tev[i + 1]) == hipSuccess) ms[D->tkind[i / 2]] += t;
+  }
+  for (int k = 0; k < G3_NCOLL; ++k) {
+    out_host[3 * k] = D->n_calls[k];
+    out_host[3 * k + 1] = D->n_bytes[k];
+    out_host[3 * k + 2] = ms[k];
+    D->n_calls[k] = D->n_bytes[k] = 0;
+  }
+  D->tused = 0;
+  return G3_OK;
+}
+
+// rows x cols view of the rank's local matrix (tests / debugging): copies A[row0 : row0 + rows, 0 : cols) to the host
+extern "C" int g3_dist_local_rows(g3_dist* D, int64_t* rows_mat, int64_t* rows_rhs, int64_t* ld) {
+  if (!D || !D->planned) return -1;
+  if (rows_mat) *rows_mat = D->rows_mat;
+  if (rows_rhs) *rows_rhs = D->rows_rhs;
+  if (ld) *ld = D->Np;
+  return G3_OK;
+}

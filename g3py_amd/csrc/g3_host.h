@@ -46,3 +46,55 @@ static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, std
   for (int k = 0; k < nblk; k += G) grp->push_back(k);
   grp->push_back(nblk);
 }
+
+// ---- staircase launches of the multi-GPU sweep.  One launch describes at most G3H_STAIR_MAX row segments and
+// G3H_STAIR_MAX blocks of the B operand (the raster table travels in the kernel arguments, g3_gemm.hip::RasterTab):
+// a longer staircase -- N / nb > 160 row blocks -- is cut into row chunks and column chunks.
+#define G3H_STAIR_MAX 160
+struct G3hStairChunk {
+  int64_t row0, col0;              // first row / column of the chunk, relative to the staircase
+  std::vector<int64_t> rows, cols; // segment rows / columns inside the chunk
+  int blk0, nblk;                  // blocks of B the chunk multiplies with: [blk0, blk0 + nblk) of the block table
+};
+static inline int g3h_stair_limit() {
+  const int v = g3h_env_int("G3_STAIR_MAX", G3H_STAIR_MAX);   // tests lower it to exercise the chunking
+  return v < 1 ? 1 : (v > G3H_STAIR_MAX ? G3H_STAIR_MAX : v);
+}
+// seg_rows / seg_cols: the staircase (entries multiples of 128; columns multiples of block_rows); nperm: blocks in
+// the B table (columns beyond nperm * block_rows do not exist)
+static inline void g3h_stair_chunks(const std::vector<int64_t>& seg_rows, const std::vector<int64_t>& seg_cols, int64_t block_rows,
+                                    int nperm, std::vector<G3hStairChunk>* out) {
+  out->clear();
+  const int limit = g3h_stair_limit();
+  const int nseg = (int)seg_rows.size();
+  int64_t width = 0;
+  for (int s = 0; s < nseg; ++s) width = seg_cols[s] > width ? seg_cols[s] : width;
+  if (width > (int64_t)nperm * block_rows) width = (int64_t)nperm * block_rows;
+  const int64_t cstep = (int64_t)limit * block_rows;
+  int64_t r0 = 0;
+  for (int s0 = 0; s0 < nseg; s0 += limit) {
+    const int s1 = s0 + limit < nseg ? s0 + limit : nseg;
+    int64_t rsum = 0;
+    for (int s = s0; s < s1; ++s) rsum += seg_rows[s];
+    for (int64_t c0 = 0; c0 < width && rsum > 0; c0 += cstep) {
+      G3hStairChunk ch;
+      ch.row0 = r0;
+      ch.col0 = c0;
+      int64_t cmaxw = 0;
+      for (int s = s0; s < s1; ++s) {
+        int64_t c = seg_cols[s] - c0;
+        if (c < 0) c = 0;
+        if (c > cstep) c = cstep;
+        if (c0 + c > width) c = width - c0;
+        ch.rows.push_back(seg_rows[s]);
+        ch.cols.push_back(c);
+        if (c > cmaxw && seg_rows[s] > 0) cmaxw = c;
+      }
+      if (cmaxw <= 0) continue;
+      ch.blk0 = (int)(c0 / block_rows);
+      ch.nblk = (int)((cmaxw + block_rows - 1) / block_rows);
+      out->push_back(ch);
+    }
+    r0 += rsum;
+  }
+}

@@ -142,6 +142,8 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd);
 int g3i_reset_info(g3_ctx* ctx);
 int g3i_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value);
+// A[0:rows, 0:cols) *= factor (stream-ordered)
+int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_dtype dt, double factor);
 int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N, int64_t ldx,
                   int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host);
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt);

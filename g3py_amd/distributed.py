@@ -694,6 +694,173 @@ class DistributedGP:
         return logp
 
 
+# --------------------------------------------------------------------------- the driver inside the library
+class NativeDistributedGP:
+    """The multi-GPU evaluation behind the C ABI (g3_dist_*, g3py_amd/csrc/g3_dist.hip): the library owns the
+    three HIP streams, the device buffers, the per-panel loop and the RCCL communicators (two: panel all-gathers and
+    diagonal-factor broadcasts never share a queue).  This class only boots it -- rank 0 makes the communicator
+    ids, `dist` (any torch.distributed backend, gloo is enough) carries their 2 x 128 bytes to the other ranks --
+    and wraps one call per evaluation; there is no Python loop over panels.  Same `step()` / `last` contract as
+    DistributedGP, which stays as the readable reference of the schedule (and runs on CPU with a test double).
+
+    transport='callbacks' (tests only): the collectives are served by `dist` through host staging, so several ranks
+    can share ONE GPU -- RCCL refuses that -- and the library's schedule is checked for world > 1 on a one-GPU box."""
+
+    def __init__(self, dev, dist, rank, world, N, d, M, nb=512, dtype=np.float64, transport='rccl'):
+        import ctypes as C
+        from . import _lib
+        from .device import compile_spec
+        self._C, self._lib, self._compile = C, _lib, compile_spec
+        self.dev, self.dist, self.rank, self.world = dev, dist, rank, world
+        self.N, self.d, self.M = N, d, M
+        self.nb = max(128, (nb // 128) * 128)
+        self.dtype = np.dtype(dtype)
+        self._dt = _lib.dtype_code(self.dtype)
+        self.last = {}
+        self.h = C.c_void_p()
+        lib = dev.lib
+        if transport == 'rccl':
+            ids = [None]
+            if rank == 0:
+                bufs = []
+                for _ in range(2):
+                    b = C.create_string_buffer(_lib.G3_DIST_ID_BYTES)
+                    rc = lib.g3_dist_unique_id(b)
+                    if rc:
+                        raise _lib.G3Error('g3_dist_unique_id failed (%d): is librccl available? (G3_RCCL_PATH)' % rc)
+                    bufs.append(bytes(b.raw))
+                ids = [bufs]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            a, b = ids[0]
+            rc = lib.g3_dist_create(dev.ctx, a, b, rank, world, C.byref(self.h))
+            if rc:
+                raise _lib.G3Error('g3_dist_create failed (%d): %s' % (rc, (lib.g3_last_error(dev.ctx) or b'').decode()))
+        elif transport == 'callbacks':
+            self._cb = self._make_callbacks()
+            rc = lib.g3_dist_create_callbacks(dev.ctx, C.byref(self._cb), rank, world, C.byref(self.h))
+            if rc:
+                raise _lib.G3Error('g3_dist_create_callbacks failed (%d)' % rc)
+        else:
+            raise ValueError(transport)
+        self.transport = transport
+        self._chk(lib.g3_dist_plan(self.h, N, d, M, self.nb, self._dt), 'g3_dist_plan')
+
+    def _chk(self, rc, what):
+        if rc:
+            raise self._lib.G3Error('%s failed (%d): %s' % (what, rc, (self.dev.lib.g3_dist_last_error(self.h) or b'').decode()))
+
+    def _make_callbacks(self):
+        """collectives for the test transport: device buffer -> host (C ABI memcpy) -> torch.distributed on CPU
+        tensors -> device"""
+        import torch
+        C, lib, dev, dist, world = self._C, self.dev.lib, self.dev, self.dist, self.world
+
+        def d2h(ptr, n):
+            a = np.empty(n, dtype=np.uint8)
+            assert lib.g3_memcpy_d2h(dev.ctx, a.ctypes.data, ptr, n) == 0
+            return a
+
+        def h2d(ptr, a):
+            assert lib.g3_memcpy_h2d(dev.ctx, ptr, a.ctypes.data, a.nbytes) == 0
+
+        def bcast(user, buf, nbytes, root):
+            try:
+                t = torch.from_numpy(d2h(buf, nbytes))
+                if world > 1:
+                    dist.broadcast(t, src=root)
+                h2d(buf, t.numpy())
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allgather(user, sendp, recvp, nbytes):
+            try:
+                t = torch.from_numpy(d2h(sendp, nbytes))
+                out = [torch.empty_like(t) for _ in range(world)]
+                if world > 1:
+                    dist.all_gather(out, t)
+                else:
+                    out = [t]
+                h2d(recvp, np.ascontiguousarray(np.concatenate([o.numpy() for o in out])))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allreduce(user, vals, n, op):
+            try:
+                a = np.ctypeslib.as_array(vals, shape=(n,))
+                t = torch.from_numpy(a.copy())
+                if world > 1:
+                    dist.all_reduce(t, op=[dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX][op])
+                a[:] = t.numpy()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb_keep = (self._lib.DIST_BCAST_CB(bcast), self._lib.DIST_ALLGATHER_CB(allgather),
+                         self._lib.DIST_ALLREDUCE_CB(allreduce))
+        return self._lib.DistCallbacks(None, *self._cb_keep)
+
+    @staticmethod
+    def _ptr_ld(a):
+        """(device pointer, row stride in elements) of a DeviceArray or a 2-D / 1-D torch tensor"""
+        if hasattr(a, 'ptr'):
+            return a.ptr, a.ld
+        return a.data_ptr(), (a.stride(0) if a.dim() == 2 else a.shape[-1])
+
+    def step(self, spec_noise, spec_f, X, Xs, delta, Z=None, loc_prior=None):
+        """one pass of the hot path on all ranks; returns logp (mean / variance pieces in self.last).  With Z (M x S
+        standard normals, gaussian.py:91) also the posterior covariance, its Cholesky and the latent draws
+        loc + L_post Z (self.last['draws']; the caller applies the mapping)"""
+        C, lib = self._C, self.dev.lib
+        pn, pf = self._compile(spec_noise, self.d), self._compile(spec_f, self.d)
+        xp, ldx = self._ptr_ld(X)
+        xsp, ldxs = self._ptr_ld(Xs)
+        dp, _ = self._ptr_ld(delta)
+        out = (C.c_double * 5)()
+        M = self.M
+        mean = np.zeros(max(M, 1))
+        ss = np.zeros(max(M, 1))
+        self._chk(lib.g3_dist_gp_factor_predict(self.h, C.byref(pn), C.byref(pf), xp, ldx, dp, xsp, ldxs, out,
+                                                mean.ctypes.data_as(C.POINTER(C.c_double)),
+                                                ss.ctypes.data_as(C.POINTER(C.c_double))), 'g3_dist_gp_factor_predict')
+        logdet, quad = out[0], out[1]
+        mean, ss = mean[:M], ss[:M]
+        self.last.update(logdet=logdet, quad=quad, info=int(out[2]), tries=int(out[3]), fallback=bool(out[4]), mean=mean, ss=ss)
+        if Z is not None:
+            loc = mean if loc_prior is None else np.asarray(loc_prior, dtype=np.float64) + mean
+            Zc = np.ascontiguousarray(Z, dtype=self.dtype)
+            S = Zc.shape[1]
+            locc = np.ascontiguousarray(loc, dtype=self.dtype)
+            draws = np.empty((M, S), dtype=self.dtype)
+            tries, fb = C.c_int(0), C.c_int(0)
+            self._chk(lib.g3_dist_posterior_draws(self.h, C.byref(pf), xsp, ldxs, locc.ctypes.data, Zc.ctypes.data, S,
+                                                  draws.ctypes.data, C.byref(tries), C.byref(fb)), 'g3_dist_posterior_draws')
+            self.last.update(draws=draws.astype(np.float64), cov_tries=tries.value, cov_fallback=bool(fb.value))
+        logp = -0.5 * self.N * np.log(2 * np.pi) - 0.5 * quad - logdet
+        self.last['logp'] = logp
+        return logp
+
+    def comm_stats(self):
+        """per collective kind since the last call: calls, bytes sent + received by this rank, device milliseconds
+        inside the collectives (HIP events on the stream each ran on)"""
+        out = (self._C.c_double * 9)()
+        self._chk(self.dev.lib.g3_dist_comm_stats(self.h, out), 'g3_dist_comm_stats')
+        return {k: {'calls': out[3 * i], 'bytes': out[3 * i + 1], 'device_ms': out[3 * i + 2]}
+                for i, k in enumerate(('bcast', 'allgather', 'allreduce'))}
+
+    def close(self):
+        if self.h:
+            self.dev.lib.g3_dist_destroy(self.h)
+            self.h = self._C.c_void_p()
+
+
 # --------------------------------------------------------------------------- replicas
 def logp_chain_sharded(process, chain, dist, rank, world, prior=False, torch_device=None):
     """logp of every row of a flat-parameter chain with the rows dealt round-robin to the ranks.

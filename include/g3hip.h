@@ -350,6 +350,53 @@ int g3_prof_enable(g3_ctx* ctx, int on);
 int g3_prof_reset(g3_ctx* ctx);
 int g3_prof_collect(g3_ctx* ctx, double* out_host /* 3 * G3_PROF_NTAGS */);
 
+/* ---- multi-GPU: the N x N covariance block-partitioned over the GPUs of one node ------------
+ * One process per GPU; the library owns the RCCL communicators (librccl is dlopen'ed by g3_dist_create only) and the
+ * whole per-panel loop -- a caller needs neither torch nor a Python loop.  The reference has no distributed code
+ * (its only parallelism is a process pool, g3py/processes/stochastic.py:773-783); what is distributed here is the
+ * algebra of tensors.py:197-222 (CholeskyRobust incl. the jitter schedule and the 1e-10*I fallback),
+ * gaussian.py:208-224 (logp pieces) and elliptical.py:81-97 (posterior location / variance), SURVEY.md 8(b)/(e).
+ * Layout, schedule and byte counts: DESIGN.md section 6 (row-block-cyclic; diagonal-factor broadcast on its own
+ * communicator and stream, panel all-gather, bulk staircase updates on a third stream).
+ *
+ * Bootstrap: rank 0 calls g3_dist_unique_id twice and ships the 2 x G3_DIST_ID_BYTES to every rank by any channel
+ * (MPI, a file, torch.distributed over gloo ...); every rank then calls g3_dist_create (collective). */
+typedef struct g3_dist g3_dist;
+#define G3_DIST_ID_BYTES 128
+int g3_dist_unique_id(void* id_out /* G3_DIST_ID_BYTES */);
+int g3_dist_create(g3_ctx* ctx, const void* id_gather, const void* id_bcast, int rank, int world, g3_dist** out);
+/* Test transport: the three collectives are supplied by the caller as blocking host callbacks on DEVICE buffers
+ * (return 0 on success).  Lets several ranks share ONE GPU (RCCL refuses that) so the schedule can be checked for
+ * world > 1 on a one-GPU box; never used by the product path. */
+typedef struct {
+  void* user;
+  int (*bcast)(void* user, void* buf_dev, size_t bytes, int root);
+  int (*allgather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+  int (*allreduce)(void* user, double* vals_host, int n, int op /* 0 sum, 1 min, 2 max */);
+} g3_dist_callbacks;
+int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb, int rank, int world, g3_dist** out);
+int g3_dist_destroy(g3_dist* D);
+const char* g3_dist_last_error(g3_dist* D);
+/* Problem shape: N observations in d columns, M test points, nb-row blocks (multiple of 128).  Allocates the
+ * rank's rows of the covariance ((its blocks + its right-hand-side chunks) x roundup(N, nb)) and the panel buffers. */
+int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb, g3_dtype dt);
+/* One evaluation (the multi-GPU g3_gp_factor_predict): every rank passes the SAME replicated device inputs
+ * X (N x d), delta (N), Xs (M x d).  out_host = [sum log L_ii, a^T a, potrf info of the first attempt, jitter tries,
+ * 1 if the 1e-10*I fallback was taken]; mean_host[i] = V_i . a, ss_host[i] = |V_i|^2 (all ranks get all M). */
+int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog_noise, const g3_kernel_prog* prog_cross,
+                              const void* X_dev, int64_t ldx, const void* delta_dev, const void* Xs_dev, int64_t ldxs,
+                              double out_host[5], double* mean_host, double* ss_host);
+/* After g3_dist_gp_factor_predict: posterior covariance K_f(Xs, Xs) - V V^T, its robust Cholesky and the latent draws
+ * loc + L_post Z (gaussian.py:75-97, elliptical.py:86-92).  loc_host (M), Z_host (M x S), out_host (M x S) are host
+ * arrays of the plan's dtype; every rank returns the same draws. */
+int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f, const void* Xs_dev, int64_t ldxs,
+                            const void* loc_host, const void* Z_host, int64_t S, void* out_host, int* tries_host,
+                            int* fallback_host);
+/* out_host[3k .. 3k+2] for k = 0 broadcast, 1 all-gather, 2 all-reduce: calls, bytes sent + received by this rank,
+ * device milliseconds inside the collective calls (HIP events on the stream each ran on).  Resets the counters. */
+int g3_dist_comm_stats(g3_dist* D, double out_host[9]);
+int g3_dist_local_rows(g3_dist* D, int64_t* rows_mat, int64_t* rows_rhs, int64_t* ld);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,3 +222,41 @@ def chain_worker(rank, world, port, N, d, rows, out_path):
             np.savez(out_path, got=got, ref=ref)
     finally:
         dist.destroy_process_group()
+
+
+def native_worker(rank, world, port, N, d, M, nb, transport, spec_f, noise, out_path, dup=False, draws=0, dtype='f64'):
+    """one rank of the driver INSIDE libg3hip (g3_dist_*): transport 'callbacks' lets `world` ranks share cuda:0 over
+    gloo (host-staged collectives), 'rccl' is the product transport (one rank per GPU: world 1 on a one-GPU box)"""
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        from g3py_amd.distributed import NativeDistributedGP
+        from oracle import g3_oracle as orc
+        X, y, Xs = synth(N, d, M, 77)
+        if dup:
+            X[1::2] = X[0::2][:len(X[1::2])]
+            y = np.sin(X.sum(1) / np.sqrt(d))
+        spec_n = orc.with_noise(spec_f, noise) if noise is not None else spec_f
+        npdt = np.float32 if dtype == 'f32' else np.float64
+        dev = g3.Device(0)
+        dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, dtype=npdt, transport=transport)
+        Xd, Xsd, yd = dev.upload(X.astype(npdt)), dev.upload(Xs.astype(npdt)), dev.upload(y.astype(npdt))
+        Z = np.random.default_rng(5).standard_normal((M, draws)) if draws else None
+        lp = dgp.step(spec_n, spec_f, Xd, Xsd, yd, Z=Z)
+        lp2 = dgp.step(spec_n, spec_f, Xd, Xsd, yd)          # a second evaluation on the same plan: same numbers
+        assert lp2 == lp or (np.isnan(lp) and np.isnan(lp2)), (lp, lp2)
+        cs = dgp.comm_stats()
+        if rank == 0:
+            prior = np.diag(orc.kernel_cov(spec_f, Xs))
+            np.savez(out_path, logp=lp, mean=dgp.last['mean'], var=np.maximum(prior - dgp.last['ss'], 0),
+                     tries=dgp.last['tries'], fallback=dgp.last['fallback'],
+                     draws=dgp.last['draws'] if draws else np.zeros(0),
+                     comm_calls=sum(v['calls'] for v in cs.values()), comm_bytes=sum(v['bytes'] for v in cs.values()))
+        dgp.close()
+    finally:
+        dist.destroy_process_group()
