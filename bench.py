@@ -280,8 +280,15 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    # one rank per GPU; G3_DIST_BACKEND=gloo (rehearsal of N>1 on a one-GPU box) lets ranks share a device
+    # One rank per GPU.  G3_DIST_DRIVER=native (default): the multi-GPU driver INSIDE libg3hip (g3_dist_*: the library
+    # owns the RCCL communicators, streams and the per-panel loop); torch.distributed over gloo only carries the
+    # 2 x 128 communicator-id bytes, the barriers and the max-over-ranks of the timing.  G3_DIST_DRIVER=python: the
+    # torch.distributed driver (g3py_amd/distributed.py::DistributedGP) over ProcessGroupNCCL.  If the native driver
+    # cannot be created on some rank (no librccl ...) every rank falls back to the python driver together.
+    # G3_DIST_BACKEND=gloo (python driver only) rehearses N > 1 on a one-GPU box: ranks may then share a device.
+    driver = os.environ.get('G3_DIST_DRIVER', 'native')
     backend = os.environ.get('G3_DIST_BACKEND', 'nccl')
+    native_transport = 'callbacks' if backend == 'gloo' else 'rccl'   # gloo + native: host-staged collectives (rehearsal)
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
@@ -290,9 +297,10 @@ def main():
                          'several ranks on one GPU)' % (world, world, ndev))
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    # G3_FORCE_DIST=1 G3_DIST_COLLECTIVES=1 on one GPU: the multi-rank driver with ONE rank whose collectives
-    # really go through ProcessGroupNCCL = RCCL (stream semantics, work handles, the second communicator)
-    solo_pg = world == 1 and os.environ.get('G3_FORCE_DIST', '0') == '1' and os.environ.get('G3_DIST_COLLECTIVES', '0') == '1'
+    # G3_FORCE_DIST=1 on one GPU: the multi-rank driver with ONE rank.  The native driver then still creates its RCCL
+    # communicators and issues every collective; the python driver does so with G3_DIST_COLLECTIVES=1
+    force_dist = os.environ.get('G3_FORCE_DIST', '0') == '1'
+    solo_pg = world == 1 and force_dist and driver == 'python' and os.environ.get('G3_DIST_COLLECTIVES', '0') == '1'
     if solo_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if 'MASTER_PORT' not in os.environ:
@@ -301,7 +309,9 @@ def main():
                 s_.bind(('127.0.0.1', 0))
                 os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
     if world > 1 or solo_pg:
-        if backend == 'nccl':
+        if driver == 'native':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        elif backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -393,10 +403,31 @@ def main():
             result['stats'] = st
         parallelism = '1gpu'
     else:
-        from g3py_amd.distributed import DistributedGP
+        from g3py_amd.distributed import DistributedGP, NativeDistributedGP
         if args.nb <= 0:
             args.nb = 1024 if world <= 4 else 512
-        dgp = DistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, torch_device=tdev, dtype=npdt)
+        dgp = None
+        if driver == 'native':
+            why = ''
+            try:
+                dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, dtype=npdt, transport=native_transport)
+            except Exception as e:       # noqa: BLE001 -- any failure on any rank sends ALL ranks to the python driver
+                why = '%s: %s' % (type(e).__name__, e)
+            ok = torch.tensor([0 if dgp is None else 1], dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if dgp is not None:
+                    dgp.close()
+                    dgp = None
+                driver = 'python (native driver unavailable%s)' % ((': ' + why) if why else ' on another rank')
+                if rank == 0:
+                    print('bench.py: falling back to the torch.distributed driver -- ' + driver, file=sys.stderr)
+        if dgp is None:
+            gb = 'nccl' if (world > 1 and dist.get_backend() == 'gloo' and backend == 'nccl') else None
+            dgp = DistributedGP(dev, dist if (world > 1 or solo_pg) else None, rank, world, N, d, M, nb=args.nb, torch_device=tdev,
+                                dtype=npdt, group_backend=gb)
+        native = isinstance(dgp, NativeDistributedGP)
         result = {}
 
         def step():
@@ -409,13 +440,18 @@ def main():
                 result['logp'] = lp
             else:
                 result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
-        parallelism = 'row-block-cyclic x%d (nb=%d): RCCL diagonal-factor broadcast + panel all-gather, look-ahead' % (world, args.nb)
+        parallelism = 'row-block-cyclic x%d (nb=%d): RCCL diagonal-factor broadcast + panel all-gather, look-ahead; driver: %s' \
+            % (world, args.nb, 'libg3hip g3_dist_* (C++ loop, library-owned RCCL communicators)' if native else 'torch.distributed (' + str(driver) + ')')
 
     for _ in range(args.warmup):
         step()
     # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
     dev.prof_enable(0 if args.no_prof else (3 if use_dist else 1))
     dev.prof_reset()
+    if use_dist:
+        dgp.comm_stats()         # reset: the warm-up's lazy RCCL connection setup is not part of the timed steps
+    if use_dist and native and not args.no_prof:
+        dgp.prof_enable(2)       # every MFMA GEMM launch of the driver's bulk stream (two staircase launches per step)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -428,8 +464,13 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = dev.prof_collect()
     dev.prof_enable(False)
+    if use_dist and native and not args.no_prof:
+        pb = dgp.prof_collect()
+        for k_ in pb:            # the bulk stream's launches are where a rank's flops are
+            for f_ in ('count', 'ms', 'work'):
+                prof[k_][f_] += pb[k_][f_]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=tdt, device=tdev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     comm_all = None
@@ -457,12 +498,19 @@ def main():
             'e2e_sec': sec, 'logp': float(result['logp']),
         }
         if comm_all is not None:
-            out['comm'] = {'per_rank': [{k: {'calls_per_step': v['calls'] / args.steps, 'bytes_per_step': v['bytes'] / args.steps,
-                                             'host_wait_s_per_step': v['wait_s'] / args.steps} for k, v in r.items()}
-                                        for r in comm_all],
-                           'collectives_forced_at_world_1': bool(solo_pg), 'backend': backend,
-                           'note': 'bytes = sent + received by the rank; host_wait = host time inside work.wait() / blocking '
-                                   'all-reduces (RCCL waits are stream dependencies: ~0 unless the host is the bottleneck)'}
+            def per(v):
+                o = {'calls_per_step': v['calls'] / args.steps, 'bytes_per_step': v['bytes'] / args.steps}
+                if 'device_ms' in v:
+                    o['device_ms_per_step'] = v['device_ms'] / args.steps
+                else:
+                    o['host_wait_s_per_step'] = v['wait_s'] / args.steps
+                return o
+            out['comm'] = {'per_rank': [{k: per(v) for k, v in r.items()} for r in comm_all],
+                           'driver': 'native' if native else 'python', 'collectives_forced_at_world_1': bool(solo_pg or (native and world == 1)),
+                           'transport': ('rccl (library-owned communicators)' if native_transport == 'rccl' else 'host callbacks over gloo (rehearsal)') if native else backend,
+                           'note': 'bytes = sent + received by the rank; device_ms = HIP-event time of the collective calls on '
+                                   'the stream each ran on (native driver); host_wait = host time inside work.wait() / blocking '
+                                   'all-reduces (python driver: RCCL waits are stream dependencies, ~0 unless the host is the bottleneck)'}
         if S > 0:
             dr = result['draws']
             out['metric'] += ' (+ posterior covariance, its Cholesky and %d draws)' % S
@@ -488,8 +536,9 @@ def main():
         if use_dist:
             # the row-block layout issues per-block updates (m = nb rows): a 1-in-16 sample of the MFMA GEMM launches of rank 0
             g = {k: sum(prof[t][k] for t in ('gemm_bulk', 'gemm_mid', 'gemm_small')) for k in ('count', 'ms', 'work')}
-            kern = 'gemm_nt_kernel<%s,*>: 1-in-16 sample of the MFMA GEMM launches of rank 0 (trailing updates and panel solves of ' \
-                   'its row blocks)' % ('float' if args.f32 else 'double')
+            kern = ('gemm_nt_kernel<%s,*>: rank 0, every staircase launch of the bulk stream + a 1-in-16 sample of the chain ' \
+                    "stream's MFMA GEMM launches" if native else 'gemm_nt_kernel<%s,*>: 1-in-16 sample of the MFMA GEMM launches of ' \
+                    'rank 0 (trailing updates and panel solves of its row blocks)') % ('float' if args.f32 else 'double')
         if g['count'] and g['ms'] > 0:
             ach = g['work'] / (g['ms'] * 1e-3) / 1e12
             peak = FP32_MATRIX_PEAK_TFLOPS if args.f32 else FP64_MATRIX_PEAK_TFLOPS
@@ -566,10 +615,12 @@ def main():
     # every rank learns the verdict BEFORE the group is torn down, so a failed pin ends all ranks at once
     # instead of leaving the others to the launcher's timeout
     if world > 1:
-        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=tdev)
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=tdev if dist.get_backend() == 'nccl' else 'cpu')
         dist.broadcast(flag, src=0)
         if int(flag.item()) and not failed:
             failed = 'bench.py: rank 0 reported a failed oracle pin'
+    if use_dist and native:
+        dgp.close()                       # communicators and driver buffers, before the contexts they live on
     if world > 1 or solo_pg:
         dist.destroy_process_group()
     # explicit teardown while the HIP runtime is alive (streams, events, pinned buffers, workspaces)

@@ -80,7 +80,7 @@ _SIGS = {
     'g3_gemm_nt': ([_P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, C.c_double, C.c_double, C.c_int,
                     C.c_int], C.c_int),
     'g3_gemm_nt_stair': ([_P, _P, _I64, _P, _I64, _P, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), C.c_int,
-                          C.c_double, C.c_double, C.c_int, _I64, C.POINTER(C.c_int32), C.c_int], C.c_int),
+                          C.c_double, C.c_double, C.c_int, _I64, C.POINTER(C.c_int32), C.c_int, C.POINTER(_I64)], C.c_int),
     'g3_potrf': ([_P, _P, _I64, _I64, C.c_int, _P, C.POINTER(C.c_int)], C.c_int),
     'g3_potrf_nowait': ([_P, _P, _I64, _I64, C.c_int, _P, _P], C.c_int),
     'g3_potrf_robust': ([_P, _P, _I64, _P, _I64, _I64, C.c_int, C.c_int, C.POINTER(C.c_int),
@@ -118,6 +118,8 @@ _SIGS = {
     'g3_dist_posterior_draws': ([_P, C.POINTER(KernelProg), _P, _I64, _P, _P, _I64, _P, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)], C.c_int),
     'g3_dist_comm_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
+    'g3_dist_prof_enable': ([_P, C.c_int], C.c_int),
+    'g3_dist_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),
     'g3_dist_local_rows': ([_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)], C.c_int),
     'g3_prof_enable': ([_P, C.c_int], C.c_int),
     'g3_prof_reset': ([_P], C.c_int),

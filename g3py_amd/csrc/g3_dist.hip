@@ -563,14 +563,15 @@ static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_tmp, hip
 }
 
 static int stair(g3_dist* D, g3_ctx* cx, int64_t row0, int64_t col0, int64_t kcol, const char* G, const std::vector<int64_t>& seg_rows,
-                 const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm) {
+                 const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm, const std::vector<int64_t>* seg_diag = nullptr) {
   // C[rows_s, col0 : col0 + seg_cols[s]) -= A[rows_s, kcol : kcol + nb) G[block table]^T, cut into launches of at
   // most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
   std::vector<G3hStairChunk> ch;
-  g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch);
+  g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch, seg_diag);
   for (const auto& c : ch) {
     G3D_RC(cx, g3_gemm_nt_stair(cx, Aat(D, row0 + c.row0, col0 + c.col0), D->Np, Aat(D, row0 + c.row0, kcol), D->Np, G, D->nb, D->nb,
-                                c.rows.data(), c.cols.data(), (int)c.rows.size(), -1.0, 1.0, D->dt, D->nb, perm + c.blk0, c.nblk));
+                                c.rows.data(), c.cols.data(), (int)c.rows.size(), -1.0, 1.0, D->dt, D->nb, perm + c.blk0, c.nblk,
+                                seg_diag ? c.diag.data() : nullptr));
   }
   return G3_OK;
 }
@@ -598,7 +599,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
   }
   hipEvent_t ev_prev = nullptr;
   std::vector<int32_t> perm;
-  std::vector<int64_t> seg_rows, seg_cols;
+  std::vector<int64_t> seg_rows, seg_cols, seg_diag;
   for (int k = 0; k + 1 < nblk; ++k) {
     const int64_t c0 = (int64_t)k * nb, c1 = c0 + nb, c2 = c1 + nb, c3 = c2 + nb;
     perm_of(D, k, &perm);
@@ -609,23 +610,23 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
     if (rc) return rc;
     if (k + 2 < nblk) {
       // d1. block column k+2 (block k+2's diagonal block included: the look-ahead adds panel k+1 only)
-      seg_rows.clear(); seg_cols.clear();
+      seg_rows.clear(); seg_cols.clear(); seg_diag.clear();
       int64_t lo = -1;
-      for (int I : D->my_blocks) if (I >= k + 2) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back(nb); }
-      if (D->rows_rhs > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back(nb); }
+      for (int I : D->my_blocks) if (I >= k + 2) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back(nb); seg_diag.push_back(I == k + 2); }
+      if (D->rows_rhs > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back(nb); seg_diag.push_back(0); }
       if (!seg_rows.empty()) {
-        rc = stair(D, D->ctx_bulk, lo, c2, c0, G, seg_rows, seg_cols, perm.data() + 1, 1);
+        rc = stair(D, D->ctx_bulk, lo, c2, c0, G, seg_rows, seg_cols, perm.data() + 1, 1, &seg_diag);
         if (rc) return rc;
       }
       ev_k = D->ev[k];
       G3D_HIP(hipEventRecord(ev_k, sB));
       // d2. the rest: block columns >= k+3 of my blocks >= k+3 and of the right-hand-side rows
-      seg_rows.clear(); seg_cols.clear();
+      seg_rows.clear(); seg_cols.clear(); seg_diag.clear();
       lo = -1;
-      for (int I : D->my_blocks) if (I >= k + 3) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back((int64_t)(I - k - 2) * nb); }
-      if (D->rows_rhs > 0 && nblk - k - 3 > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back((int64_t)(nblk - k - 3) * nb); }
+      for (int I : D->my_blocks) if (I >= k + 3) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back((int64_t)(I - k - 2) * nb); seg_diag.push_back(1); }
+      if (D->rows_rhs > 0 && nblk - k - 3 > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back((int64_t)(nblk - k - 3) * nb); seg_diag.push_back(0); }
       if (!seg_rows.empty()) {
-        rc = stair(D, D->ctx_bulk, lo, c3, c0, G, seg_rows, seg_cols, perm.data() + 2, (int)perm.size() - 2);
+        rc = stair(D, D->ctx_bulk, lo, c3, c0, G, seg_rows, seg_cols, perm.data() + 2, (int)perm.size() - 2, &seg_diag);
         if (rc) return rc;
       }
     }
@@ -897,7 +898,7 @@ extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f,
     g3h_stair_chunks(sr, sc, pad, nch, &ch);
     for (const auto& cc : ch)
       G3D_TRY(g3_gemm_nt_stair(D->ctx, rows + (size_t)cc.col0 * es, Mp, sendb, Np, Vall, Np, Np, cc.rows.data(), cc.cols.data(),
-                               (int)cc.rows.size(), -1.0, 1.0, D->dt, pad, perm.data() + cc.blk0, cc.nblk));
+                               (int)cc.rows.size(), -1.0, 1.0, D->dt, pad, perm.data() + cc.blk0, cc.nblk, nullptr));
   }
   G3D_TRY(do_allgather(D, rows, call, (size_t)cmax * pad * Mp * es, s));
   for (int c = 0; c < nch; ++c)
@@ -937,6 +938,20 @@ extern "C" int g3_dist_comm_stats(g3_dist* D, double out_host[9]) {
   }
   D->tused = 0;
   return G3_OK;
+}
+
+// HIP-event profiling of the bulk stream's MFMA GEMM launches (the staircase updates: where the flops of a rank
+// are), same tags and output layout as g3_prof_collect
+extern "C" int g3_dist_prof_enable(g3_dist* D, int on) {
+  if (!D) return -1;
+  int rc = g3_prof_enable(D->ctx_bulk, on);
+  if (!rc) rc = g3_prof_reset(D->ctx_bulk);
+  return rc;
+}
+extern "C" int g3_dist_prof_collect(g3_dist* D, double* out_host) {
+  if (!D) return -1;
+  if (!out_host) return -2;
+  return g3_prof_collect(D->ctx_bulk, out_host);
 }
 
 // rows x cols view of the rank's local matrix (tests / debugging): copies A[row0 : row0 + rows, 0 : cols) to the host

@@ -22,12 +22,9 @@
 #include <stdlib.h>
 
 #include "g3_mfma.h"
+#include "g3_host.h"
 
 constexpr int ROWB = 128;  // bytes of K per LDS row and per stage
-// row tiles per raster group.  Measured on a 30720^2 x 1024 lower-triangular update (rocprofv3 --pmc
-// FETCH_SIZE, profiles/r02_summary.md): 2 -> 66.8 TFLOP/s, 23.0 GB fetched; 4 -> 66.3, 22.6 GB;
-// 8 -> 65.9, 24.7 GB; 16 -> 64.8, 28.2 GB
-constexpr int GROUP_M = 4;
 // LDS buffers per tile configuration.  Two everywhere: deeper pipelines (four buffers) were measured on
 // the small tiles and LOST -- 64 / 80 KiB of LDS per workgroup no longer fits into the slot a retiring
 // bulk workgroup leaves behind, so the critical-path launches wait for several to retire at once
@@ -37,30 +34,6 @@ constexpr int STAGES = 2;
 #ifndef G3_GEMM_ORDER
 #define G3_GEMM_ORDER 1   // 1: fragment reads before the DMA issue in the K loop (0: the round-2 order, kept for A/B builds)
 #endif
-
-// ---- tile raster.  The host describes the ACTIVE tiles of a launch as a list of row groups (a few
-// consecutive row tiles each) with a column-tile count per group; the table travels by value in the
-// kernel arguments.  This one mechanism covers dense products, lower-triangular / trapezoidal
-// updates of the factorisation (column count grows with the row, `diag_off` masks the elements above
-// the shifted diagonal) and the multi-GPU "staircase" (a rank's row blocks, each with its own
-// width, updated by ONE launch).  Tiles that are not wanted are never launched.
-constexpr int G3_RASTER_MAX = 160;
-constexpr int G3_DENSE_OFF = 1 << 30;
-struct RasterTab {
-  int ngroups;
-  int diag_off;                             // element (row, col) is wanted iff col <= row + diag_off
-  // per group, packed so that the search and the payload of a small launch share one cache line
-  // (the table is read with dependent scalar loads at the start of every workgroup)
-  struct Group {
-    int prefix;                             // first virtual tile id of the group; g[ngroups].prefix = grid size
-    unsigned short row0;                    // first row tile
-    unsigned short nrows;                   // row tiles in the group (its tiles are ordered column-major)
-  } g[G3_RASTER_MAX + 1];
-  // optional row-block permutation of B: logical block s (b_nb rows) lives at physical block
-  // b_blk[s] -- the gathered panel of the multi-GPU sweep arrives rank-major, not in global order
-  int b_nb;                                 // 0: B is in logical order
-  unsigned short b_blk[G3_RASTER_MAX];
-};
 
 // One output tile: C[m0.., n0..] = alpha * A_rows * B_rows^T + beta * C, with gA / gB the first row of the
 // tile's A / B operand (k contiguous).  Shared by the GEMM kernel (one tile per workgroup) and the
@@ -336,18 +309,6 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
 // overwritten)  and  update  X_hi -= X_lo L_hi,lo^T.  Each step reads what earlier steps of the SAME
 // workgroup wrote; the barrier between steps carries workgroup-scope release / acquire.  Replaces the
 // 2 n/128 - 1 launches of the recursive solve on the factorisation's critical path.
-constexpr int G3_TRSM_MAXOPS = 20;          // n <= 1024: 8 leaves + 12 update tiles of 128 columns
-struct TrsmOps {
-  int nops;
-  struct Op {      // one 32 x 128 output tile
-    int col;       // first column of the tile written
-    int acol;      // first column of the left operand (leaf: col)
-    int k;         // reduction length
-    int brow, bcol;  // leaf: index of the 128 x 128 inverse block (bcol unused); update: row / column of the L block
-    int leaf;
-  } op[G3_TRSM_MAXOPS];
-};
-
 template <typename T, int BM>
 __global__ void __launch_bounds__(256, 2)
 trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const int* __restrict__ info,
@@ -369,99 +330,6 @@ trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const
   }
 }
 
-
-// ---- host side: which elements of C a launch produces
-struct GemmShape {
-  int kind;                 // 0 dense, 1 trapezoid (col <= row + off), 2 staircase (row segments with own widths)
-  int64_t m, n;             // extent of C in elements (staircase: m = sum of segment rows, n = widest segment)
-  int64_t off;              // trapezoid: diagonal offset in elements
-  int nseg;                 // staircase
-  const int64_t* seg_rows;
-  const int64_t* seg_cols;
-  int64_t b_nb;             // rows per permuted block of B (0: none)
-  const int32_t* b_perm;    // physical block of logical block s
-  int nperm;
-};
-
-static double shape_elems(const GemmShape& sh) {
-  if (sh.kind == 0) return (double)sh.m * (double)sh.n;
-  if (sh.kind == 2) {
-    double e = 0;
-    for (int s = 0; s < sh.nseg; ++s) e += (double)sh.seg_rows[s] * (double)sh.seg_cols[s];
-    return e;
-  }
-  // sum_{i < m} clamp(i + off + 1, 0, n)
-  int64_t i0 = sh.off < 0 ? -sh.off : 0;           // first row with a wanted element: i + off + 1 >= 1
-  if (i0 > sh.m) i0 = sh.m;
-  int64_t i1 = sh.n - 1 - sh.off;                  // first row that is full width
-  if (i1 < i0) i1 = i0;
-  if (i1 > sh.m) i1 = sh.m;
-  const double cnt = (double)(i1 - i0);
-  const double tri = cnt * ((double)i0 + (double)sh.off + 1.0) + 0.5 * cnt * (cnt - 1.0);
-  return tri + (double)(sh.m - i1) * (double)sh.n;
-}
-
-// Build the raster table for BM x BN tiles.  Returns the grid size, or -1 when the launch needs more
-// than G3_RASTER_MAX groups (staircases with very many segments: the caller splits the launch).
-template <int BM, int BN>
-static long long build_raster(const GemmShape& sh, RasterTab* tab) {
-  const int64_t tiles_m = sh.m / BM;
-  tab->diag_off = sh.kind == 1 ? (int)sh.off : G3_DENSE_OFF;
-  int ng = 0;
-  long long total = 0;
-  auto push = [&](int64_t row_tile0, int64_t rows, int64_t nc) -> bool {
-    if (rows <= 0 || nc <= 0) return true;
-    if (ng >= G3_RASTER_MAX) return false;
-    tab->g[ng].prefix = (int)total;
-    tab->g[ng].row0 = (unsigned short)row_tile0;
-    tab->g[ng].nrows = (unsigned short)rows;
-    total += rows * nc;
-    ++ng;
-    return true;
-  };
-  if (sh.kind == 2) {
-    int64_t rt = 0;
-    // group height: GROUP_M row tiles unless that needs too many groups
-    int64_t ngroups_min = 0;
-    for (int s = 0; s < sh.nseg; ++s) ngroups_min += (sh.seg_rows[s] / BM + GROUP_M - 1) / GROUP_M;
-    const int64_t gh = ngroups_min <= G3_RASTER_MAX ? GROUP_M : GROUP_M * ((ngroups_min + G3_RASTER_MAX - 1) / G3_RASTER_MAX + 1);
-    for (int s = 0; s < sh.nseg; ++s) {
-      const int64_t st = sh.seg_rows[s] / BM, nc = sh.seg_cols[s] / BN;
-      for (int64_t t = 0; t < st; t += gh) {
-        // groups never span segments; a group's row tiles are consecutive, so an empty segment in
-        // between simply starts a new group
-        if (!push(rt + t, (st - t < gh ? st - t : gh), nc)) return -1;
-      }
-      rt += st;
-    }
-  } else {
-    const int64_t tiles_n = sh.n / BN;
-    int64_t gh = GROUP_M;
-    if ((tiles_m + gh - 1) / gh > G3_RASTER_MAX) gh = (tiles_m + G3_RASTER_MAX - 1) / G3_RASTER_MAX;
-    if (gh > 65535) return -1;
-    for (int64_t t = 0; t < tiles_m; t += gh) {
-      const int64_t rows = tiles_m - t < gh ? tiles_m - t : gh;
-      int64_t nc = tiles_n;
-      if (sh.kind == 1) {
-        const int64_t lim = (t + rows) * BM - 1 + sh.off;   // last wanted column of the group's last row
-        nc = lim < 0 ? 0 : lim / BN + 1;
-        if (nc > tiles_n) nc = tiles_n;
-      }
-      if (!push(t, rows, nc)) return -1;
-    }
-  }
-  tab->ngroups = ng;
-  tab->g[ng].prefix = (int)total;
-  tab->g[ng].row0 = 0;
-  tab->g[ng].nrows = 1;
-  tab->b_nb = 0;
-  if (sh.b_nb > 0 && sh.b_perm) {
-    if (sh.nperm > G3_RASTER_MAX || sh.b_nb % BN) return -1;
-    tab->b_nb = (int)sh.b_nb;
-    for (int i = 0; i < sh.nperm; ++i) tab->b_blk[i] = (unsigned short)sh.b_perm[i];
-  }
-  return total;
-}
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
@@ -588,7 +456,7 @@ int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda
                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                    g3_dtype dt, int lower_only, int wide) {
   if (m == 0 || n == 0) return G3_OK;
-  const GemmShape sh{lower_only ? 1 : 0, m, n, 0, 0, nullptr, nullptr, 0, nullptr, 0};
+  const GemmShape sh{lower_only ? 1 : 0, m, n, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, wide);
 }
 
@@ -604,34 +472,11 @@ int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t l
                      int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                      g3_dtype dt, int64_t diag_off) {
   if (m == 0 || n == 0) return G3_OK;
-  const GemmShape sh{1, m, n, diag_off, 0, nullptr, nullptr, 0, nullptr, 0};
+  const GemmShape sh{1, m, n, diag_off, 0, nullptr, nullptr, 0, nullptr, 0, nullptr};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
 }
 
 // ---- stripe-local solve X <- X L^-T (X: m x n rows of a panel, n <= 1024, m % 32 == 0), one launch
-static int64_t trsm_split(int64_t n) {     // must mirror split_point() of g3_potrf.hip (same recursion shape)
-  int64_t g = G3_LB;
-  while (g * 2 <= n / 4 && g < 2048) g *= 2;
-  int64_t n1 = g3_roundup(n / 2, g);
-  if (n1 >= n) n1 = n - G3_LB;
-  return n1;
-}
-
-static void trsm_ops_rec(TrsmOps* ops, int64_t c0, int64_t n) {
-  if (n == G3_LB) {
-    auto& o = ops->op[ops->nops++];
-    o.col = (int)c0; o.acol = (int)c0; o.k = G3_LB; o.brow = (int)(c0 / G3_LB); o.bcol = 0; o.leaf = 1;
-    return;
-  }
-  const int64_t n1 = trsm_split(n), n2 = n - n1;
-  trsm_ops_rec(ops, c0, n1);
-  for (int64_t t = 0; t < n2; t += G3_LB) {       // X[:, c0+n1+t .. +128) -= X[:, c0 .. c0+n1) L[c0+n1+t .., c0 ..)^T
-    auto& o = ops->op[ops->nops++];
-    o.col = (int)(c0 + n1 + t); o.acol = (int)c0; o.k = (int)n1; o.brow = (int)(c0 + n1 + t); o.bcol = (int)c0; o.leaf = 0;
-  }
-  trsm_ops_rec(ops, c0 + n1, n2);
-}
-
 template <typename T, int BM>
 static int trsm_stripe_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* X, int64_t m, int64_t ldx, const T* W) {
   constexpr int LDS = STAGES * (BM + 128) * ROWB;
@@ -675,14 +520,15 @@ int g3i_trsm_stripe(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* X,
 // staircase: row segment s (seg_rows[s] rows, stacked) gets its first seg_cols[s] columns
 int g3i_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                       int64_t ldb, int64_t k, const int64_t* seg_rows, const int64_t* seg_cols, int nseg,
-                      double alpha, double beta, g3_dtype dt, int64_t b_nb, const int32_t* b_perm, int nperm) {
+                      double alpha, double beta, g3_dtype dt, int64_t b_nb, const int32_t* b_perm, int nperm,
+                      const int64_t* seg_diag) {
   int64_t m = 0, n = 0;
   for (int s = 0; s < nseg; ++s) {
     m += seg_rows[s];
     if (seg_cols[s] > n) n = seg_cols[s];
   }
   if (m == 0 || n == 0) return G3_OK;
-  const GemmShape sh{2, m, n, 0, nseg, seg_rows, seg_cols, b_nb, b_perm, nperm};
+  const GemmShape sh{2, m, n, 0, nseg, seg_rows, seg_cols, b_nb, b_perm, nperm, seg_diag};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
 }
 
@@ -715,7 +561,7 @@ extern "C" int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int6
 extern "C" int g3_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
                                 const void* B, int64_t ldb, int64_t k, const int64_t* seg_rows,
                                 const int64_t* seg_cols, int nseg, double alpha, double beta, g3_dtype dt,
-                                int64_t b_block_rows, const int32_t* b_perm, int nperm) {
+                                int64_t b_block_rows, const int32_t* b_perm, int nperm, const int64_t* seg_diag) {
   if (!ctx) return -1;
   g3_dev_guard _dg(ctx);
   if (!C) return -2;
@@ -731,6 +577,7 @@ extern "C" int g3_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A
   for (int s = 0; s < nseg; ++s) {
     if (seg_rows[s] < 0 || seg_rows[s] % 128) return -9;
     if (seg_cols[s] < 0 || seg_cols[s] % 128) return -10;
+    if (seg_diag && seg_diag[s] && seg_cols[s] < seg_rows[s]) return -18;   // a diagonal block needs seg_rows[s] columns
     m += seg_rows[s];
     if (seg_cols[s] > n) n = seg_cols[s];
   }
@@ -748,5 +595,5 @@ extern "C" int g3_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A
   int rc = g3i_reset_info(ctx);
   if (rc) return rc;
   return g3i_gemm_nt_stair(ctx, C, ldc, A, lda, B, ldb, k, seg_rows, seg_cols, nseg, alpha, beta, dt,
-                           b_perm ? b_block_rows : 0, b_perm, b_perm ? nperm : 0);
+                           b_perm ? b_block_rows : 0, b_perm, b_perm ? nperm : 0, seg_diag);
 }

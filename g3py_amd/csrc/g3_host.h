@@ -7,6 +7,8 @@
 
 #include <vector>
 
+static_assert(true, "");
+
 #define G3H_LB 128   // = G3_LB: width of the diagonal block one kernel factors
 
 static inline int64_t g3h_roundup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
@@ -47,6 +49,183 @@ static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, std
   grp->push_back(nblk);
 }
 
+// ---- tile raster.  The host describes the ACTIVE tiles of a launch as a list of row groups (a few
+// consecutive row tiles each) with a column-tile count per group; the table travels by value in the
+// kernel arguments.  This one mechanism covers dense products, lower-triangular / trapezoidal
+// updates of the factorisation (column count grows with the row, `diag_off` masks the elements above
+// the shifted diagonal) and the multi-GPU "staircase" (a rank's row blocks, each with its own
+// width, updated by ONE launch).  Tiles that are not wanted are never launched.
+// row tiles per raster group.  Measured on a 30720^2 x 1024 lower-triangular update (rocprofv3 --pmc
+// FETCH_SIZE, profiles/r02_summary.md): 2 -> 66.8 TFLOP/s, 23.0 GB fetched; 4 -> 66.3, 22.6 GB;
+// 8 -> 65.9, 24.7 GB; 16 -> 64.8, 28.2 GB
+constexpr int GROUP_M = 4;
+constexpr int G3_RASTER_MAX = 160;
+constexpr int G3_DENSE_OFF = 1 << 30;
+struct RasterTab {
+  int ngroups;
+  int diag_off;                             // element (row, col) is wanted iff col <= row + diag_off
+  // per group, packed so that the search and the payload of a small launch share one cache line
+  // (the table is read with dependent scalar loads at the start of every workgroup)
+  struct Group {
+    int prefix;                             // first virtual tile id of the group; g[ngroups].prefix = grid size
+    unsigned short row0;                    // first row tile
+    unsigned short nrows;                   // row tiles in the group (its tiles are ordered column-major)
+  } g[G3_RASTER_MAX + 1];
+  // optional row-block permutation of B: logical block s (b_nb rows) lives at physical block
+  // b_blk[s] -- the gathered panel of the multi-GPU sweep arrives rank-major, not in global order
+  int b_nb;                                 // 0: B is in logical order
+  unsigned short b_blk[G3_RASTER_MAX];
+};
+
+
+// ---- host side: which elements of C a launch produces
+struct GemmShape {
+  int kind;                 // 0 dense, 1 trapezoid (col <= row + off), 2 staircase (row segments with own widths)
+  int64_t m, n;             // extent of C in elements (staircase: m = sum of segment rows, n = widest segment)
+  int64_t off;              // trapezoid: diagonal offset in elements
+  int nseg;                 // staircase
+  const int64_t* seg_rows;
+  const int64_t* seg_cols;
+  int64_t b_nb;             // rows per permuted block of B (0: none)
+  const int32_t* b_perm;    // physical block of logical block s
+  int nperm;
+  // staircase: seg_diag[s] != 0 says the LAST seg_rows[s] columns of segment s are its square diagonal block, of
+  // which only the lower triangle is wanted: tiles entirely above it are not launched (the elements above the
+  // diagonal inside a launched tile are still written -- the strict upper part of a diagonal block is scratch)
+  const int64_t* seg_diag;
+};
+
+static inline double shape_elems(const GemmShape& sh) {
+  if (sh.kind == 0) return (double)sh.m * (double)sh.n;
+  if (sh.kind == 2) {
+    double e = 0;
+    for (int s = 0; s < sh.nseg; ++s) {
+      e += (double)sh.seg_rows[s] * (double)sh.seg_cols[s];
+      if (sh.seg_diag && sh.seg_diag[s] && sh.seg_cols[s] >= sh.seg_rows[s])   // algorithmic count: the lower triangle only
+        e -= 0.5 * (double)sh.seg_rows[s] * ((double)sh.seg_rows[s] - 1.0);
+    }
+    return e;
+  }
+  // sum_{i < m} clamp(i + off + 1, 0, n)
+  int64_t i0 = sh.off < 0 ? -sh.off : 0;           // first row with a wanted element: i + off + 1 >= 1
+  if (i0 > sh.m) i0 = sh.m;
+  int64_t i1 = sh.n - 1 - sh.off;                  // first row that is full width
+  if (i1 < i0) i1 = i0;
+  if (i1 > sh.m) i1 = sh.m;
+  const double cnt = (double)(i1 - i0);
+  const double tri = cnt * ((double)i0 + (double)sh.off + 1.0) + 0.5 * cnt * (cnt - 1.0);
+  return tri + (double)(sh.m - i1) * (double)sh.n;
+}
+
+// Build the raster table for BM x BN tiles.  Returns the grid size, or -1 when the launch needs more
+// than G3_RASTER_MAX groups (staircases with very many segments: the caller splits the launch).
+template <int BM, int BN>
+static inline long long build_raster(const GemmShape& sh, RasterTab* tab) {
+  const int64_t tiles_m = sh.m / BM;
+  tab->diag_off = sh.kind == 1 ? (int)sh.off : G3_DENSE_OFF;
+  int ng = 0;
+  long long total = 0;
+  auto push = [&](int64_t row_tile0, int64_t rows, int64_t nc) -> bool {
+    if (rows <= 0 || nc <= 0) return true;
+    if (ng >= G3_RASTER_MAX) return false;
+    tab->g[ng].prefix = (int)total;
+    tab->g[ng].row0 = (unsigned short)row_tile0;
+    tab->g[ng].nrows = (unsigned short)rows;
+    total += rows * nc;
+    ++ng;
+    return true;
+  };
+  if (sh.kind == 2) {
+    int64_t rt = 0;
+    // group height: GROUP_M row tiles unless that needs too many groups
+    int64_t ngroups_min = 0;
+    for (int s = 0; s < sh.nseg; ++s) ngroups_min += (sh.seg_rows[s] / BM + GROUP_M - 1) / GROUP_M;
+    const int64_t gh = ngroups_min <= G3_RASTER_MAX ? GROUP_M : GROUP_M * ((ngroups_min + G3_RASTER_MAX - 1) / G3_RASTER_MAX + 1);
+    for (int s = 0; s < sh.nseg; ++s) {
+      const int64_t st = sh.seg_rows[s] / BM, nc = sh.seg_cols[s] / BN;
+      const bool dg = sh.seg_diag && sh.seg_diag[s] && sh.seg_cols[s] >= sh.seg_rows[s];
+      const int64_t dcol0 = sh.seg_cols[s] - sh.seg_rows[s];      // first column of the diagonal block
+      for (int64_t t = 0; t < st; t += gh) {
+        // groups never span segments; a group's row tiles are consecutive, so an empty segment in
+        // between simply starts a new group
+        const int64_t rows = st - t < gh ? st - t : gh;
+        int64_t ncg = nc;
+        if (dg) {     // columns up to the diagonal element of the group's last row
+          ncg = (dcol0 + (t + rows) * BM - 1) / BN + 1;
+          if (ncg > nc) ncg = nc;
+        }
+        if (!push(rt + t, rows, ncg)) return -1;
+      }
+      rt += st;
+    }
+  } else {
+    const int64_t tiles_n = sh.n / BN;
+    int64_t gh = GROUP_M;
+    if ((tiles_m + gh - 1) / gh > G3_RASTER_MAX) gh = (tiles_m + G3_RASTER_MAX - 1) / G3_RASTER_MAX;
+    if (gh > 65535) return -1;
+    for (int64_t t = 0; t < tiles_m; t += gh) {
+      const int64_t rows = tiles_m - t < gh ? tiles_m - t : gh;
+      int64_t nc = tiles_n;
+      if (sh.kind == 1) {
+        const int64_t lim = (t + rows) * BM - 1 + sh.off;   // last wanted column of the group's last row
+        nc = lim < 0 ? 0 : lim / BN + 1;
+        if (nc > tiles_n) nc = tiles_n;
+      }
+      if (!push(t, rows, nc)) return -1;
+    }
+  }
+  tab->ngroups = ng;
+  tab->g[ng].prefix = (int)total;
+  tab->g[ng].row0 = 0;
+  tab->g[ng].nrows = 1;
+  tab->b_nb = 0;
+  if (sh.b_nb > 0 && sh.b_perm) {
+    if (sh.nperm > G3_RASTER_MAX || sh.b_nb % BN) return -1;
+    tab->b_nb = (int)sh.b_nb;
+    for (int i = 0; i < sh.nperm; ++i) tab->b_blk[i] = (unsigned short)sh.b_perm[i];
+  }
+  return total;
+}
+
+
+// ---- stripe-local triangular solve: the op list of one launch (g3_gemm.hip::trsm_stripe_kernel)
+constexpr int G3_TRSM_MAXOPS = 20;          // n <= 1024: 8 leaves + 12 update tiles of 128 columns
+struct TrsmOps {
+  int nops;
+  struct Op {      // one 32 x 128 output tile
+    int col;       // first column of the tile written
+    int acol;      // first column of the left operand (leaf: col)
+    int k;         // reduction length
+    int brow, bcol;  // leaf: index of the 128 x 128 inverse block (bcol unused); update: row / column of the L block
+    int leaf;
+  } op[G3_TRSM_MAXOPS];
+};
+
+
+static inline int64_t trsm_split(int64_t n) {     // must mirror split_point() of g3_potrf.hip (same recursion shape)
+  int64_t g = G3H_LB;
+  while (g * 2 <= n / 4 && g < 2048) g *= 2;
+  int64_t n1 = g3h_roundup(n / 2, g);
+  if (n1 >= n) n1 = n - G3H_LB;
+  return n1;
+}
+
+static inline void trsm_ops_rec(TrsmOps* ops, int64_t c0, int64_t n) {
+  if (n == G3H_LB) {
+    auto& o = ops->op[ops->nops++];
+    o.col = (int)c0; o.acol = (int)c0; o.k = G3H_LB; o.brow = (int)(c0 / G3H_LB); o.bcol = 0; o.leaf = 1;
+    return;
+  }
+  const int64_t n1 = trsm_split(n), n2 = n - n1;
+  trsm_ops_rec(ops, c0, n1);
+  for (int64_t t = 0; t < n2; t += G3H_LB) {       // X[:, c0+n1+t .. +128) -= X[:, c0 .. c0+n1) L[c0+n1+t .., c0 ..)^T
+    auto& o = ops->op[ops->nops++];
+    o.col = (int)(c0 + n1 + t); o.acol = (int)c0; o.k = (int)n1; o.brow = (int)(c0 + n1 + t); o.bcol = (int)c0; o.leaf = 0;
+  }
+  trsm_ops_rec(ops, c0 + n1, n2);
+}
+
+
 // ---- staircase launches of the multi-GPU sweep.  One launch describes at most G3H_STAIR_MAX row segments and
 // G3H_STAIR_MAX blocks of the B operand (the raster table travels in the kernel arguments, g3_gemm.hip::RasterTab):
 // a longer staircase -- N / nb > 160 row blocks -- is cut into row chunks and column chunks.
@@ -54,6 +233,7 @@ static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, std
 struct G3hStairChunk {
   int64_t row0, col0;              // first row / column of the chunk, relative to the staircase
   std::vector<int64_t> rows, cols; // segment rows / columns inside the chunk
+  std::vector<int64_t> diag;       // != 0: the segment's trailing square block inside this chunk is its diagonal block
   int blk0, nblk;                  // blocks of B the chunk multiplies with: [blk0, blk0 + nblk) of the block table
 };
 static inline int g3h_stair_limit() {
@@ -63,7 +243,7 @@ static inline int g3h_stair_limit() {
 // seg_rows / seg_cols: the staircase (entries multiples of 128; columns multiples of block_rows); nperm: blocks in
 // the B table (columns beyond nperm * block_rows do not exist)
 static inline void g3h_stair_chunks(const std::vector<int64_t>& seg_rows, const std::vector<int64_t>& seg_cols, int64_t block_rows,
-                                    int nperm, std::vector<G3hStairChunk>* out) {
+                                    int nperm, std::vector<G3hStairChunk>* out, const std::vector<int64_t>* seg_diag = nullptr) {
   out->clear();
   const int limit = g3h_stair_limit();
   const int nseg = (int)seg_rows.size();
@@ -88,6 +268,10 @@ static inline void g3h_stair_chunks(const std::vector<int64_t>& seg_rows, const 
         if (c0 + c > width) c = width - c0;
         ch.rows.push_back(seg_rows[s]);
         ch.cols.push_back(c);
+        // the diagonal block (block aligned, so never cut by a chunk boundary) belongs to the chunk that holds
+        // the segment's last column
+        const bool dg = seg_diag && (*seg_diag)[s] && seg_cols[s] > c0 && seg_cols[s] <= c0 + cstep && c >= seg_rows[s];
+        ch.diag.push_back(dg ? 1 : 0);
         if (c > cmaxw && seg_rows[s] > 0) cmaxw = c;
       }
       if (cmaxw <= 0) continue;

@@ -131,7 +131,8 @@ int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t l
 // staircase: stacked row segments, segment s updates its first seg_cols[s] columns (one launch)
 int g3i_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                       int64_t ldb, int64_t k, const int64_t* seg_rows, const int64_t* seg_cols, int nseg,
-                      double alpha, double beta, g3_dtype dt, int64_t b_nb, const int32_t* b_perm, int nperm);
+                      double alpha, double beta, g3_dtype dt, int64_t b_nb, const int32_t* b_perm, int nperm,
+                      const int64_t* seg_diag = nullptr);
 // one-launch stripe-local solve X <- X L^-T (n <= 1024); 1 = shape not covered, 0 = done
 int g3i_trsm_stripe(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* X, int64_t m, int64_t ldx, const void* W,
                     g3_dtype dt);

@@ -1052,7 +1052,20 @@ extern "C" int g3_potrf_nowait(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, 
   if (ld < n || ld % (16 / (int64_t)g3_esize(dt))) return -4;
   if (!invd_dev) return -6;
   if (!info_accum_dev) return -7;
-  int rc = g3i_potrf(ctx, A_dev, n, ld, dt, invd_dev);
+  int rc;
+  if (n <= 2048) {
+    // a diagonal block of the multi-GPU sweep: it is factored beside bulk updates that fill the chip, exactly like
+    // the diagonal block of a panel of the one-GPU sweep -- same code path (one stream, recursion down to the fused
+    // 256-wide kernel) instead of the two-stream sweep tuned for a stand-alone small matrix
+    G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
+    ctx->info_clean = false;
+    ctx->fuse256 = true;
+    if (n == 0) rc = G3_OK;
+    else if (dt == G3_F64) rc = potrf_rec<double>(ctx, (double*)A_dev, n, ld, (double*)invd_dev, 0, dt);
+    else rc = potrf_rec<float>(ctx, (float*)A_dev, n, ld, (float*)invd_dev, 0, dt);
+  } else {
+    rc = g3i_potrf(ctx, A_dev, n, ld, dt, invd_dev);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(info_merge_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_info, info_accum_dev);
   G3_LAUNCH_CHECK();

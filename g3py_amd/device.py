@@ -216,9 +216,10 @@ class Device:
         _check(self, rc, 'g3_gemm_nt')
 
     def gemm_nt_stair(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, k, seg_rows, seg_cols, dtype, alpha=1.0, beta=0.0,
-                      b_block_rows=0, b_perm=None):
+                      b_block_rows=0, b_perm=None, seg_diag=None):
         """one launch over stacked row segments: segment s gets its first seg_cols[s] columns;
-        b_perm[s] = physical position of logical row block s of B (blocks of b_block_rows rows)"""
+        b_perm[s] = physical position of logical row block s of B (blocks of b_block_rows rows);
+        seg_diag[s] != 0: the last seg_rows[s] columns of segment s are its diagonal block (lower triangle wanted)"""
         n = len(seg_rows)
         rows = (C.c_int64 * n)(*[int(v) for v in seg_rows])
         cols = (C.c_int64 * n)(*[int(v) for v in seg_cols])
@@ -226,8 +227,9 @@ class Device:
         if b_perm is not None:
             nperm = len(b_perm)
             perm = (C.c_int32 * nperm)(*[int(v) for v in b_perm])
+        diag = (C.c_int64 * n)(*[int(v) for v in seg_diag]) if seg_diag is not None else None
         rc = self.lib.g3_gemm_nt_stair(self.ctx, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, k, rows, cols, n, alpha, beta,
-                                       _lib.dtype_code(dtype), int(b_block_rows), perm, nperm)
+                                       _lib.dtype_code(dtype), int(b_block_rows), perm, nperm, diag)
         _check(self, rc, 'g3_gemm_nt_stair')
 
     def potrf(self, A, n):

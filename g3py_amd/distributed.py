@@ -43,10 +43,11 @@ def block_ranges(Np, nb):
     return [(a, min(nb, Np - a)) for a in r]
 
 
-def stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, limit):
+def stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, limit, seg_diag=None):
     """cut a staircase update into launches of at most `limit` row segments and `limit` blocks of B.
-    Yields (first row, segment rows, first column, segment columns, block table) per launch; columns are cut at
-    multiples of b_block_rows (the whole width when B has no block table and fits)"""
+    Yields (first row, segment rows, first column, segment columns, block table[, diagonal flags]) per launch;
+    columns are cut at multiples of b_block_rows (the whole width when B has no block table and fits).  With
+    seg_diag the sixth item flags the segments whose diagonal block (their last seg_rows columns) lies in the chunk"""
     nseg = len(seg_rows)
     width = max(seg_cols)
     cstep = limit * b_block_rows if b_block_rows > 0 else width
@@ -60,7 +61,12 @@ def stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, limit):
                 if b_perm is not None:
                     b0 = c0 // b_block_rows
                     perm = list(b_perm[b0:b0 + limit])
-                yield r0, rows, c0, cols, perm
+                if seg_diag is None:
+                    yield r0, rows, c0, cols, perm
+                else:
+                    dg = [1 if (g and c0 < c <= c0 + cstep) else 0
+                          for g, c in zip(seg_diag[s0:s0 + limit], seg_cols[s0:s0 + limit])]
+                    yield r0, rows, c0, cols, perm, dg
         r0 += sum(rows)
 
 
@@ -216,20 +222,23 @@ class HipPanelOps:
             self.dev.gemm_nt(self._w(C_, m, n), self._w(A, m, k), self._w(B, n, k), m, n, k, alpha=-1.0, beta=1.0,
                              lower_only=lower_only)
 
-    def gemm_sub_stair(self, C_, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None):
+    def gemm_sub_stair(self, C_, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None, seg_diag=None):
         """stacked row segments of C: C[rows_s, :seg_cols[s]] -= A[rows_s, :k] B[:seg_cols[s], :k]^T in one launch;
-        logical row block s of B (b_block_rows rows) is stored at block b_perm[s]"""
+        logical row block s of B (b_block_rows rows) is stored at block b_perm[s]; seg_diag[s] != 0: the last
+        seg_rows[s] columns of segment s are its diagonal block, only the lower triangle of which is needed"""
         if sum(seg_rows) <= 0 or max(seg_cols) <= 0:
             return
         # one launch describes at most STAIR_MAX row segments and STAIR_MAX blocks of B (the raster table travels
         # in the kernel arguments, g3_gemm.hip::RasterTab): longer staircases -- N / nb > 160 row blocks -- are
         # cut into row chunks and column chunks, each its own launch on the same stream
         es = C_.element_size()
-        for (r0, rows, c0, cols, perm) in stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, self.STAIR_MAX):
+        diag = seg_diag if seg_diag is not None else [0] * len(seg_rows)
+        for (r0, rows, c0, cols, perm, dg) in stair_chunks(seg_rows, seg_cols, b_block_rows, b_perm, self.STAIR_MAX, diag):
             self.dev.gemm_nt_stair(C_.data_ptr() + (r0 * C_.stride(0) + c0) * es, C_.stride(0),
                                    A.data_ptr() + r0 * A.stride(0) * es, A.stride(0),
                                    B.data_ptr() + (0 if perm is not None else c0 * B.stride(0) * es), B.stride(0), k,
-                                   rows, cols, self.dtype, alpha=-1.0, beta=1.0, b_block_rows=b_block_rows, b_perm=perm)
+                                   rows, cols, self.dtype, alpha=-1.0, beta=1.0, b_block_rows=b_block_rows, b_perm=perm,
+                                   seg_diag=dg if seg_diag is not None else None)
 
     import os as _os
     STAIR_MAX = int(_os.environ.get('G3_STAIR_MAX', '160'))     # tests lower it to exercise the chunking
@@ -285,7 +294,8 @@ class HipPanelOps:
 class DistributedGP:
     """One evaluation of logp + posterior mean / variance over `world` ranks."""
 
-    def __init__(self, dev, dist, rank, world, N, d, M, nb=512, torch_device=None, ops=None, dtype=np.float64):
+    def __init__(self, dev, dist, rank, world, N, d, M, nb=512, torch_device=None, ops=None, dtype=np.float64,
+                 group_backend=None):
         import torch
         self.dist, self.rank, self.world = dist, rank, world
         self.N, self.d, self.M = N, d, M
@@ -323,7 +333,13 @@ class DistributedGP:
         # The diagonal-factor broadcast (critical path, <= 9 MiB) gets its OWN process group = its own RCCL
         # communicator and stream: on one communicator it would queue behind the panel all-gather (up to
         # 134 MB) issued just before it.  Both are issued in the same order on every rank.
-        self.g_bcast = dist.new_group(ranks=list(range(world))) if (self.use_coll and dist is not None) else None
+        # group_backend (e.g. 'nccl' when the default group is gloo): both groups are created with that backend
+        self.g_bcast = self.g_main = None
+        if self.use_coll and dist is not None:
+            kw = {'backend': group_backend} if group_backend else {}
+            self.g_bcast = dist.new_group(ranks=list(range(world)), **kw)
+            if group_backend:
+                self.g_main = dist.new_group(ranks=list(range(world)), **kw)
         self.comm = {k: {'calls': 0, 'bytes': 0, 'wait_s': 0.0} for k in ('bcast', 'allgather', 'allreduce')}
 
     def owner(self, I):
@@ -398,7 +414,7 @@ class DistributedGP:
         opmap = {'sum': dist.ReduceOp.SUM, 'min': dist.ReduceOp.MIN, 'max': dist.ReduceOp.MAX}
         dev_t = t.to(self.A.device) if self.A.is_cuda else t
         t0 = time.perf_counter()
-        dist.all_reduce(dev_t, op=opmap[op])
+        dist.all_reduce(dev_t, op=opmap[op], group=self.g_main)
         out = dev_t.cpu()
         self.comm['allreduce']['wait_s'] += time.perf_counter() - t0
         self._count('allreduce', dev_t, 2 * (self.world - 1) / max(self.world, 1))
@@ -418,11 +434,11 @@ class DistributedGP:
         self._count('allgather', inp, 2 * (self.world - 1))
         if hasattr(self.dist, 'all_gather_into_tensor'):
             try:
-                return self.dist.all_gather_into_tensor(out, inp, async_op=True)
+                return self.dist.all_gather_into_tensor(out, inp, group=self.g_main, async_op=True)
             except (RuntimeError, NotImplementedError):
                 pass
         chunks = list(out.view(self.world, inp.shape[0], inp.shape[1]).unbind(0))
-        return self.dist.all_gather(chunks, inp, async_op=True)
+        return self.dist.all_gather(chunks, inp, group=self.g_main, async_op=True)
 
     def _wait(self, work, kind=None):
         """make the current stream wait for the collective (RCCL: a stream dependency, the host does not block;
@@ -526,7 +542,8 @@ class DistributedGP:
                     seg_rows = [nb] * len(mine) + rhs
                     if seg_rows:
                         lo = self.loff[mine[0]] if mine else self.rows_mat
-                        o.gemm_sub_stair(A[lo:, c2:c3], A[lo:, c0:c1], G, nb, seg_rows, [nb] * len(seg_rows), nb, perm[1:2])
+                        o.gemm_sub_stair(A[lo:, c2:c3], A[lo:, c0:c1], G, nb, seg_rows, [nb] * len(seg_rows), nb, perm[1:2],
+                                         seg_diag=[1 if I == k + 2 else 0 for I in mine] + [0] * len(rhs))
                     ev_k = o.mark()
                     # d2. the rest
                     mine = [I for I in self.my_blocks if I >= k + 3]
@@ -534,7 +551,8 @@ class DistributedGP:
                     seg_cols = [(I - k - 2) * nb for I in mine] + ([(self.nblk - k - 3) * nb] if rhs else [])
                     if seg_rows and max(seg_cols) > 0:
                         lo = self.loff[mine[0]] if mine else self.rows_mat
-                        o.gemm_sub_stair(A[lo:, c3:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm[2:])
+                        o.gemm_sub_stair(A[lo:, c3:], A[lo:, c0:c1], G, nb, seg_rows, seg_cols, nb, perm[2:],
+                                         seg_diag=[1] * len(mine) + [0] * len(rhs))
             # a. block column k+1 (it carries the updates up to panel k-1 once B_{k-1} has fired)
             o.wait_event(ev_prev)
             mine = [I for I in self.my_blocks if I >= k + 2]
@@ -854,6 +872,16 @@ class NativeDistributedGP:
         self._chk(self.dev.lib.g3_dist_comm_stats(self.h, out), 'g3_dist_comm_stats')
         return {k: {'calls': out[3 * i], 'bytes': out[3 * i + 1], 'device_ms': out[3 * i + 2]}
                 for i, k in enumerate(('bcast', 'allgather', 'allreduce'))}
+
+    def prof_enable(self, on=2):
+        """HIP events around the MFMA GEMM launches of the driver's bulk stream (its staircase updates)"""
+        self._chk(self.dev.lib.g3_dist_prof_enable(self.h, int(on)), 'g3_dist_prof_enable')
+
+    def prof_collect(self):
+        n = len(self._lib.PROF_TAGS)
+        out = (self._C.c_double * (3 * n))()
+        self._chk(self.dev.lib.g3_dist_prof_collect(self.h, out), 'g3_dist_prof_collect')
+        return {t: {'count': int(out[3 * i]), 'ms': out[3 * i + 1], 'work': out[3 * i + 2]} for i, t in enumerate(self._lib.PROF_TAGS)}
 
     def close(self):
         if self.h:

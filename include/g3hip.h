@@ -154,13 +154,16 @@ int g3_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
  * seg_rows / seg_cols are HOST arrays (borrowed for the call), entries multiples of 128 (0 allowed).
  * b_perm (HOST, may be NULL): B is stored as blocks of b_block_rows rows (a multiple of 128) and
  * logical block s -- the rows that multiply columns [s, s+1) * b_block_rows of C -- is physical
- * block b_perm[s]; nperm entries.  This is the trailing update of one rank of the multi-GPU
+ * block b_perm[s]; nperm entries.  seg_diag (HOST, may be NULL): seg_diag[s] != 0 says the last seg_rows[s]
+ * columns of segment s are its square DIAGONAL block, of which only the lower triangle is wanted -- tiles
+ * entirely above it are skipped (elements above the diagonal inside a computed tile are still written: the strict
+ * upper part of a diagonal block is scratch).  This is the trailing update of one rank of the multi-GPU
  * factorisation: its row blocks of the lower triangle have different widths and the all-gathered
  * panel arrives rank-major (g3py/libs/tensors.py:198 is one dpotrf on one host). */
 int g3_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda,
                      const void* B, int64_t ldb, int64_t k, const int64_t* seg_rows,
                      const int64_t* seg_cols, int nseg, double alpha, double beta, g3_dtype dt,
-                     int64_t b_block_rows, const int32_t* b_perm, int nperm);
+                     int64_t b_block_rows, const int32_t* b_perm, int nperm, const int64_t* seg_diag);
 
 /* In-place lower Cholesky of the lower triangle of A (n x n, n a multiple of 128; the
  * strict upper triangle is neither read nor written).  Replaces the dpotrf call at
@@ -395,6 +398,9 @@ int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f, const void
 /* out_host[3k .. 3k+2] for k = 0 broadcast, 1 all-gather, 2 all-reduce: calls, bytes sent + received by this rank,
  * device milliseconds inside the collective calls (HIP events on the stream each ran on).  Resets the counters. */
 int g3_dist_comm_stats(g3_dist* D, double out_host[9]);
+/* g3_prof_enable / g3_prof_collect for the driver's bulk stream (its staircase MFMA-GEMM launches), same layout */
+int g3_dist_prof_enable(g3_dist* D, int on);
+int g3_dist_prof_collect(g3_dist* D, double* out_host /* 3 * G3_PROF_NTAGS */);
 int g3_dist_local_rows(g3_dist* D, int64_t* rows_mat, int64_t* rows_rhs, int64_t* ld);
 
 #ifdef __cplusplus

@@ -111,7 +111,7 @@ class NumpyPanelOps:
                 upd = np.where(np.tril(np.ones((m, n), bool)), upd, 0.0)
             c[:m, :n] -= upd
 
-    def gemm_sub_stair(self, C, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None):
+    def gemm_sub_stair(self, C, A, B, k, seg_rows, seg_cols, b_block_rows=0, b_perm=None, seg_diag=None):
         if getattr(self, '_info', 0):
             return
         c, a, b = C.numpy(), A.numpy(), B.numpy()

@@ -77,6 +77,46 @@ def test_gemm_nt_stair(dev, dt, case):
 
 
 @pytest.mark.parametrize('dt', [np.float64, np.float32])
+@pytest.mark.parametrize('case', ['small', 'big'])
+def test_gemm_nt_stair_diagonal_blocks(dev, dt, case):
+    """seg_diag: the trailing square block of a flagged segment is a DIAGONAL block -- its lower triangle must be
+    exact, tiles entirely above it are not launched (C keeps its old value there), and the strict upper part of the
+    block inside launched tiles is scratch (either the old or the updated value)"""
+    rng = np.random.default_rng(3)
+    if case == 'small':
+        seg_rows, seg_cols, diag, k = [256, 512, 384, 128], [256, 1024, 384, 640], [1, 1, 1, 0], 128
+    else:
+        seg_rows, seg_cols, diag, k = [1024] * 10 + [256], [1024 * (i + 1) for i in range(10)] + [10240], [1] * 10 + [0], 128
+    m, n = sum(seg_rows), max(seg_cols)
+    A = rng.standard_normal((m, k)).astype(dt)
+    B = rng.standard_normal((n, k)).astype(dt)
+    C = rng.standard_normal((m, n)).astype(dt)
+    Ad, Bd, Cd = dev.upload(A), dev.upload(B), dev.upload(C)
+    dev.gemm_nt_stair(Cd.ptr, Cd.ld, Ad.ptr, Ad.ld, Bd.ptr, Bd.ld, k, seg_rows, seg_cols, dt, alpha=-1.0, beta=1.0, seg_diag=diag)
+    got = dev.download(Cd).astype(np.float64)
+    old = C.astype(np.float64)
+    tol = TOL[dt] * np.abs(old).max() * max(1, k / 64) * 8
+    r = 0
+    for rows, cols, dg in zip(seg_rows, seg_cols, diag):
+        new = old[r:r + rows, :cols] - A[r:r + rows].astype(np.float64) @ B[:cols].astype(np.float64).T
+        g = got[r:r + rows, :cols]
+        if not dg:
+            assert np.abs(g - new).max() <= tol
+        else:
+            c0 = cols - rows
+            assert np.abs(g[:, :c0] - new[:, :c0]).max() <= tol if c0 else True
+            lower = np.tril(np.ones((rows, rows), bool))
+            gd, nd, od = g[:, c0:], new[:, c0:], old[r:r + rows, c0:cols]
+            assert np.abs(gd - nd)[lower].max() <= tol
+            up = ~lower
+            assert np.all((np.abs(gd - nd)[up] <= tol) | (gd[up] == od[up]))       # updated or untouched, nothing else
+            if rows >= 512:
+                assert np.any(gd[up] == od[up])                                   # some tiles above the diagonal were skipped
+        assert np.array_equal(got[r:r + rows, cols:], old[r:r + rows, cols:])      # beyond the segment's width: untouched
+        r += rows
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
 @pytest.mark.parametrize('lower', [False, True])
 def test_gemm_unaligned_c_takes_the_scalar_epilogue(dev, dt, lower):
     """C with an odd leading dimension / offset start is not 16-byte aligned row by row: the kernel
