@@ -1,6 +1,7 @@
 // Context, device memory, element-wise / reduction kernels and the fused hot-path entry
 // points of libg3hip (see include/g3hip.h for the contract of each function).
 #include "g3_internal.h"
+#include "g3_host.h"
 #include <stdlib.h>
 
 // ----------------------------------------------------------------------------- context
@@ -655,22 +656,20 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     double st[3];
     rc = g3_diag_stats(ctx, K, N, ldk, dt, st);
     if (rc) return rc;
-    const double c6 = (double)1e-6f, c10 = (double)10.0f;
-    double dK = st[1] * c6, lift = 0.0;
-    if (st[0] <= 0.0) lift = st[1] * c6 - st[0];
+    G3hJitter jit(st[1], st[0]);
     bool ok = false;
-    for (int t = 0; t < 20; ++t) {
+    for (int t = 0; t < G3hJitter::max_tries(); ++t) {
       tries += 1;
       if (t > 0) {
         rc = build();
         if (rc) return rc;
       }
-      rc = g3_diag_add(ctx, K, N, ldk, dt, lift + dK);
+      rc = g3_diag_add(ctx, K, N, ldk, dt, jit.value());
       if (rc) return rc;
       rc = factor(&info);
       if (rc) return rc;
       if (info == 0) { ok = true; break; }
-      dK *= c10;
+      jit.next();
     }
     if (!ok) {
       fallback = 1;

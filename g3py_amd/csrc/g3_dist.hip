@@ -696,17 +696,15 @@ static int factor_robust(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel
     rc = do_allreduce(D, &gmin, 1, 1);
     if (rc) return rc;
     const double mean = acc[0] / (acc[1] > 1.0 ? acc[1] : 1.0);
-    const double c6 = (double)1e-6f, c10 = (double)10.0f;
-    double dK = mean * c6, lift = 0.0;
-    if (gmin <= 0.0) lift = mean * c6 - gmin;
+    G3hJitter jit(mean, gmin);
     bool ok = false;
-    for (int t = 0; t < 20; ++t) {
+    for (int t = 0; t < G3hJitter::max_tries(); ++t) {
       ++tries;
       int inf2 = 0;
-      rc = factor(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, lift + dK, &inf2);
+      rc = factor(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, jit.value(), &inf2);
       if (rc) return rc;
       if (inf2 == 0) { ok = true; break; }
-      dK *= c10;
+      jit.next();
     }
     if (!ok) {
       // CholeskyRobust.perform never raises: the factor becomes 1e-10 * I (tensors.py:215-222), identity on the

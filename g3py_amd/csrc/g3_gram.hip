@@ -7,6 +7,7 @@
 // evaluates the whole kernel expression for its pairs and writes K exactly once, row-wise
 // coalesced (HBM-write bound).  tt_to_num (tensors.py:90-92) is fused into the store.
 #include "g3_internal.h"
+#include "g3_host.h"
 #include <stdlib.h>
 
 #define GT 64           // output tile edge
@@ -203,15 +204,7 @@ __device__ __forceinline__ T scrub(T v) {
 // kernel on an ARD metric -- SE, OU, MAT32, MAT52 or RQ, the expressions the reference's examples are built from.
 // D and the kind are compile-time: x_j lives in registers, x_i is an LDS broadcast, nothing is interpreted
 // (the run-time interpreter costs 36 % on top of the arithmetic).
-template <typename T, int D>
-struct SeParams {
-  T w[D];   // ARD_L2 kinds: 0.5 * rate^2 ; OU (ARD_L1): rate
-  T var, noise, alpha;
-  // optional second term  pvar * prod_k cos(2 pi freq_k dx_k)  (COS, kernels.py:466-467): f = 2 pi freq
-  T f[D];
-  T pvar;
-};
-
+// (SeParams and the host-side matcher g3h_match_fast live in g3_host.h)
 // One workgroup (256 threads) writes a 64-row x 128-column tile; a thread owns two adjacent
 // columns (one 16-byte store per row for fp64: a wave writes 1 KiB of one row per instruction)
 // and every fourth row.
@@ -403,20 +396,14 @@ int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int /*slot*/, const
   // A ring of pinned + device slots keeps the host ahead of the stream: the launch that read the
   // previous slot is already enqueued when the next program arrives, so an event recorded now sits
   // behind it, and a slot is only waited for when the ring has wrapped onto work still in flight.
-  if (ctx->prog_last >= 0) {
-    G3_HIP(hipEventRecord(ctx->prog_ev[ctx->prog_last], ctx->prog_stream));
-    ctx->prog_busy[ctx->prog_last] = true;
-  }
-  const int s = ctx->prog_next;
-  ctx->prog_next = (s + 1) % G3_PROG_SLOTS;
-  if (ctx->prog_busy[s]) {
-    G3_HIP(hipEventSynchronize(ctx->prog_ev[s]));
-    ctx->prog_busy[s] = false;
-  }
+  bool must_wait = false;
+  int mark = -1;
+  const int s = g3h_ring_take(ctx->prog_busy, G3_PROG_SLOTS, &ctx->prog_next, &ctx->prog_last, &must_wait, &mark);
+  if (mark >= 0) G3_HIP(hipEventRecord(ctx->prog_ev[mark], ctx->prog_stream));
+  if (must_wait) G3_HIP(hipEventSynchronize(ctx->prog_ev[s]));
   memcpy(&ctx->h_prog[s], prog, sizeof(g3_kernel_prog));
   G3_HIP(hipMemcpyAsync(&ctx->d_prog[s], &ctx->h_prog[s], sizeof(g3_kernel_prog),
                         hipMemcpyHostToDevice, ctx->stream));
-  ctx->prog_last = s;
   ctx->prog_stream = ctx->stream;
   *dptr = &ctx->d_prog[s];
   return G3_OK;
@@ -424,22 +411,7 @@ int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int /*slot*/, const
 
 int g3i_validate_prog(const g3_kernel_prog* p, int d);
 static int validate_prog(const g3_kernel_prog* p, int d) { return g3i_validate_prog(p, d); }
-int g3i_validate_prog(const g3_kernel_prog* p, int d) {
-  if (p->nleaf < 0 || p->nleaf > G3_MAXLEAF || p->nprod < 0 || p->nprod > G3_MAXPROD) return 1;
-  for (int l = 0; l < p->nleaf; ++l) {
-    const g3_leaf& lf = p->leaf[l];
-    if (lf.kind < 0 || lf.kind > G3_K_WN) return 1;
-    if (lf.ndims < 0 || lf.ndims > G3_MAXD) return 1;
-    for (int k = 0; k < lf.ndims; ++k)
-      if (lf.dims[k] < 0 || lf.dims[k] >= d) return 1;
-  }
-  for (int q = 0; q < p->nprod; ++q) {
-    if (p->prod[q].nfac < 0 || p->prod[q].nfac > G3_MAXFAC) return 1;
-    for (int f = 0; f < p->prod[q].nfac; ++f)
-      if (p->prod[q].fac[f] < 0 || p->prod[q].fac[f] >= p->nleaf) return 1;
-  }
-  return 0;
-}
+int g3i_validate_prog(const g3_kernel_prog* p, int d) { return g3h_validate_prog(p, d); }
 
 static dim3 gram_grid(int64_t n1pad, int64_t n2pad, unsigned flags) {
   const int64_t tr = (n1pad + GT - 1) / GT, tc = (n2pad + GTN - 1) / GTN;
@@ -452,54 +424,6 @@ static dim3 gram_grid(int64_t n1pad, int64_t n2pad, unsigned flags) {
 
 // row offset of the block being built by g3_gram_rows (0 for every other entry point)
 static inline int64_t ctx_diag_off(const g3_ctx* ctx) { return ctx->gram_diag_off; }
-
-// recognise  var * k(x[:, 0:d]) [+ pvar * COS(x[:, 0:d])] [+ Noise]  so the common cases take the register fast
-// path.  Returns the stationary leaf's kind (-1: no match) and the periodic term's kind in *pk (-1: none)
-template <typename T, int D>
-static int match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out, int* pk) {
-  *pk = -1;
-  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 3) return -1;
-  int se = -1, noise = -1, per = -1;
-  for (int q = 0; q < p->nprod; ++q) {
-    if (p->prod[q].nfac != 1) return -1;
-    // (coef * var) applied once; identical to var * k only when coef == 1 (the un-scaled kernel)
-    if (p->prod[q].coef != 1.0) return -1;
-    const g3_leaf& lf = p->leaf[p->prod[q].fac[0]];
-    const bool stat = lf.kind == G3_K_SE || lf.kind == G3_K_OU || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52 ||
-                      lf.kind == G3_K_RQ;
-    if (stat && se < 0) se = q;
-    else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
-    else if (lf.kind == G3_K_COS && per < 0) per = q;
-    else return -1;
-  }
-  if (se < 0) return -1;
-  const g3_leaf& lf = p->leaf[p->prod[se].fac[0]];
-  if (lf.ndims != D) return -1;
-  for (int k = 0; k < D; ++k) {
-    if (lf.dims[k] != k) return -1;
-    out->w[k] = lf.kind == G3_K_OU ? (T)lf.rate[k] : (T)(0.5 * lf.rate[k] * lf.rate[k]);
-    out->f[k] = T(0);
-  }
-  out->var = (T)lf.var;
-  out->alpha = (T)lf.alpha;
-  out->noise = T(0);
-  out->pvar = T(0);
-  if (noise >= 0) out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
-  if (per >= 0) {
-    const g3_leaf& pl = p->leaf[p->prod[per].fac[0]];
-    // instantiated for the stationary kinds and widths below (compile time); everything else is interpreted
-    const bool have = (lf.kind == G3_K_SE || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52) &&
-                      (D == 1 || D == 2 || D == 4 || D == 8);
-    if (!have || pl.ndims != D) return -1;
-    for (int k = 0; k < D; ++k) {
-      if (pl.dims[k] != k) return -1;
-      out->f[k] = T(2 * G3_PI) * (T)pl.freq[k];     // the generic path's  (2 pi * freq) * x
-    }
-    out->pvar = (T)pl.var;
-    *pk = G3_K_COS;
-  }
-  return lf.kind;
-}
 
 template <typename T, int D>
 static int launch_gram_fast(g3_ctx* ctx, int kind, int pk, const SeParams<T, D>& se, const T* X1, int64_t n1, int64_t ldx1,
@@ -543,7 +467,7 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
     int fk, pk;
     SeParams<T, 1> s1; SeParams<T, 2> s2; SeParams<T, 3> s3; SeParams<T, 4> s4; SeParams<T, 8> s8; SeParams<T, 16> s16;
 #define G3_TRY_FAST(DD, SS)                                                                                   \
-    if (!nofast && (fk = match_fast<T, DD>(prog, d, &SS, &pk)) >= 0)                                          \
+    if (!nofast && (fk = g3h_match_fast<T, DD>(prog, d, &SS, &pk)) >= 0)                                          \
       return launch_gram_fast<T, DD>(ctx, fk, pk, SS, X1, n1, ldx1, X2, n2, ldx2, K, ldk, n1pad, n2pad, flags, sym)
     G3_TRY_FAST(1, s1);
     G3_TRY_FAST(2, s2);

@@ -7,7 +7,7 @@
 
 #include <vector>
 
-static_assert(true, "");
+#include "g3hip.h"
 
 #define G3H_LB 128   // = G3_LB: width of the diagonal block one kernel factors
 
@@ -266,6 +266,7 @@ static inline void g3h_stair_chunks(const std::vector<int64_t>& seg_rows, const 
         if (c < 0) c = 0;
         if (c > cstep) c = cstep;
         if (c0 + c > width) c = width - c0;
+        if (seg_rows[s] <= 0) c = 0;       // an empty segment asks for nothing (and must not widen the launch)
         ch.rows.push_back(seg_rows[s]);
         ch.cols.push_back(c);
         // the diagonal block (block aligned, so never cut by a chunk boundary) belongs to the chunk that holds
@@ -281,4 +282,112 @@ static inline void g3h_stair_chunks(const std::vector<int64_t>& seg_rows, const 
     }
     r0 += rsum;
   }
+}
+
+
+// ---- CholeskyRobust's jitter schedule (g3py/libs/tensors.py:203-213): dK = mean(diag) * 1e-6 (float32 constants, as
+// the reference's Theano graph has them), non-positive diagonals lifted by mean * 1e-6 - min, then up to 20 retries
+// with dK *= 10.  One definition for the single-GPU, batched and multi-GPU callers.
+struct G3hJitter {
+  double dK, lift;
+  int tries;
+  G3hJitter(double diag_mean, double diag_min) : dK(diag_mean * (double)1e-6f), lift(0.0), tries(0) {
+    if (diag_min <= 0.0) lift = diag_mean * (double)1e-6f - diag_min;
+  }
+  double value() const { return lift + dK; }        // what is added to the diagonal in this attempt
+  bool usable() const { const double v = lift + dK; return v == v; }   // NaN statistics: every retry fails
+  void next() { dK *= (double)10.0f; ++tries; }
+  static int max_tries() { return 20; }
+};
+
+// ---- ring of kernel-program slots (pinned + device copies): which slot the next upload takes and whether the
+// host must first wait for the launch that read it.  busy[] / next / last live in the context.
+static inline int g3h_ring_take(bool* busy, int nslots, int* next, int* last, bool* must_wait, int* mark_busy) {
+  // the launch that read the previous slot is already enqueued: an event recorded now sits behind it
+  *mark_busy = *last;                     // slot to record an event for (-1: none)
+  if (*last >= 0) busy[*last] = true;
+  const int s = *next;
+  *next = (s + 1) % nslots;
+  *must_wait = busy[s];
+  busy[s] = false;
+  *last = s;
+  return s;
+}
+
+// ---- Gram fast paths: recognise  var * k(x[:, 0:d]) [+ pvar * COS(x[:, 0:d])] [+ Noise]  (compile-time kernels of
+// g3_gram.hip).  D and the kinds are template / run-time outputs; see g3_gram.hip for the device side.
+template <typename T, int D>
+struct SeParams {
+  T w[D];   // ARD_L2 kinds: 0.5 * rate^2 ; OU (ARD_L1): rate
+  T var, noise, alpha;
+  // optional second term  pvar * prod_k cos(2 pi freq_k dx_k)  (COS, kernels.py:466-467): f = 2 pi freq
+  T f[D];
+  T pvar;
+};
+#define G3H_PI 3.14159265358979323846
+// returns the stationary leaf's kind (-1: no match) and the periodic term's kind in *pk (-1: none)
+template <typename T, int D>
+static inline int g3h_match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out, int* pk) {
+  *pk = -1;
+  if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 3) return -1;
+  int se = -1, noise = -1, per = -1;
+  for (int q = 0; q < p->nprod; ++q) {
+    if (p->prod[q].nfac != 1) return -1;
+    // (coef * var) applied once; identical to var * k only when coef == 1 (the un-scaled kernel)
+    if (p->prod[q].coef != 1.0) return -1;
+    const int li = p->prod[q].fac[0];
+    if (li < 0 || li >= p->nleaf || li >= G3_MAXLEAF) return -1;
+    const g3_leaf& lf = p->leaf[li];
+    const bool stat = lf.kind == G3_K_SE || lf.kind == G3_K_OU || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52 ||
+                      lf.kind == G3_K_RQ;
+    if (stat && se < 0) se = q;
+    else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
+    else if (lf.kind == G3_K_COS && per < 0) per = q;
+    else return -1;
+  }
+  if (se < 0) return -1;
+  const g3_leaf& lf = p->leaf[p->prod[se].fac[0]];
+  if (lf.ndims != D) return -1;
+  for (int k = 0; k < D; ++k) {
+    if (lf.dims[k] != k) return -1;
+    out->w[k] = lf.kind == G3_K_OU ? (T)lf.rate[k] : (T)(0.5 * lf.rate[k] * lf.rate[k]);
+    out->f[k] = T(0);
+  }
+  out->var = (T)lf.var;
+  out->alpha = (T)lf.alpha;
+  out->noise = T(0);
+  out->pvar = T(0);
+  if (noise >= 0) out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
+  if (per >= 0) {
+    const g3_leaf& pl = p->leaf[p->prod[per].fac[0]];
+    // instantiated for the stationary kinds and widths below (compile time); everything else is interpreted
+    const bool have = (lf.kind == G3_K_SE || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52) &&
+                      (D == 1 || D == 2 || D == 4 || D == 8);
+    if (!have || pl.ndims != D) return -1;
+    for (int k = 0; k < D; ++k) {
+      if (pl.dims[k] != k) return -1;
+      out->f[k] = T(2 * G3H_PI) * (T)pl.freq[k];     // the generic path's  (2 pi * freq) * x
+    }
+    out->pvar = (T)pl.var;
+    *pk = G3_K_COS;
+  }
+  return lf.kind;
+}
+
+// validity of a kernel program for inputs with d columns (every index the device will follow)
+static inline int g3h_validate_prog(const g3_kernel_prog* p, int d) {
+  if (p->nleaf < 0 || p->nleaf > G3_MAXLEAF || p->nprod < 0 || p->nprod > G3_MAXPROD) return 1;
+  for (int l = 0; l < p->nleaf; ++l) {
+    const g3_leaf& lf = p->leaf[l];
+    if (lf.kind < 0 || lf.kind > G3_K_WN) return 1;
+    if (lf.ndims < 0 || lf.ndims > G3_MAXD) return 1;
+    for (int k = 0; k < lf.ndims; ++k)
+      if (lf.dims[k] < 0 || lf.dims[k] >= d) return 1;
+  }
+  for (int q = 0; q < p->nprod; ++q) {
+    if (p->prod[q].nfac < 0 || p->prod[q].nfac > G3_MAXFAC) return 1;
+    for (int f = 0; f < p->prod[q].nfac; ++f)
+      if (p->prod[q].fac[f] < 0 || p->prod[q].fac[f] >= p->nleaf) return 1;
+  }
+  return 0;
 }

@@ -1164,10 +1164,7 @@ static int robust_t(g3_ctx* ctx, const T* K, int64_t ldk, T* L, int64_t ldl, int
     double st[3];
     rc = g3_diag_stats(ctx, K, n, ldk, dt, st);
     if (rc) return rc;
-    const double c6 = (double)1e-6f, c10 = (double)10.0f;
-    double dK = st[1] * c6;
-    double lift = 0.0;
-    if (st[0] <= 0.0) lift = st[1] * c6 - st[0];
+    G3hJitter jit(st[1], st[0]);
     // sp.linalg.cholesky(check_finite=True) raises on NaN/Inf input: every retry then fails
     unsigned long long* cnt = (unsigned long long*)ctx->d_stats;
     G3_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
@@ -1181,16 +1178,16 @@ static int robust_t(g3_ctx* ctx, const T* K, int64_t ldk, T* L, int64_t ldl, int
     bool ok = false;
     for (int t = 0; t < maxtries; ++t) {
       ++tries;
-      if (finite && (lift + dK) == (lift + dK)) {
-        rc = attempt(lift + dK, &info);
+      if (finite && jit.usable()) {
+        rc = attempt(jit.value(), &info);
         if (rc) return rc;
         if (info == 0) {
           ok = true;
-          jitter = lift + dK;
+          jitter = jit.value();
           break;
         }
       }
-      dK *= c10;
+      jit.next();
     }
     if (!ok) {
       fallback = 1;
