@@ -331,6 +331,17 @@ trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const
 }
 
 
+static FILE* gemm_log() {
+  static FILE* f = nullptr;
+  static int tried = 0;
+  if (!tried) {
+    tried = 1;
+    const char* e = getenv("G3_GEMM_LOG");
+    if (e && *e) f = fopen(e, "w");
+  }
+  return f;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                       int64_t ldb, int64_t k, double alpha, double beta, const GemmShape& sh) {
@@ -372,6 +383,9 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
   // tag: launches of the 128 x 128 tile with >= 1024 tiles are the bulk panel updates
   const int tag = (BM == 128 && BN == 128) ? (nv >= 1024 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
   const int pr = g3i_prof_begin(ctx, tag, 2.0 * shape_elems(sh) * (double)k);
+  if (FILE* lg = gemm_log())   // G3_GEMM_LOG=<file>: one line per launch, joined with a kernel trace by scripts/launch_table.py
+    fprintf(lg, "gemm %d %d %d %lld %lld %lld %d %lld %.9e %d\n", BM, BN, NT / 64, (long long)sh.m, (long long)sh.n, (long long)k, sh.kind,
+            nv, 2.0 * shape_elems(sh) * (double)k, ctx->stream == ctx->side_stream ? 1 : 0);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds_req, ctx->stream, (T*)C, ldc, (const T*)A, lda,
                      (const T*)B, ldb, (int)k, (T)alpha, (T)beta, ctx->d_info,
                      g3_bstride_of(ctx, C), g3_bstride_of(ctx, A), g3_bstride_of(ctx, B), tab);
@@ -491,6 +505,9 @@ static int trsm_stripe_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* X, 
   ops.nops = 0;
   trsm_ops_rec(&ops, 0, n);
   const int pr = g3i_prof_begin(ctx, G3_TAG_GEMM_SMALL, (double)m * (double)n * (double)n);
+  if (FILE* lg = gemm_log())
+    fprintf(lg, "trsm %d 128 4 %lld %lld %lld 0 %lld %.9e %d\n", BM, (long long)m, (long long)n, (long long)n, (long long)(m / BM),
+            (double)m * (double)n * (double)n, ctx->stream == ctx->side_stream ? 1 : 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)(m / BM), (unsigned)g3_nbatch(ctx)), dim3(256), LDS, ctx->stream, X, ldx, L, ldl, W,
                      ctx->d_info, g3_bstride_of(ctx, X), g3_bstride_of(ctx, L), g3_bstride_of(ctx, W), ops);
   g3i_prof_end(ctx, pr);

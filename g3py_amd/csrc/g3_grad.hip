@@ -472,25 +472,29 @@ grad_reduce_kernel(const double* __restrict__ partial, int nblocks, int width, d
   if (threadIdx.x == 0) out[s] = red[0];
 }
 
-// ---- fast path: prog == var * SE(all d columns in order) [+ noise on the diagonal], D compile-time.
-// Accumulators live in registers (var, noise, D rates); one exp per pair; the pass is bound by
-// reading the lower triangle of K^-1.  Slot order of the partial sums: [var, noise, rate_0..rate_{D-1}].
+// ---- fast path: prog == var * k(all d columns in order) [+ noise on the diagonal] with k one stationary kernel
+// (SE, OU, MAT32, MAT52, RQ); D and the kind are compile-time.  Accumulators live in registers (var, noise, D rates,
+// alpha); one exp (or pow) per pair; for SE the pass is bound by reading the lower triangle of K^-1.  Slot order of
+// the partial sums: [var, noise, alpha, rate_0..rate_{D-1}].  Derivatives (kernels.py:388-436, metrics.py:89-102):
+//   d = sum_k w_k dx_k^2, w = rate^2 / 2 (OU: d = sum_k rate_k |dx_k|);  dk/drate_k = dk/dd * rate_k dx_k^2  (OU: * |dx_k|)
+//   SE, OU  dk/dd = -k            MAT32  -3/2 e^-s, s = sqrt(3 d)      MAT52  -5/6 (1 + s) e^-s, s = sqrt(5 d)
+//   RQ      dk/dd = -(1 + d/alpha)^(-alpha-1),  dk/dalpha = k (d / (alpha + d) - log(1 + d/alpha))
 template <int D>
 struct SeGradParams {
-  double w[D];      // 0.5 * rate^2
+  double w[D];      // 0.5 * rate^2 (OU: rate)
   double rate[D];
-  double var;
+  double var, alpha;
 };
 
-template <typename T, int D>
+template <typename T, int D, int FK>
 __global__ void __launch_bounds__(GG_THREADS)
 gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int64_t ldx, const T* __restrict__ G,
                     int64_t ldg, const T* __restrict__ alpha, double* __restrict__ partial) {
   __shared__ double xi_s[GG_T * (D | 1)], xj_s[GG_T * (D | 1)], ai_s[GG_T], aj_s[GG_T];
-  __shared__ double red[(D + 2) * (GG_THREADS / 64)];
+  __shared__ double red[(D + 3) * (GG_THREADS / 64)];
   constexpr int dp = D | 1;
   const int tid = threadIdx.x;
-  double g_var = 0.0, g_noise = 0.0, g_rate[D];
+  double g_var = 0.0, g_noise = 0.0, g_alpha = 0.0, g_rate[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) g_rate[k] = 0.0;
   const int64_t nt = (N + GG_T - 1) / GG_T;
@@ -522,64 +526,88 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
       if (i >= N || j > i) continue;
       const bool diag = i == j;
       const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj - (double)G[i * ldg + j]);
-      double dx2[D], dd = 0.0;
+      double dm[D], dd = 0.0;       // dm: dx^2 (|dx| for OU)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const double dx = xi_s[rr * dp + k] - xj[k];
-        dx2[k] = dx * dx;
-        dd = fma(dx2[k], se.w[k], dd);
+        dm[k] = FK == G3_K_OU ? fabs(dx) : dx * dx;
+        dd = fma(dm[k], se.w[k], dd);
       }
-      const double gk = g * exp(-dd);            // g * k_ij (unit variance)
-      g_var += gk;
+      double kv, dkdd;              // unit-variance kernel value and its derivative with respect to d
+      if constexpr (FK == G3_K_MAT32) {
+        const double s3 = sqrt(3.0 * dd), e = exp(-s3);
+        kv = (1.0 + s3) * e;
+        dkdd = -1.5 * e;
+      } else if constexpr (FK == G3_K_MAT52) {
+        const double s5 = sqrt(5.0 * dd), e = exp(-s5);
+        kv = (1.0 + s5 + 5.0 * dd / 3.0) * e;
+        dkdd = -(5.0 / 6.0) * (1.0 + s5) * e;
+      } else if constexpr (FK == G3_K_RQ) {
+        const double b = 1.0 + dd / se.alpha;
+        kv = pow(b, -se.alpha);
+        dkdd = -kv / b;
+        g_alpha = fma(g * se.var * kv, dd / (se.alpha + dd) - log(b), g_alpha);
+      } else {
+        kv = exp(-dd);
+        dkdd = -kv;
+      }
+      g_var = fma(g, kv, g_var);
       if (diag) g_noise += g;
-      const double gv = -gk * se.var;
+      const double gv = g * dkdd * se.var;
 #pragma unroll
-      for (int k = 0; k < D; ++k) g_rate[k] = fma(gv * se.rate[k], dx2[k], g_rate[k]);
+      for (int k = 0; k < D; ++k) {
+        if constexpr (FK == G3_K_OU) g_rate[k] = fma(gv, dm[k], g_rate[k]);
+        else g_rate[k] = fma(gv * se.rate[k], dm[k], g_rate[k]);
+      }
     }
   }
-  // block reduction of the D + 2 sums
+  // block reduction of the D + 3 sums
   const int lane = tid & 63, wv = tid >> 6;
-  double vals[D + 2];
-  vals[0] = g_var; vals[1] = g_noise;
+  double vals[D + 3];
+  vals[0] = g_var; vals[1] = g_noise; vals[2] = g_alpha;
 #pragma unroll
-  for (int k = 0; k < D; ++k) vals[2 + k] = g_rate[k];
+  for (int k = 0; k < D; ++k) vals[3 + k] = g_rate[k];
 #pragma unroll
-  for (int s = 0; s < D + 2; ++s) {
+  for (int s = 0; s < D + 3; ++s) {
     double v = vals[s];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0) red[s * (GG_THREADS / 64) + wv] = v;
   }
   __syncthreads();
-  if (tid < D + 2) {
+  if (tid < D + 3) {
     double v = 0.0;
     for (int q = 0; q < GG_THREADS / 64; ++q) v += red[tid * (GG_THREADS / 64) + q];
-    partial[(size_t)blockIdx.x * (D + 2) + tid] = v;
+    partial[(size_t)blockIdx.x * (D + 3) + tid] = v;
   }
 }
 
 template <int D>
-static bool match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, int* leaf_se, int* leaf_noise) {
-  if (d != D || p->nprod < 1 || p->nprod > 2) return false;
+static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, int* leaf_se, int* leaf_noise) {
+  // returns the stationary leaf's kind, or -1
+  if (d != D || p->nprod < 1 || p->nprod > 2 || p->shift != 0.0) return -1;
   int se = -1, noise = -1;
   for (int q = 0; q < p->nprod; ++q) {
-    if (p->prod[q].nfac != 1 || p->prod[q].coef != 1.0) return false;
+    if (p->prod[q].nfac != 1 || p->prod[q].coef != 1.0) return -1;
     const int l = p->prod[q].fac[0];
-    if (p->leaf[l].kind == G3_K_SE && se < 0) se = l;
-    else if (p->leaf[l].kind == G3_K_NOISE && noise < 0) noise = l;
-    else return false;
+    const int kd = p->leaf[l].kind;
+    const bool stat = kd == G3_K_SE || kd == G3_K_OU || kd == G3_K_MAT32 || kd == G3_K_MAT52 || kd == G3_K_RQ;
+    if (stat && se < 0) se = l;
+    else if (kd == G3_K_NOISE && noise < 0) noise = l;
+    else return -1;
   }
-  if (se < 0) return false;
+  if (se < 0) return -1;
   const g3_leaf& lf = p->leaf[se];
-  if (lf.ndims != D) return false;
+  if (lf.ndims != D) return -1;
   for (int k = 0; k < D; ++k) {
-    if (lf.dims[k] != k) return false;
-    out->w[k] = 0.5 * lf.rate[k] * lf.rate[k];
+    if (lf.dims[k] != k) return -1;
+    out->w[k] = lf.kind == G3_K_OU ? lf.rate[k] : 0.5 * lf.rate[k] * lf.rate[k];
     out->rate[k] = lf.rate[k];
   }
   out->var = lf.var;
+  out->alpha = lf.alpha;
   *leaf_se = se;
   *leaf_noise = noise;
-  return true;
+  return lf.kind;
 }
 
 template <int D>
@@ -588,9 +616,10 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
                         bool* handled) {
   SeGradParams<D> se;
   int lse = -1, lnoise = -1;
-  *handled = match_se_grad<D>(prog, D, &se, &lse, &lnoise);
+  const int kind = match_se_grad<D>(prog, D, &se, &lse, &lnoise);
+  *handled = kind >= 0;
   if (!*handled) return G3_OK;
-  const int ns = D + 2;
+  const int ns = D + 3;
   const int64_t nt = (N + GG_T - 1) / GG_T;
   const int64_t ntiles = nt * (nt + 1) / 2;
   const int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
@@ -600,12 +629,23 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   double* partial = (double*)ctx->work;
   double* dout = (double*)((char*)ctx->work + pbytes);
   int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * (N + 1) / 2 * g3_esize(dt));
-  if (dt == G3_F64)
-    hipLaunchKernelGGL((gram_grad_se_kernel<double, D>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,
-                       (const double*)X, N, ldx, (const double*)G, ldg, (const double*)alpha, partial);
-  else
-    hipLaunchKernelGGL((gram_grad_se_kernel<float, D>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,
-                       (const float*)X, N, ldx, (const float*)G, ldg, (const float*)alpha, partial);
+#define G3_GRAD_FAST(KIND)                                                                                          \
+  do {                                                                                                              \
+    if (dt == G3_F64)                                                                                               \
+      hipLaunchKernelGGL((gram_grad_se_kernel<double, D, KIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se, \
+                         (const double*)X, N, ldx, (const double*)G, ldg, (const double*)alpha, partial);           \
+    else                                                                                                            \
+      hipLaunchKernelGGL((gram_grad_se_kernel<float, D, KIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,  \
+                         (const float*)X, N, ldx, (const float*)G, ldg, (const float*)alpha, partial);              \
+  } while (0)
+  switch (kind) {
+    case G3_K_SE: G3_GRAD_FAST(G3_K_SE); break;
+    case G3_K_OU: G3_GRAD_FAST(G3_K_OU); break;
+    case G3_K_MAT32: G3_GRAD_FAST(G3_K_MAT32); break;
+    case G3_K_MAT52: G3_GRAD_FAST(G3_K_MAT52); break;
+    default: G3_GRAD_FAST(G3_K_RQ); break;
+  }
+#undef G3_GRAD_FAST
   G3_LAUNCH_CHECK();
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(ns), dim3(256), 0, ctx->stream, partial, nblocks, ns, dout);
   G3_LAUNCH_CHECK();
@@ -616,8 +656,9 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   for (int s = 0; s < map->nslots; ++s) out_host[s] = 0.0;
   if (map->var[lse] >= 0) out_host[map->var[lse]] = h[0];
   if (lnoise >= 0 && map->var[lnoise] >= 0) out_host[map->var[lnoise]] = h[1];
+  if (kind == G3_K_RQ && map->alpha[lse] >= 0) out_host[map->alpha[lse]] = h[2];
   if (map->rate[lse] >= 0)
-    for (int k = 0; k < D; ++k) out_host[map->rate[lse] + k] = h[2 + k];
+    for (int k = 0; k < D; ++k) out_host[map->rate[lse] + k] = h[3 + k];
   return G3_OK;
 }
 

@@ -249,3 +249,38 @@ def test_fast_exp_accuracy_and_range(dev):
     K = _gram(dev, spec, Xb, flags=lib.G3_GRAM_SCRUB)
     Kr = orc.tt_to_num(orc.kernel_cov(spec, Xb))
     np.testing.assert_allclose(K, Kr, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize('kind', ['SE', 'OU', 'MAT32', 'MAT52', 'RQ'])
+@pytest.mark.parametrize('d', [1, 3, 4, 8])
+@pytest.mark.parametrize('noise', [None, 0.2])
+def test_gram_grad_fast_paths_all_stationary_kinds(dev, kind, d, noise):
+    """round 3: the register fast path of g3_gram_grad for  var * k (+ noise), k any of the five stationary kinds, all
+    columns in order (the shape `find_MAP` differentiates thousands of times, stochastic.py:308-309): every
+    parameter slot against the oracle's dK/dparam (kernels.py:388-436 differentiated), ragged N, fp64 and fp32"""
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    N = 171
+    rng = np.random.default_rng(17 * d + len(kind))
+    X = rng.uniform(0, 3, (N, d))
+    X[11] = X[5]                                  # a coincident pair: d = 0 (sqrt at 0 for the Matern kinds)
+    r = rng.uniform(0.4, 1.3, d)
+    spec = (kind, 1.3, r, 1.7, None) if kind == 'RQ' else (kind, 1.3, r, None)
+    if noise is not None:
+        spec = orc.with_noise(spec, noise)
+    A = rng.standard_normal((N, N))
+    G = (A + A.T) / 2
+    alpha = rng.standard_normal(N)
+    K, grads = orc.kernel_cov_grads(spec, X)
+    Gfull = np.outer(alpha, alpha) - G
+    prog = compile_spec(spec, d)
+    gmap = dev.grad_layout(prog)
+    assert gmap.nslots == len(grads)
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-4)):
+        out = dev.gram_grad(prog, gmap, dev.upload(X.astype(dtype)), N, d, dev.upload(np.tril(G).astype(dtype)),
+                            dev.upload(alpha.astype(dtype)))
+        for (leaf, pname, k, dK) in grads:
+            slot = getattr(gmap, pname)[leaf] + (0 if k is None else k)
+            want = 0.5 * np.sum(Gfull * dK)
+            scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
+            assert abs(out[slot] - want) < tol * scale, (kind, d, leaf, pname, k, out[slot], want)
