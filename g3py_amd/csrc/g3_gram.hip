@@ -24,13 +24,13 @@ __host__ __device__ __forceinline__ bool leaf_has_trig(int kind) {
   return kind == G3_K_COS || kind == G3_K_SIN || kind == G3_K_SM;
 }
 
-// exp(x) for the compile-time fast paths.  fp64: n = rint(x / ln 2), r = x - n ln 2 in two pieces (|r| <= ln2 / 2),
-// degree-13 Taylor polynomial of exp(r) (truncation 4e-18 relative), one v_ldexp_f64 -- about half the
-// instructions of the library routine, whose special-case handling the Gram does not need: NaN propagates,
-// arguments below -746 give 0 (through a correctly rounded subnormal range), above 709.78 +Inf.
-// Checked against NumPy in tests/test_gpu_gram.py (<= 4 ulp).  fp32 keeps the library exp.
+// exp(x) for the compile-time fast paths.  Round 3 built an own fp64 exp -- n = rint(x / ln 2), r = x - n ln 2 in two
+// pieces, degree-13 Taylor polynomial of exp(r) (truncation 4e-18), one v_ldexp_f64; <= 4 ulp, NaN / +-Inf and the
+// subnormal range handled -- and MEASURED it against the library routine (scripts/gram_bench.py, profiles/r03_gram.md):
+// SE d=4 N=32768 1.645 vs 1.599 ms, MAT52+COS d=8 N=16384 0.790 vs 0.766 ms: the device library's exp is already a short
+// branch-free sequence and wins by 2-3 %.  The library routine is used; -DG3_FAST_EXP=1 builds the other one.
 #ifndef G3_FAST_EXP
-#define G3_FAST_EXP 1
+#define G3_FAST_EXP 0
 #endif
 __device__ __forceinline__ double g3_exp(double x) {
 #if G3_FAST_EXP
