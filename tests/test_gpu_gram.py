@@ -218,6 +218,8 @@ def test_gram_fast_path_stationary_plus_periodic(dev, d, stat, noise):
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
     got = _gram(dev, spec, Xs, X)
     np.testing.assert_allclose(got, orc.kernel_cov(spec, Xs, X), rtol=1e-12, atol=1e-13)     # cross: no noise term
+    got32 = _gram(dev, spec, X, dtype=np.float32)                                            # the fp32 instantiation
+    np.testing.assert_allclose(got32, ref, rtol=3e-4, atol=3e-5)
 
 
 def test_fast_exp_accuracy_and_range(dev):
