@@ -121,7 +121,7 @@ def test_logp_chain_sharded_over_replicas(tmp_path, world):
 
 # ---- the driver inside libg3hip (g3_dist_*, g3py_amd/csrc/g3_dist.hip)
 @pytest.mark.parametrize('world,N,nb,M', [(1, 1500, 512, 50), (2, 1500, 512, 50), (2, 2048, 256, 300), (3, 2300, 128, 130),
-                                          (3, 256, 128, 10)])
+                                          (3, 256, 128, 10), (4, 1100, 128, 130), (5, 640, 128, 129)])   # up to five ranks on the one GPU
 def test_native_driver_matches_oracle(tmp_path, world, N, nb, M):
     """the C++ per-panel loop (three streams, diagonal-factor broadcast + panel all-gather + staircase updates) with
     `world` ranks sharing cuda:0: collectives served through the callback transport over gloo"""
