@@ -443,8 +443,9 @@ def main():
                 result['logp'] = lp
             else:
                 result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
-        parallelism = 'row-block-cyclic x%d (nb=%d): RCCL diagonal-factor broadcast + panel all-gather, look-ahead; driver: %s' \
-            % (world, args.nb, 'libg3hip g3_dist_* (C++ loop, library-owned RCCL communicators)' if native else 'torch.distributed (' + str(driver) + ')')
+        parallelism = 'row-block-cyclic x%d (nb=%d): diagonal-factor broadcast + panel all-gather (%s), look-ahead; driver: %s' \
+            % (world, args.nb, ('RCCL' if (native_transport == 'rccl' if native else backend == 'nccl') else 'gloo, host-staged: rehearsal'),
+               'libg3hip g3_dist_* (C++ loop, library-owned communicators)' if native else 'torch.distributed (' + str(driver) + ')')
 
     for _ in range(args.warmup):
         step()
