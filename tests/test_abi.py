@@ -41,14 +41,17 @@ def test_header_symbols_exported(lib):
 def test_struct_layout_matches_c(tmp_path):
     from g3py_amd import _lib
     src = tmp_path / 'sz.c'
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "g3hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "g3hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n",'
                    'sizeof(g3_leaf),sizeof(g3_prod),sizeof(g3_kernel_prog),offsetof(g3_leaf,rate),'
-                   'offsetof(g3_kernel_prog,leaf),offsetof(g3_kernel_prog,prod));return 0;}\n')
+                   'offsetof(g3_kernel_prog,leaf),offsetof(g3_kernel_prog,prod),sizeof(g3_grad_map),sizeof(g3_dist_callbacks),'
+                   'offsetof(g3_dist_callbacks,allreduce),G3_DIST_ID_BYTES);return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     assert got == [ctypes.sizeof(_lib.Leaf), ctypes.sizeof(_lib.Prod), ctypes.sizeof(_lib.KernelProg),
-                   _lib.Leaf.rate.offset, _lib.KernelProg.leaf.offset, _lib.KernelProg.prod.offset]
+                   _lib.Leaf.rate.offset, _lib.KernelProg.leaf.offset, _lib.KernelProg.prod.offset,
+                   ctypes.sizeof(_lib.GradMap), ctypes.sizeof(_lib.DistCallbacks), _lib.DistCallbacks.allreduce.offset,
+                   _lib.G3_DIST_ID_BYTES]
 
 
 def test_header_compiles_as_plain_c(tmp_path):
