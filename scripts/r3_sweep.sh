@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the A/B build: scripts/build_variant.sh order0 g3_gemm.hip -DG3_GEMM_ORDER=0, in the build container)
 # round-3 measurement sweep (one gpurun call): parity suite, headline bench, super-panel / panel-width sweep at
 # configs 2-4, A/B of the K-loop order.  Everything goes to gpurun_out/$1/
 set -o pipefail
