@@ -445,7 +445,7 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   for (int i = 0; i < 3; ++i) G3D_HIP(hipMalloc((void**)&D->gath[i], (size_t)D->world * D->cmax * nb * nb * D->es));
   G3D_HIP(hipMalloc((void**)&D->avec, (size_t)D->Np * D->es));
   G3D_HIP(hipMalloc((void**)&D->dots, 2 * 128 * D->es));
-  D->ev.resize(D->nblk + 4);
+  D->ev.resize(D->nblk + 5);
   for (auto& e : D->ev) G3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   G3D_HIP(hipStreamSynchronize(D->ctx->stream));
   D->planned = true;
@@ -527,11 +527,13 @@ static int64_t rows_done(const g3_dist* D, int k) {   // local rows of the block
 
 // panel k: solve my rows below block k (right-hand-side rows included) against L_kk, then all-gather them into
 // gath[k % 3] -- all on the chain stream, which has nothing else to do until the panel is there
-static int solve_and_gather(g3_dist* D, int k) {
+static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const int64_t nb = D->nb, c0 = (int64_t)k * nb;
   const int64_t r_lo = rows_done(D, k);
   const int64_t m = D->rows_mat + D->rows_rhs - r_lo;
   if (m > 0) G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), m, D->Np, D->dt, Wof(D, k)));
+  // the look-ahead of block k+1 needs these rows, not the gathered panel: it starts while the all-gather is in flight
+  G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
   if (D->nblk - 1 - k <= 0) return G3_OK;
   std::vector<int32_t> idx;
   const int cnt = perm_of(D, k, &idx);
@@ -542,12 +544,14 @@ static int solve_and_gather(g3_dist* D, int k) {
 
 // diagonal block j on the look-ahead stream: its owner applies the update with panel j-1 from its own panel rows
 // (the earlier panels arrived with the bulk stream's column launches: event `after`), factors and broadcasts;
-// the others post the receive.  `joined`: event recorded behind the broadcast, the chain waits for it before
-// it uses dbuf[j % 2]
-static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_tmp, hipEvent_t joined) {
+// the others post the receive.  `ev_solved`: panel j-1 is solved on this rank (recorded by solve_and_gather BEFORE
+// its all-gather: the factorisation of block j overlaps the exchange of panel j-1; it also says that the chain has
+// finished reading the broadcast buffer this block will overwrite).  `joined`: event recorded behind the broadcast,
+// the chain waits for it before it uses dbuf[j % 2]
+static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_solved, hipEvent_t joined) {
   const int64_t nb = D->nb;
-  int rc = stream_after(D, D->s_look, D->ctx->stream, ev_tmp);
-  if (rc) return rc;
+  int rc = G3_OK;
+  G3D_HIP(hipStreamWaitEvent(D->s_look, ev_solved, 0));
   if (owner_of(D, j) == D->rank) {
     if (after) G3D_HIP(hipStreamWaitEvent(D->s_look, after, 0));
     const int64_t lo = D->loff[j];
@@ -581,7 +585,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
   const int64_t nb = D->nb;
   const int nblk = D->nblk;
   hipStream_t sA = D->ctx->stream, sB = D->s_bulk;
-  hipEvent_t ev_tmp = D->ev[nblk], ev_join = D->ev[nblk + 1], ev_bc[2] = {D->ev[nblk + 2], D->ev[nblk + 3]};
+  hipEvent_t ev_tmp = D->ev[nblk], ev_join = D->ev[nblk + 1], ev_bc[2] = {D->ev[nblk + 2], D->ev[nblk + 3]}, ev_sv = D->ev[nblk + 4];
   int rc = build(D, prog, prog_cross, X, ldx, Xs, ldxs, delta, jitter);
   if (rc) return rc;
   G3D_HIP(hipMemsetAsync(D->info_dev, 0, sizeof(int), sA));
@@ -591,10 +595,10 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
   }
   rc = do_bcast(D, D->dbuf[0], dbuf_bytes(D), owner_of(D, 0), sA);
   if (rc) return rc;
-  rc = solve_and_gather(D, 0);
+  rc = solve_and_gather(D, 0, ev_sv);
   if (rc) return rc;
   if (nblk > 1) {
-    rc = lookahead(D, 1, nullptr, ev_tmp, ev_bc[1]);
+    rc = lookahead(D, 1, nullptr, ev_sv, ev_bc[1]);
     if (rc) return rc;
   }
   hipEvent_t ev_prev = nullptr;
@@ -644,11 +648,11 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
     }
     // b. panel k+1: needs the broadcast factor
     G3D_HIP(hipStreamWaitEvent(sA, ev_bc[(k + 1) % 2], 0));
-    rc = solve_and_gather(D, k + 1);
+    rc = solve_and_gather(D, k + 1, ev_sv);
     if (rc) return rc;
     // c. diagonal block k+2
     if (k + 2 < nblk) {
-      rc = lookahead(D, k + 2, ev_k, ev_tmp, ev_bc[k % 2]);
+      rc = lookahead(D, k + 2, ev_k, ev_sv, ev_bc[k % 2]);
       if (rc) return rc;
     }
     ev_prev = ev_k;
