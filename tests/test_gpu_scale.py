@@ -351,3 +351,51 @@ def test_config5_matches_oracle_pin(dev, golden_dir, name, dtype, rtol, atol):
     assert not fb and (dtype == np.float32 or tries == g['cov_tries'])
     np.testing.assert_allclose(draws[g['draw_rows']], np.asarray(g['draw_values']), atol=10 * atol)
     assert abs(draws.mean() - g['draws_mean']) <= 10 * atol and abs(draws.std() - g['draws_std']) <= 10 * atol
+
+
+@pytest.mark.parametrize('env', [{'G3_SB': '2'}, {'G3_SB': '3', 'G3_NB': '256'}, {'G3_SB': '4', 'G3_NB': '128', 'G3_NB_TAIL': '0'},
+                                 {'G3_GEMM_BULK8': '0', 'G3_GEMM_BIG_MIN': '64'}, {'G3_GEMM_BIG_MIN': '64'}])
+def test_alternative_sweep_schedules_give_the_same_factor(tmp_path, env):
+    """the knobs README.md documents select other schedules of the SAME arithmetic: super-panels (G3_SB: bulk updates
+    with K = G3_SB x panel width), the four-wave bulk tile, the 128 x 128 tile from 64 tiles on.  Each must reproduce
+    the default sweep's statistics (the environment is read once per process: run in a child)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import g3py_amd as g3
+from g3py_amd import _lib
+from g3py_amd.device import compile_spec
+dev = g3.Device(0)
+out = {}
+for N in (3072, 5120, 7040):
+    d, M = 4, 200
+    rng = np.random.default_rng(N)
+    X = rng.uniform(0, N ** (1 / d), (N, d)); Xs = rng.uniform(0, N ** (1 / d), (M, d))
+    y = np.sin(X.sum(1) / 2) + 0.1 * rng.standard_normal(N)
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, 128)
+    K = dev.alloc(Np + 128 + Mp, Np, np.float64)
+    W, a = dev.alloc_inverses(Np, np.float64), dev.alloc(1, Np, np.float64)
+    mu, ss = dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
+    st = dev.gp_factor_predict(compile_spec(('sum', spec_f, ('NOISE', 0.1)), d), compile_spec(spec_f, d), dev.upload(X), N, d,
+                               dev.upload(y), dev.upload(Xs), M, K, W, a, mu, ss)
+    out[str(N)] = [st['info'], st['logdet'], st['quad']] + dev.download(mu, 1, M)[0][:8].tolist() + dev.download(ss, 1, M)[0][:8].tolist()
+print('RESULT ' + json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        e = dict(os.environ)
+        for k in ('G3_SB', 'G3_NB', 'G3_NB_TAIL', 'G3_GEMM_BULK8', 'G3_GEMM_BIG_MIN'):
+            e.pop(k, None)
+        e.update(extra)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
+    ref, got = run({}), run(env)
+    for N in ref:
+        assert got[N][0] == 0 and ref[N][0] == 0
+        np.testing.assert_allclose(got[N][1:], ref[N][1:], rtol=1e-11, atol=1e-11)
