@@ -249,7 +249,7 @@ __device__ __forceinline__ void gemm_tile(T* C, int64_t ldc, const T* gA, int64_
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, 2)
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) >= 16 ? 1 : 2))
 gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                int K, T alpha, T beta, const int* __restrict__ info,
                int64_t bsC, int64_t bsA, int64_t bsB, const RasterTab tab) {
@@ -425,6 +425,15 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   if (forced == 3) return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   if (forced == 5 && all128)    // 8 waves per 128 x 128 tile (64 x 32 each): four waves per SIMD with two tiles per CU
     return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+#ifdef G3_GEMM_EXPERIMENTS      // measurement build only (scripts/build_variant.sh exp g3_gemm.hip -DG3_GEMM_EXPERIMENTS)
+  if (forced == 6 && all128) return launch_cfg<T, 128, 128, 32, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 7 && sh.kind != 2 && sh.m % 256 == 0 && sh.n % 128 == 0)
+    return launch_cfg<T, 256, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 8 && sh.kind != 2 && sh.m % 128 == 0 && sh.n % 256 == 0)
+    return launch_cfg<T, 128, 256, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+  if (forced == 9 && sh.kind != 2 && sh.n % 128 == 0)
+    return launch_cfg<T, 64, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
+#endif
   if (forced == 4 && sh.kind != 2 && sh.n % 128 == 0)
     return launch_cfg<T, 32, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   // Tile choice (measured on MI355X, scripts/gemm_bench.py):
