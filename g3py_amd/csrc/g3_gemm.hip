@@ -462,7 +462,9 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
     const char* e = getenv("G3_GEMM_BULK8");
     bulk8 = e ? atoi(e) : 1;
   }
-  if (all128 && blocks128 >= big_tile_min()) {
+  // the big tile from 4096 tiles on, and from 1024 tiles on when K >= 1024 (round 3, scripts/r3_sweep2.sh: N = 32768
+  // 204.0 -> 203.3 ms, config 3 33.54 -> 33.43; at K = 512 -- config 2 -- the small tile stays better: 7.25 vs 7.31 ms)
+  if (all128 && (blocks128 >= big_tile_min() || (blocks128 >= 1024 && k >= 1024 && big_tile_min() == 4096))) {
     if (bulk8) return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
     return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   }
