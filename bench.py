@@ -87,7 +87,7 @@ def _measure_traffic(argv_workload):
             for row in csv.DictReader(open(fs[0])):
                 name = row['Kernel_Name']
                 if 'gemm_nt_kernel' in name and ', 128, 128, 64, ' in name and \
-                        int(row['Grid_Size']) // int(row['Workgroup_Size']) >= 1024:
+                        int(row['Grid_Size']) // int(row['Workgroup_Size']) >= 4096:
                     n += 1
                     kb += float(row['Counter_Value'])
             if n == 0:
@@ -535,7 +535,7 @@ def main():
             out['cholesky_tflops'] = (N ** 3 / 3.0) / t_ph / 1e12
             out['factor_solve_tflops'] = prof['potrf']['work'] / prof['potrf']['count'] / t_ph / 1e12
         g = prof['gemm_bulk']
-        kern = 'gemm_nt_kernel<%s,128,128,64,32> (eight waves per 128 x 128 tile), launches with >= 1024 tiles ' % ('float' if args.f32 else 'double') + \
+        kern = 'gemm_nt_kernel<%s,128,128,64,32> (eight waves per 128 x 128 tile), launches with >= 4096 tiles ' % ('float' if args.f32 else 'double') + \
                '(bulk panel updates of the blocked Cholesky and of the trsm)'
         if use_dist:
             # the row-block layout issues per-block updates (m = nb rows): a 1-in-16 sample of the MFMA GEMM launches of rank 0

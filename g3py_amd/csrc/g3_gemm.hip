@@ -380,8 +380,10 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
     if (side_lds > LDS && ctx->stream == ctx->side_stream) lds_req = side_lds;
   }
   // algorithmic flops: 2 k per output element that is wanted.  Profiling
-  // tag: launches of the 128 x 128 tile with >= 1024 tiles are the bulk panel updates
-  const int tag = (BM == 128 && BN == 128) ? (nv >= 1024 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
+  // tag: launches of the 128 x 128 tile with >= 4096 tiles are the bulk panel updates
+  // (>= 4096 tiles: the P2b launches, as in rounds 1-2 when nothing smaller used this tile; the column updates that take it
+  //  since round 3 -- 1024 .. 4095 tiles -- are tagged MID so that the bulk figure stays comparable)
+  const int tag = (BM == 128 && BN == 128) ? (nv >= 4096 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
   const int pr = g3i_prof_begin(ctx, tag, 2.0 * shape_elems(sh) * (double)k);
   if (FILE* lg = gemm_log())   // G3_GEMM_LOG=<file>: one line per launch, joined with a kernel trace by scripts/launch_table.py
     fprintf(lg, "gemm %d %d %d %lld %lld %lld %d %lld %.9e %d\n", BM, BN, NT / 64, (long long)sh.m, (long long)sh.n, (long long)k, sh.kind,

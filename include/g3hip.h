@@ -344,7 +344,7 @@ int g3_gp_sample(g3_ctx* ctx, const void* L_dev, int64_t M, int64_t ldl, const v
  * g3_gp_cross.  g3_prof_collect synchronises and returns, per tag t (G3_PROF_NTAGS of them):
  * out[3t] = number of regions, out[3t+1] = summed milliseconds, out[3t+2] = summed
  * algorithmic work (flops, or bytes for the Gram tags).  Tags: 0 MFMA GEMM, 128x128 tile,
- * launches with >= 1024 tiles (the bulk panel updates), 1 Gram, 2 potrf (whole factorisation),
+ * launches with >= 4096 tiles (the bulk panel updates), 1 Gram, 2 potrf (whole factorisation),
  * 3 trsv (L^-1 delta), 4 cross Gram, 5 trsm (predict), 6 reductions; and with on = 2 also
  * 7 other 128x128-tile GEMM launches, 8 small-tile GEMM launches, 9 fused diagonal-block kernels;
  * on = 3 times only every 16th of those small launches (a sample, for launch-bound callers). */

@@ -22,7 +22,7 @@ def klass(name, grid, wg):
         cfg = name.split('<')[1].split('>')[0].replace(' ', '')
         blocks = int(grid) // int(wg)
         if ',128,128,64,' in cfg:
-            return 'gemm_nt<%s> grid>=1024 (bulk panel updates)' % cfg if blocks >= 1024 else 'gemm_nt<%s> grid<1024' % cfg
+            return 'gemm_nt<%s> grid>=4096 (bulk panel updates)' % cfg if blocks >= 4096 else 'gemm_nt<%s> grid<4096' % cfg
         return 'gemm_nt<%s>' % cfg
     return name.split('(')[0].replace('void ', '')
 

@@ -15,7 +15,7 @@ for d in by.values():
     n = d['name']
     if 'gemm_nt' in n:
         cfg = n.split('<')[1].split('>')[0].replace(' ', '')
-        key = 'gemm_nt<%s>' % cfg + (' grid>=1024 (bulk panel updates)' if ',128,128,64,' in cfg and d['grid'] // d['wg'] >= 1024 else '')
+        key = 'gemm_nt<%s>' % cfg + (' grid>=4096 (bulk panel updates)' if ',128,128,64,' in cfg and d['grid'] // d['wg'] >= 4096 else '')
     else:
         key = n.split('(')[0].replace('void ', '')
     a = agg[key]
