@@ -987,9 +987,78 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
   return g3i_trsm_rlt(ctx, A, n, ld, (char*)A + (size_t)n * ld * g3_esize(dt), E, ld, dt, invd);
 }
 
+// ---- X <- X L^-T for FEW right-hand-side rows against a LARGE factor (the posterior's cross solve after a
+// factorisation: m = M test points, n = N; elliptical.py:81-91): right-looking over 1024-wide column blocks with one
+// block of look-ahead on two streams.  The recursion above runs its n / 1024 leaf solves -- each the same ~20 dependent
+// tile steps whatever m is, ~0.3 ms with only m / 16 workgroups -- and its updates one after the other; here the leaf of
+// block j+1 and its own column update (chain, stream A) run beside the update of everything to the right of it with
+// block j (bulk, stream B, K = 1024).  N = 32768: M = 1024 24.3 -> 20.6 ms, M = 128 12.0 -> 10.9 ms (what is left there is the
+// leaves' own latency: twenty dependent tile steps through global memory, ~0.33 ms each; a four-buffer DMA pipeline for
+// them was measured and did not help -- 11.4 ms -- the steps are bound by their fixed round trips, not by the K loop).
+template <typename T>
+static int trsm_lookahead(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64_t m, int64_t ldb, const T* W, g3_dtype dt) {
+  const int64_t NBK = 1024;
+  const int nblk = (int)((n + NBK - 1) / NBK);
+  if (ctx->la_nev < 2 * nblk + 1) {
+    if (ctx->la_ev) {
+      for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
+      free(ctx->la_ev);
+    }
+    ctx->la_nev = 2 * nblk + 1;
+    ctx->la_ev = (hipEvent_t*)calloc(ctx->la_nev, sizeof(hipEvent_t));
+    if (!ctx->la_ev) return G3_ERR_NOMEM;
+    for (int i = 0; i < ctx->la_nev; ++i) G3_HIP(hipEventCreateWithFlags(&ctx->la_ev[i], hipEventDisableTiming));
+  }
+  hipEvent_t* evX = ctx->la_ev;            // block j of X solved (stream A)
+  hipEvent_t* evU = ctx->la_ev + nblk;     // everything right of block j+1 carries block j (stream B)
+  hipEvent_t evJoin = ctx->la_ev[2 * nblk];
+  hipStream_t sA = ctx->stream, sB = ctx->side_stream;
+  auto c = [&](int j) { return j < nblk ? (int64_t)j * NBK : n; };
+  G3_HIP(hipEventRecord(evJoin, sA));
+  G3_HIP(hipStreamWaitEvent(sB, evJoin, 0));
+  auto leaf = [&](int j) -> int {
+    return trsm_rec<T>(ctx, L + c(j) * ldl + c(j), c(j + 1) - c(j), ldl, B + c(j), m, ldb, W + (c(j) / LB) * LB * LB, dt);
+  };
+  // B[:, col0:col1) -= X_j L[col0:col1, block j]^T
+  auto update = [&](int j, int64_t col0, int64_t col1) -> int {
+    if (col1 <= col0) return G3_OK;
+    return g3i_gemm_nt(ctx, B + col0, ldb, B + c(j), ldb, L + col0 * ldl + c(j), ldl, m, col1 - col0, c(j + 1) - c(j), -1.0, 1.0, dt, 0);
+  };
+  int rc = leaf(0);
+  if (rc) return rc;
+  G3_HIP(hipEventRecord(evX[0], sA));
+  for (int j = 0; j + 1 < nblk; ++j) {
+    // stream B: block j applied to the blocks right of j+1
+    if (c(j + 2) < n) {
+      G3_HIP(hipStreamWaitEvent(sB, evX[j], 0));
+      ctx->stream = sB;
+      rc = update(j, c(j + 2), n);
+      ctx->stream = sA;
+      if (rc) return rc;
+    }
+    G3_HIP(hipEventRecord(evU[j], sB));
+    // stream A: block j applied to block j+1 (which carries the blocks before j once U_{j-1} has fired), then its leaf
+    if (j >= 1) G3_HIP(hipStreamWaitEvent(sA, evU[j - 1], 0));
+    rc = update(j, c(j + 1), c(j + 2));
+    if (!rc) rc = leaf(j + 1);
+    if (rc) return rc;
+    G3_HIP(hipEventRecord(evX[j + 1], sA));
+  }
+  G3_HIP(hipEventRecord(evJoin, sB));
+  G3_HIP(hipStreamWaitEvent(sA, evJoin, 0));
+  return G3_OK;
+}
+
 int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,
                  int64_t ldb, g3_dtype dt, const void* invd) {
   if (n == 0 || m == 0) return G3_OK;
+  static int la = -1;     // G3_TRSM_LOOKAHEAD=0: the recursion for every shape (development comparison)
+  if (la < 0) { const char* e = getenv("G3_TRSM_LOOKAHEAD"); la = e ? atoi(e) : 1; }
+  // few rows against a long factor, outside batch mode and not from inside a two-stream sweep (side stream free)
+  if (la && n >= 4096 && m <= 4096 && ctx->batch <= 1 && ctx->stream != ctx->side_stream) {
+    if (dt == G3_F64) return trsm_lookahead<double>(ctx, (const double*)L, n, ldl, (double*)B, m, ldb, (const double*)invd, dt);
+    return trsm_lookahead<float>(ctx, (const float*)L, n, ldl, (float*)B, m, ldb, (const float*)invd, dt);
+  }
   if (dt == G3_F64)
     return trsm_rec<double>(ctx, (const double*)L, n, ldl, (double*)B, m, ldb, (const double*)invd, dt);
   return trsm_rec<float>(ctx, (const float*)L, n, ldl, (float*)B, m, ldb, (const float*)invd, dt);

@@ -6,14 +6,14 @@ from g3py_amd import _lib
 from g3py_amd.device import compile_spec
 from bench import synth
 dev = g3.Device(0)
-N, d = 32768, 4
+N, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 32768), 4
 X, y, _ = synth(N, d, 8, 1004)
 Np = _lib.roundup(N)
 Xd, yd = dev.upload(X), dev.upload(y)
 K, a, W = dev.alloc(Np + 128, Np, np.float64), dev.alloc(1, Np, np.float64), dev.alloc_inverses(Np, np.float64)
 spec_f = ('SE', 1.0, np.ones(d), None)
 dev.gp_factor(compile_spec(('sum', spec_f, ('NOISE', 0.1)), d), Xd, N, d, yd, K, W, a)
-for M in (1024, 4096):
+for M in (128, 1024, 4096):
     Xs = np.random.default_rng(M).uniform(0, N ** (1 / d), (M, d))
     Mp = _lib.roundup(M, 128)
     V, mu, ss = dev.alloc(Mp, Np, np.float64), dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
