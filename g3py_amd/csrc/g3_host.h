@@ -32,9 +32,20 @@ static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, std
   grp->clear();
   if (NB < G3H_LB) NB = G3H_LB;
   if (G < 1) G = 1;
+  // G3_NB_HEAD=h: the first panels ramp up NB / 2^h ... NB / 2 (one each): the bulk stream has nothing to do until the
+  // first panel is final, a narrow one gets it started sooner.  Measured (round 3, two A/B rounds on one box): one
+  // half-width panel first is worth 1.0 - 1.3 % up to n = 16384 (8192: 7.22 -> 7.14 ms, 16384: 33.0 -> 32.6), nothing at
+  // 20480 and costs 0.3 - 0.4 % from 24576 on (its K = NB / 2 bulk update is a slower launch): default 1 up to 16384
+  const int head = g3h_env_int("G3_NB_HEAD", n <= 16384 ? 1 : 0);
   int64_t r0 = 0;
+  int hstep = head;
   while (r0 < n) {
     int64_t w = NB;
+    if (hstep > 0 && n >= 8 * NB) {
+      w = NB >> hstep;
+      if (w < G3H_LB) w = G3H_LB;
+      --hstep;
+    }
     if (taper) {
       const int64_t rem = n - r0;
       while (w > wlo && rem <= (int64_t)taper * w) w /= 2;
