@@ -181,6 +181,7 @@ struct g3_dist {
   std::vector<hipEvent_t> tev;  // timing event pairs
   std::vector<int> tkind;
   size_t tused = 0;
+  bool timing_now = false;
   // outcome of the last evaluation
   int last_info = 0, last_tries = 0, last_fallback = 0;
   char err[512] = {0};
@@ -232,9 +233,12 @@ static inline char* Lof(const g3_dist* D, int k) { return D->dbuf[k % 2]; }
 static inline char* Wof(const g3_dist* D, int k) { return D->dbuf[k % 2] + (size_t)D->nb * D->nb * D->es; }
 static inline size_t dbuf_bytes(const g3_dist* D) { return ((size_t)D->nb * D->nb + (size_t)D->nb * 128) * D->es; }
 
+static const size_t G3D_MAX_TIMED = 16384;   // event pairs kept between two g3_dist_comm_stats calls; beyond that only counts
 static int coll_begin(g3_dist* D, int kind, hipStream_t s, double bytes) {
   D->n_calls[kind] += 1;
   D->n_bytes[kind] += bytes;
+  D->timing_now = D->tused + 2 <= 2 * G3D_MAX_TIMED;
+  if (!D->timing_now) return G3_OK;        // a caller that never collects the statistics must not grow the event pool
   if (D->tused + 2 > D->tev.size()) {
     for (int i = 0; i < 64; ++i) {
       hipEvent_t e;
@@ -248,6 +252,7 @@ static int coll_begin(g3_dist* D, int kind, hipStream_t s, double bytes) {
   return G3_OK;
 }
 static int coll_end(g3_dist* D, hipStream_t s) {
+  if (!D->timing_now) return G3_OK;
   G3D_HIP(hipEventRecord(D->tev[D->tused + 1], s));
   D->tused += 2;
   return G3_OK;
@@ -313,6 +318,9 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&D->s_bulk, hipStreamNonBlocking, lo);
   if (e == hipSuccess) e = hipMalloc((void**)&D->info_dev, sizeof(int));
   if (e != hipSuccess) {
+    if (D->s_look) (void)hipStreamDestroy(D->s_look);
+    if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
+    if (D->info_dev) (void)hipFree(D->info_dev);
     g3_ctx_destroy(D->ctx_look);
     g3_ctx_destroy(D->ctx_bulk);
     delete D;
@@ -320,6 +328,7 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
   }
   g3_ctx_set_stream(D->ctx_look, D->s_look);
   g3_ctx_set_stream(D->ctx_bulk, D->s_bulk);
+  D->ctx_bulk->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
   *out = D;
   return G3_OK;
 }

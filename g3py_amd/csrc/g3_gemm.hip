@@ -377,7 +377,7 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
       const char* e = getenv("G3_SIDE_LDS");
       side_lds = e ? atoi(e) : 54000;
     }
-    if (side_lds > LDS && ctx->stream == ctx->side_stream) lds_req = side_lds;
+    if (side_lds > LDS && (ctx->stream == ctx->side_stream || ctx->bulk_role)) lds_req = side_lds;
   }
   // algorithmic flops: 2 k per output element that is wanted.  Profiling
   // tag: launches of the 128 x 128 tile with >= 4096 tiles are the bulk panel updates

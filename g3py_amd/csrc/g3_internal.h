@@ -21,6 +21,7 @@ struct g3_ctx {
   bool info_clean;         // d_info is known to be zero (left so by the previous evaluation's last kernel)
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
   bool adopted;            // stream belongs to the caller
+  bool bulk_role;          // this context's stream carries bulk updates beside another context's chain (multi-GPU driver)
   // batch mode (g3_gp_factor_batched): every MFMA GEMM and diagonal-block launch of a sweep acts on
   // `batch` matrices at once (grid.y); operands inside the block-inverse buffer [bw_base, +bw_bytes)
   // are `bstride_w` elements apart, everything else `bstride` elements
