@@ -1,39 +1,43 @@
 """Multi-GPU GP hot path: the N x N covariance block-partitioned over the GPUs of one node.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  The reference has no
-distributed code at all; the algebra is the same Gram + Cholesky +
-triangular solves as the single-GPU path (g3py/libs/tensors.py:197-222,
+One process per GPU.  The reference has no distributed code at all; the algebra is the same
+Gram + Cholesky + triangular solves as the single-GPU path (g3py/libs/tensors.py:197-222,
 g3py/processes/gaussian.py:208-224, elliptical.py:81-97).
 
-Layout: ROW-block-cyclic.  The (identity-padded) covariance is cut into nb-row blocks dealt
-round-robin to the ranks; a rank keeps its row blocks stacked in one local matrix (full width, so
-the rows below any block are one contiguous slab), followed by its share of the right-hand-side
-rows [delta^T; K(Xs, X)] (128-row chunks, also dealt round-robin), which ride through the
-factorisation exactly as on one GPU.
+Two drivers with ONE schedule:
+  * NativeDistributedGP -- the product: a thin wrapper of the driver inside libg3hip (g3_dist_*,
+    g3py_amd/csrc/g3_dist.hip): the library owns the streams, the buffers, the per-panel loop and the RCCL
+    communicators; nothing here loops over panels.
+  * DistributedGP -- the same schedule written out on torch.distributed (backend "nccl" = RCCL over xGMI, or gloo),
+    with all tile arithmetic behind a `PanelOps` object: `HipPanelOps` (libg3hip) or a test double supplied by tests/
+    (world_size 1-8 gloo runs on CPU).  It is the readable statement of the algorithm and bench.py's fallback.
 
-Why rows and not block columns: with block columns the owner of column k+1 needs ALL of panel k
-before it can factor, so the chain  receive panel -> update -> factor -> send panel  serialises a
-whole-panel transfer per step.  With row blocks only the nb x nb diagonal factor travels on the
-critical path; the panel itself is computed in parallel (every rank solves its own rows) and
-exchanged by an all-gather in which every GPU sends and receives over all of its xGMI links at
-once.  Per step k:
+Layout: ROW-block-cyclic.  The (identity-padded) covariance is cut into nb-row blocks dealt in boustrophedon order to
+the ranks; a rank keeps its row blocks stacked in one local matrix (full width, so the rows below any block are one
+contiguous slab), followed by its share of the right-hand-side rows [delta^T; K(Xs, X)] (128-row chunks, dealt
+round-robin), which ride through the factorisation exactly as on one GPU.
 
-  1. every rank: its rows below block k (and its right-hand-side rows)  <-  . L_kk^-T     (local trsm)
-  2. all-gather of those panel rows (asynchronous)
-  3. look-ahead: the owner of block k+1 already has the rows it needs -- it updates its diagonal
-     block with its own panel rows, factors it and broadcasts the nb x nb factor (+ the inverses of
-     its 128 x 128 diagonal blocks) while the all-gather is in flight
-  4. every rank: trailing update of ALL its row blocks and right-hand-side rows with the gathered
-     panel in ONE staircase MFMA-GEMM launch (g3_gemm_nt_stair: each row block has its own width,
-     and the rank-major order of the gathered panel is a block table of the B operand -- no
-     re-ordering copy)
+Why rows and not block columns: with block columns the owner of column k+1 needs ALL of panel k before it can factor,
+so the chain  receive panel -> update -> factor -> send panel  serialises a whole-panel transfer per step.  With row
+blocks only the nb x nb diagonal factor travels on the critical path; the panel itself is computed in parallel (every
+rank solves its own rows) and exchanged by an all-gather in which every GPU sends and receives over all of its xGMI
+links at once.
+
+Schedule (three streams per rank; G_k = the gathered panel k), step k:
+  bulk stream    d1. block column k+2 of everything the rank owns from block k+2 down -= P_k G_k^T      -> event B_k
+                 d2. block columns >= k+3 of its blocks >= k+3 and of the right-hand-side rows: ONE staircase MFMA-GEMM
+                     launch (g3_gemm_nt_stair: each row block has its own width and ends in its diagonal block, of
+                     which only the tiles on or below the diagonal are launched; the rank-major order of the gathered
+                     panel is a block table of the B operand -- no re-ordering copy)
+  caller's       a.  (after B_{k-1}) block column k+1 of its blocks >= k+2 -= P_k G_k^T
+  stream         b.  (after the broadcast of L_{k+1,k+1}) solve its rows of panel k+1, all-gather them (asynchronous)
+  look-ahead     c.  (after B_k) the owner of block k+2 applies panel k+1 to its diagonal block from its own rows,
+  stream             factors it and broadcasts the nb x nb factor (+ the inverses of its 128 x 128 diagonal blocks) on
+                     the broadcast's OWN communicator, so it never queues behind a panel all-gather
 
 Gram: every rank builds exactly its own rows from the replicated N x d input: no communication.
-Scalars (log det, a^T a, posterior mean / variance pieces): one broadcast of a = L^-1 delta and
-one all-reduce of a short vector.  Only broadcast, all_gather and all_reduce are used, so the
-same driver runs on RCCL and, for tests, on gloo.  All tile arithmetic goes through a
-`PanelOps` object: `HipPanelOps` (libg3hip, the product) or a test double supplied by tests/
-(world_size-2 gloo runs on CPU).
+Scalars (log det, a^T a, posterior mean / variance pieces): one broadcast of a = L^-1 delta and one all-reduce of a
+short vector.  Only broadcast, all_gather and all_reduce are used.
 """
 import numpy as np
 
