@@ -484,19 +484,29 @@ struct SeGradParams {
   double w[D];      // 0.5 * rate^2 (OU: rate)
   double rate[D];
   double var, alpha;
+  // optional second term pvar * prod_k cos(2 pi freq_k dx_k) (COS, kernels.py:466-467): f = 2 pi freq
+  double f[D];
+  double pvar;
 };
 
-template <typename T, int D, int FK>
+// PK = G3_K_COS adds the periodic term: d/dpvar = prod_k cos(t_k), d/dfreq_k = -pvar 2 pi dx_k sin(t_k) prod_{k' != k} cos(t_k'),
+// t_k = 2 pi freq_k dx_k, with cos / sin of the angle DIFFERENCE from per-tile tables (as the Gram fast path).
+// Slots: [var, noise, alpha, rate_0..D-1, pvar, freq_0..D-1]
+template <typename T, int D, int FK, int PK>
 __global__ void __launch_bounds__(GG_THREADS)
 gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int64_t ldx, const T* __restrict__ G,
                     int64_t ldg, const T* __restrict__ alpha, double* __restrict__ partial) {
+  constexpr bool PER = PK >= 0;
+  constexpr int NS = PER ? 2 * D + 4 : D + 3;
+  constexpr int TS2 = 2 * D + 1;     // trig row stride (odd)
   __shared__ double xi_s[GG_T * (D | 1)], xj_s[GG_T * (D | 1)], ai_s[GG_T], aj_s[GG_T];
-  __shared__ double red[(D + 3) * (GG_THREADS / 64)];
+  __shared__ double ti_s[PER ? GG_T * TS2 : 1], tj_s[PER ? GG_T * TS2 : 1];
+  __shared__ double red[NS * (GG_THREADS / 64)];
   constexpr int dp = D | 1;
   const int tid = threadIdx.x;
-  double g_var = 0.0, g_noise = 0.0, g_alpha = 0.0, g_rate[D];
+  double g_var = 0.0, g_noise = 0.0, g_alpha = 0.0, g_rate[D], g_pvar = 0.0, g_freq[D];
 #pragma unroll
-  for (int k = 0; k < D; ++k) g_rate[k] = 0.0;
+  for (int k = 0; k < D; ++k) { g_rate[k] = 0.0; g_freq[k] = 0.0; }
   const int64_t nt = (N + GG_T - 1) / GG_T;
   const int64_t ntiles = nt * (nt + 1) / 2;
   for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
@@ -514,11 +524,26 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
     if (tid < GG_T) ai_s[tid] = i0 + tid < N ? (double)alpha[i0 + tid] : 0.0;
     else if (tid < 2 * GG_T) aj_s[tid - GG_T] = j0 + tid - GG_T < N ? (double)alpha[j0 + tid - GG_T] : 0.0;
     __syncthreads();
+    if constexpr (PER) {
+      for (int e = tid; e < 2 * GG_T * D; e += GG_THREADS) {
+        const int side = e / (GG_T * D), q = e - side * (GG_T * D), r = q / D, k = q - r * D;
+        const double th = se.f[k] * (side ? xj_s[r * dp + k] : xi_s[r * dp + k]);
+        double* t = (side ? tj_s : ti_s) + r * TS2 + 2 * k;
+        t[0] = cos(th);
+        t[1] = sin(th);
+      }
+      __syncthreads();
+    }
     const int c = tid & (GG_T - 1);
     const int64_t j = j0 + c;
     double xj[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) xj[k] = xj_s[c * dp + k];
+    double cj[PER ? D : 1], sj[PER ? D : 1];
+    if constexpr (PER) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) { cj[k] = tj_s[c * TS2 + 2 * k]; sj[k] = tj_s[c * TS2 + 2 * k + 1]; }
+    }
     const double aj = aj_s[c];
 #pragma unroll 4
     for (int rr = tid >> 6; rr < GG_T; rr += GG_THREADS / GG_T) {
@@ -526,12 +551,32 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
       if (i >= N || j > i) continue;
       const bool diag = i == j;
       const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj - (double)G[i * ldg + j]);
-      double dm[D], dd = 0.0;       // dm: dx^2 (|dx| for OU)
+      double dm[D], dxs[D], dd = 0.0;       // dm: dx^2 (|dx| for OU)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const double dx = xi_s[rr * dp + k] - xj[k];
+        dxs[k] = dx;
         dm[k] = FK == G3_K_OU ? fabs(dx) : dx * dx;
         dd = fma(dm[k], se.w[k], dd);
+      }
+      if constexpr (PER) {
+        double cs[D], sn[D], pre[D + 1];
+        pre[0] = 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double ci = ti_s[rr * TS2 + 2 * k], si = ti_s[rr * TS2 + 2 * k + 1];
+          cs[k] = ci * cj[k] + si * sj[k];      // cos(theta_i - theta_j)
+          sn[k] = si * cj[k] - ci * sj[k];      // sin(theta_i - theta_j)
+          pre[k + 1] = pre[k] * cs[k];
+        }
+        g_pvar = fma(g, pre[D], g_pvar);
+        double suf = 1.0;
+        const double gp = -g * se.pvar * (2.0 * GG_PI);
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) {
+          g_freq[k] = fma(gp * dxs[k] * sn[k], pre[k] * suf, g_freq[k]);
+          suf *= cs[k];
+        }
       }
       double kv, dkdd;              // unit-variance kernel value and its derivative with respect to d
       if constexpr (FK == G3_K_MAT32) {
@@ -561,31 +606,37 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
       }
     }
   }
-  // block reduction of the D + 3 sums
+  // block reduction of the NS sums
   const int lane = tid & 63, wv = tid >> 6;
-  double vals[D + 3];
+  double vals[NS];
   vals[0] = g_var; vals[1] = g_noise; vals[2] = g_alpha;
 #pragma unroll
   for (int k = 0; k < D; ++k) vals[3 + k] = g_rate[k];
+  if constexpr (PER) {
+    vals[D + 3] = g_pvar;
 #pragma unroll
-  for (int s = 0; s < D + 3; ++s) {
+    for (int k = 0; k < D; ++k) vals[D + 4 + k] = g_freq[k];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
     double v = vals[s];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0) red[s * (GG_THREADS / 64) + wv] = v;
   }
   __syncthreads();
-  if (tid < D + 3) {
+  if (tid < NS) {
     double v = 0.0;
     for (int q = 0; q < GG_THREADS / 64; ++q) v += red[tid * (GG_THREADS / 64) + q];
-    partial[(size_t)blockIdx.x * (D + 3) + tid] = v;
+    partial[(size_t)blockIdx.x * NS + tid] = v;
   }
 }
 
 template <int D>
-static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, int* leaf_se, int* leaf_noise) {
-  // returns the stationary leaf's kind, or -1
-  if (d != D || p->nprod < 1 || p->nprod > 2 || p->shift != 0.0) return -1;
-  int se = -1, noise = -1;
+static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, int* leaf_se, int* leaf_noise, int* leaf_per) {
+  // returns the stationary leaf's kind, or -1; *leaf_per = the COS leaf of the sum, or -1
+  *leaf_per = -1;
+  if (d != D || p->nprod < 1 || p->nprod > 3 || p->shift != 0.0) return -1;
+  int se = -1, noise = -1, per = -1;
   for (int q = 0; q < p->nprod; ++q) {
     if (p->prod[q].nfac != 1 || p->prod[q].coef != 1.0) return -1;
     const int l = p->prod[q].fac[0];
@@ -593,9 +644,24 @@ static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, i
     const bool stat = kd == G3_K_SE || kd == G3_K_OU || kd == G3_K_MAT32 || kd == G3_K_MAT52 || kd == G3_K_RQ;
     if (stat && se < 0) se = l;
     else if (kd == G3_K_NOISE && noise < 0) noise = l;
+    else if (kd == G3_K_COS && per < 0) per = l;
     else return -1;
   }
   if (se < 0) return -1;
+  if (per >= 0) {     // instantiated for SE / MAT32 / MAT52 and d in {1, 2, 4, 8}, as the Gram fast path
+    const g3_leaf& pl = p->leaf[per];
+    const int kd = p->leaf[se].kind;
+    if (!((kd == G3_K_SE || kd == G3_K_MAT32 || kd == G3_K_MAT52) && (D == 1 || D == 2 || D == 4 || D == 8)) || pl.ndims != D) return -1;
+    for (int k = 0; k < D; ++k) {
+      if (pl.dims[k] != k) return -1;
+      out->f[k] = 2.0 * GG_PI * pl.freq[k];
+    }
+    out->pvar = pl.var;
+    *leaf_per = per;
+  } else {
+    for (int k = 0; k < D; ++k) out->f[k] = 0.0;
+    out->pvar = 0.0;
+  }
   const g3_leaf& lf = p->leaf[se];
   if (lf.ndims != D) return -1;
   for (int k = 0; k < D; ++k) {
@@ -615,11 +681,11 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
                         int64_t ldx, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
                         bool* handled) {
   SeGradParams<D> se;
-  int lse = -1, lnoise = -1;
-  const int kind = match_se_grad<D>(prog, D, &se, &lse, &lnoise);
+  int lse = -1, lnoise = -1, lper = -1;
+  const int kind = match_se_grad<D>(prog, D, &se, &lse, &lnoise, &lper);
   *handled = kind >= 0;
   if (!*handled) return G3_OK;
-  const int ns = D + 3;
+  const int ns = lper >= 0 ? 2 * D + 4 : D + 3;
   const int64_t nt = (N + GG_T - 1) / GG_T;
   const int64_t ntiles = nt * (nt + 1) / 2;
   const int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
@@ -629,21 +695,31 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   double* partial = (double*)ctx->work;
   double* dout = (double*)((char*)ctx->work + pbytes);
   int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * (N + 1) / 2 * g3_esize(dt));
-#define G3_GRAD_FAST(KIND)                                                                                          \
+#define G3_GRAD_FAST(KIND, PKIND)                                                                                   \
   do {                                                                                                              \
     if (dt == G3_F64)                                                                                               \
-      hipLaunchKernelGGL((gram_grad_se_kernel<double, D, KIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se, \
+      hipLaunchKernelGGL((gram_grad_se_kernel<double, D, KIND, PKIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se, \
                          (const double*)X, N, ldx, (const double*)G, ldg, (const double*)alpha, partial);           \
     else                                                                                                            \
-      hipLaunchKernelGGL((gram_grad_se_kernel<float, D, KIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,  \
+      hipLaunchKernelGGL((gram_grad_se_kernel<float, D, KIND, PKIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,  \
                          (const float*)X, N, ldx, (const float*)G, ldg, (const float*)alpha, partial);              \
   } while (0)
-  switch (kind) {
-    case G3_K_SE: G3_GRAD_FAST(G3_K_SE); break;
-    case G3_K_OU: G3_GRAD_FAST(G3_K_OU); break;
-    case G3_K_MAT32: G3_GRAD_FAST(G3_K_MAT32); break;
-    case G3_K_MAT52: G3_GRAD_FAST(G3_K_MAT52); break;
-    default: G3_GRAD_FAST(G3_K_RQ); break;
+  if (lper >= 0) {
+    if constexpr (D == 1 || D == 2 || D == 4 || D == 8) {
+      switch (kind) {
+        case G3_K_SE: G3_GRAD_FAST(G3_K_SE, G3_K_COS); break;
+        case G3_K_MAT32: G3_GRAD_FAST(G3_K_MAT32, G3_K_COS); break;
+        default: G3_GRAD_FAST(G3_K_MAT52, G3_K_COS); break;
+      }
+    }
+  } else {
+    switch (kind) {
+      case G3_K_SE: G3_GRAD_FAST(G3_K_SE, -1); break;
+      case G3_K_OU: G3_GRAD_FAST(G3_K_OU, -1); break;
+      case G3_K_MAT32: G3_GRAD_FAST(G3_K_MAT32, -1); break;
+      case G3_K_MAT52: G3_GRAD_FAST(G3_K_MAT52, -1); break;
+      default: G3_GRAD_FAST(G3_K_RQ, -1); break;
+    }
   }
 #undef G3_GRAD_FAST
   G3_LAUNCH_CHECK();
@@ -659,6 +735,11 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   if (kind == G3_K_RQ && map->alpha[lse] >= 0) out_host[map->alpha[lse]] = h[2];
   if (map->rate[lse] >= 0)
     for (int k = 0; k < D; ++k) out_host[map->rate[lse] + k] = h[3 + k];
+  if (lper >= 0) {
+    if (map->var[lper] >= 0) out_host[map->var[lper]] = h[D + 3];
+    if (map->freq[lper] >= 0)
+      for (int k = 0; k < D; ++k) out_host[map->freq[lper] + k] = h[D + 4 + k];
+  }
   return G3_OK;
 }
 

@@ -287,3 +287,38 @@ def test_gram_grad_fast_paths_all_stationary_kinds(dev, kind, d, noise):
             want = 0.5 * np.sum(Gfull * dK)
             scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
             assert abs(out[slot] - want) < tol * scale, (kind, d, leaf, pname, k, out[slot], want)
+
+
+@pytest.mark.parametrize('stat', ['SE', 'MAT32', 'MAT52'])
+@pytest.mark.parametrize('d', [1, 2, 4, 8])
+@pytest.mark.parametrize('noise', [None, 0.2])
+def test_gram_grad_fast_path_stationary_plus_periodic(dev, stat, d, noise):
+    """the register fast path of g3_gram_grad for  stationary + COS (+ noise)  -- config 3's expression: every slot
+    (var, rate_k of the stationary leaf; var, freq_k of the COS leaf, kernels.py:466-467 differentiated; noise var)
+    against the oracle's dK/dparam, fp64 and fp32"""
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    N = 150
+    rng = np.random.default_rng(31 * d + len(stat))
+    X = rng.uniform(0, 3, (N, d))
+    X[9] = X[4]
+    r, f = rng.uniform(0.4, 1.3, d), rng.uniform(0.05, 0.4, d)
+    spec = ('sum', (stat, 1.3, r, None), ('COS', 0.6, f, None))
+    if noise is not None:
+        spec = orc.with_noise(spec, noise)
+    A = rng.standard_normal((N, N))
+    G = (A + A.T) / 2
+    alpha = rng.standard_normal(N)
+    K, grads = orc.kernel_cov_grads(spec, X)
+    Gfull = np.outer(alpha, alpha) - G
+    prog = compile_spec(spec, d)
+    gmap = dev.grad_layout(prog)
+    assert gmap.nslots == len(grads)
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-4)):
+        out = dev.gram_grad(prog, gmap, dev.upload(X.astype(dtype)), N, d, dev.upload(np.tril(G).astype(dtype)),
+                            dev.upload(alpha.astype(dtype)))
+        for (leaf, pname, k, dK) in grads:
+            slot = getattr(gmap, pname)[leaf] + (0 if k is None else k)
+            want = 0.5 * np.sum(Gfull * dK)
+            scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
+            assert abs(out[slot] - want) < tol * scale, (stat, d, leaf, pname, k, out[slot], want)
