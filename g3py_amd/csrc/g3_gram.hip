@@ -210,7 +210,7 @@ __device__ __forceinline__ T scrub(T v) {
 // and every fourth row.
 #define GTN 128
 // FK: g3_kind of the fast path's stationary term, -1 = generic program; PK: g3_kind of its periodic second term
-// (G3_K_COS) or -1.  The sum  stationary + periodic (+ noise)  is the shape of BASELINE config 3's kernel.
+// (G3_K_COS, G3_K_SIN, G3_K_SM) or -1.  The sum  stationary + periodic (+ noise)  is the shape of BASELINE config 3's kernel.
 template <typename T, int D, int FK, int PK = -1>
 __global__ void __launch_bounds__(256)
 gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T* __restrict__ X1,
@@ -346,13 +346,25 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
             kv = g3_exp(-dd);
           }
           v[q] = se.var * kv;
-          if constexpr (PK == G3_K_COS) {
+          if constexpr (PK >= 0) {
             const T* ti = trig_s + rr * FTS;
-            T pr = T(1);
+            T pr = T(1), sm = T(0);
 #pragma unroll
-            for (int c = 0; c < D; ++c)   // cos(theta_i - theta_j), angle-difference identity (as the generic path)
-              pr *= ti[2 * c] * (q ? cjb[c] : cja[c]) + ti[2 * c + 1] * (q ? sjb[c] : sja[c]);
-            v[q] += se.pvar * pr;
+            for (int c = 0; c < D; ++c) {   // cos(theta_i - theta_j), angle-difference identity (as the generic path)
+              const T cd = ti[2 * c] * (q ? cjb[c] : cja[c]) + ti[2 * c + 1] * (q ? sjb[c] : sja[c]);
+              if constexpr (PK == G3_K_SIN) {
+                sm += (T(0.5) * (T(1) - cd)) * se.pr[c];            // sin^2(pi f dx) = (1 - cos(2 pi f dx)) / 2, kernels.py:471-472
+              } else {
+                pr *= cd;                                           // COS, SM: kernels.py:466-467, 486-487
+                if constexpr (PK == G3_K_SM) {
+                  const T dx = xi[c] - (q ? xrb[c] : xra[c]);
+                  sm += (dx * dx) * se.pr[c];
+                }
+              }
+            }
+            if constexpr (PK == G3_K_COS) v[q] += se.pvar * pr;
+            else if constexpr (PK == G3_K_SIN) v[q] += se.pvar * exp(T(2) * sm);   // positive exponent, as written in the reference
+            else v[q] += se.pvar * (exp(T(-2 * G3_PI * G3_PI) * sm) * pr);
           }
           if (dg) v[q] += se.noise;
         } else {
@@ -437,11 +449,16 @@ static int launch_gram_fast(g3_ctx* ctx, int kind, int pk, const SeParams<T, D>&
                      ctx_diag_off(ctx))
   if (pk >= 0) {
     if constexpr (D == 1 || D == 2 || D == 4 || D == 8) {
-      switch (kind) {
-        case G3_K_SE: G3_GRAM_FAST_LAUNCH(G3_K_SE, G3_K_COS); break;
-        case G3_K_MAT32: G3_GRAM_FAST_LAUNCH(G3_K_MAT32, G3_K_COS); break;
-        default: G3_GRAM_FAST_LAUNCH(G3_K_MAT52, G3_K_COS); break;
+#define G3_GRAM_FAST_PK(PKIND)                                             \
+      switch (kind) {                                                        \
+        case G3_K_SE: G3_GRAM_FAST_LAUNCH(G3_K_SE, PKIND); break;            \
+        case G3_K_MAT32: G3_GRAM_FAST_LAUNCH(G3_K_MAT32, PKIND); break;      \
+        default: G3_GRAM_FAST_LAUNCH(G3_K_MAT52, PKIND); break;              \
       }
+      if (pk == G3_K_SIN) { G3_GRAM_FAST_PK(G3_K_SIN) }
+      else if (pk == G3_K_SM) { G3_GRAM_FAST_PK(G3_K_SM) }
+      else { G3_GRAM_FAST_PK(G3_K_COS) }
+#undef G3_GRAM_FAST_PK
     }
   } else {
     switch (kind) {

@@ -331,8 +331,10 @@ template <typename T, int D>
 struct SeParams {
   T w[D];   // ARD_L2 kinds: 0.5 * rate^2 ; OU (ARD_L1): rate
   T var, noise, alpha;
-  // optional second term  pvar * prod_k cos(2 pi freq_k dx_k)  (COS, kernels.py:466-467): f = 2 pi freq
+  // optional second term, a periodic leaf on the same columns (kernels.py:466-487): f = 2 pi freq,
+  // pr = its rate vector (SIN: rate; SM: rate^2 * 2 pi^2; COS: unused)
   T f[D];
+  T pr[D];
   T pvar;
 };
 #define G3H_PI 3.14159265358979323846
@@ -353,7 +355,7 @@ static inline int g3h_match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>*
                       lf.kind == G3_K_RQ;
     if (stat && se < 0) se = q;
     else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
-    else if (lf.kind == G3_K_COS && per < 0) per = q;
+    else if ((lf.kind == G3_K_COS || lf.kind == G3_K_SIN || lf.kind == G3_K_SM) && per < 0) per = q;
     else return -1;
   }
   if (se < 0) return -1;
@@ -363,6 +365,7 @@ static inline int g3h_match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>*
     if (lf.dims[k] != k) return -1;
     out->w[k] = lf.kind == G3_K_OU ? (T)lf.rate[k] : (T)(0.5 * lf.rate[k] * lf.rate[k]);
     out->f[k] = T(0);
+    out->pr[k] = T(0);
   }
   out->var = (T)lf.var;
   out->alpha = (T)lf.alpha;
@@ -378,9 +381,10 @@ static inline int g3h_match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>*
     for (int k = 0; k < D; ++k) {
       if (pl.dims[k] != k) return -1;
       out->f[k] = T(2 * G3H_PI) * (T)pl.freq[k];     // the generic path's  (2 pi * freq) * x
+      out->pr[k] = pl.kind == G3_K_SM ? (T)pl.rate[k] * (T)pl.rate[k] : (T)pl.rate[k];
     }
     out->pvar = (T)pl.var;
-    *pk = G3_K_COS;
+    *pk = pl.kind;
   }
   return lf.kind;
 }

@@ -300,7 +300,7 @@ static void test_match_and_validate() {
     if (k < 0) k = g3h_match_fast<float, 16>(&p, d, &s16, &pk);
     if (k >= 0) {
       CHECK(k == G3_K_SE || k == G3_K_OU || k == G3_K_MAT32 || k == G3_K_MAT52 || k == G3_K_RQ);
-      CHECK(pk == -1 || (pk == G3_K_COS && (k == G3_K_SE || k == G3_K_MAT32 || k == G3_K_MAT52) && (d == 1 || d == 2 || d == 4 || d == 8)));
+      CHECK(pk == -1 || ((pk == G3_K_COS || pk == G3_K_SIN || pk == G3_K_SM) && (k == G3_K_SE || k == G3_K_MAT32 || k == G3_K_MAT52) && (d == 1 || d == 2 || d == 4 || d == 8)));
       CHECK(p.nprod <= 3 && p.shift == 0.0);
       for (int q = 0; q < p.nprod; ++q) CHECK(p.prod[q].nfac == 1 && p.prod[q].coef == 1.0);
     }

@@ -196,6 +196,24 @@ def test_gram_grad_many_slots_and_ragged(dev):
     assert np.array_equal(out, out2)              # fixed-order reduction: bitwise reproducible
 
 
+@pytest.mark.parametrize('per', ['SIN', 'SM'])
+@pytest.mark.parametrize('d', [1, 2, 4, 8])
+@pytest.mark.parametrize('stat', ['SE', 'MAT52'])
+def test_gram_fast_path_stationary_plus_sin_or_sm(dev, per, d, stat):
+    """the other periodic leaves as the second term of the compile-time Gram variants: SIN with the reference's
+    POSITIVE exponent (kernels.py:471-472) and SM (kernels.py:486-487), square (with noise) and cross"""
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(7 * d + len(stat) + len(per))
+    n, m = 190, 70
+    X = rng.uniform(0, n ** (1.0 / d), (n, d))
+    Xs = rng.uniform(0, n ** (1.0 / d), (m, d))
+    rate, freq, prate = rng.uniform(0.5, 1.5, d), rng.uniform(0.05, 0.4, d), rng.uniform(0.05, 0.3, d)
+    spec = orc.with_noise(('sum', (stat, 1.3, rate, None), (per, 0.5, freq, prate, None)), 0.1)
+    for dtype, rtol, atol in ((np.float64, 1e-12, 1e-13), (np.float32, 3e-4, 3e-5)):
+        np.testing.assert_allclose(_gram(dev, spec, X, dtype=dtype), orc.kernel_cov(spec, X), rtol=rtol, atol=atol)
+        np.testing.assert_allclose(_gram(dev, spec, Xs, X, dtype=dtype), orc.kernel_cov(spec, Xs, X), rtol=rtol, atol=atol)
+
+
 @pytest.mark.parametrize('d', [1, 2, 4, 8])
 @pytest.mark.parametrize('stat', ['SE', 'MAT32', 'MAT52'])
 @pytest.mark.parametrize('noise', [None, 0.1])
