@@ -362,9 +362,11 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
                 }
               }
             }
-            if constexpr (PK == G3_K_COS) v[q] += se.pvar * pr;
-            else if constexpr (PK == G3_K_SIN) v[q] += se.pvar * exp(T(2) * sm);   // positive exponent, as written in the reference
-            else v[q] += se.pvar * (exp(T(-2 * G3_PI * G3_PI) * sm) * pr);
+            T pv;
+            if constexpr (PK == G3_K_COS) pv = se.pvar * pr;
+            else if constexpr (PK == G3_K_SIN) pv = se.pvar * exp(T(2) * sm);   // positive exponent, as written in the reference
+            else pv = se.pvar * (exp(T(-2 * G3_PI * G3_PI) * sm) * pr);
+            v[q] = se.mul ? v[q] * pv : v[q] + pv;       // KernelProd (the locally periodic form) or KernelSum
           }
           if (dg) v[q] += se.noise;
         } else {

@@ -336,6 +336,7 @@ struct SeParams {
   T f[D];
   T pr[D];
   T pvar;
+  int mul;     // 0: stationary + periodic (KernelSum), 1: stationary * periodic (KernelProd, kernels.py:225-226)
 };
 #define G3H_PI 3.14159265358979323846
 // returns the stationary leaf's kind (-1: no match) and the periodic term's kind in *pk (-1: none)
@@ -343,23 +344,36 @@ template <typename T, int D>
 static inline int g3h_match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>* out, int* pk) {
   *pk = -1;
   if (d != D || p->shift != 0.0 || p->nprod < 1 || p->nprod > 3) return -1;
-  int se = -1, noise = -1, per = -1;
+  int se = -1, noise = -1, per = -1;       // se / noise / per: PRODUCT indices; sel / perl: leaf indices
+  int sel = -1, perl = -1, mul = 0;
+  auto is_stat = [](int kd) { return kd == G3_K_SE || kd == G3_K_OU || kd == G3_K_MAT32 || kd == G3_K_MAT52 || kd == G3_K_RQ; };
+  auto is_per = [](int kd) { return kd == G3_K_COS || kd == G3_K_SIN || kd == G3_K_SM; };
   for (int q = 0; q < p->nprod; ++q) {
-    if (p->prod[q].nfac != 1) return -1;
     // (coef * var) applied once; identical to var * k only when coef == 1 (the un-scaled kernel)
     if (p->prod[q].coef != 1.0) return -1;
+    if (p->prod[q].nfac == 2) {             // stationary * periodic: one product term with two factors
+      const int l0 = p->prod[q].fac[0], l1 = p->prod[q].fac[1];
+      if (l0 < 0 || l0 >= p->nleaf || l1 < 0 || l1 >= p->nleaf || l0 >= G3_MAXLEAF || l1 >= G3_MAXLEAF) return -1;
+      const int k0 = p->leaf[l0].kind, k1 = p->leaf[l1].kind;
+      if (se >= 0 || per >= 0) return -1;
+      if (is_stat(k0) && is_per(k1)) { sel = l0; perl = l1; }
+      else if (is_stat(k1) && is_per(k0)) { sel = l1; perl = l0; }
+      else return -1;
+      se = per = q;
+      mul = 1;
+      continue;
+    }
+    if (p->prod[q].nfac != 1) return -1;
     const int li = p->prod[q].fac[0];
     if (li < 0 || li >= p->nleaf || li >= G3_MAXLEAF) return -1;
     const g3_leaf& lf = p->leaf[li];
-    const bool stat = lf.kind == G3_K_SE || lf.kind == G3_K_OU || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52 ||
-                      lf.kind == G3_K_RQ;
-    if (stat && se < 0) se = q;
+    if (is_stat(lf.kind) && se < 0) { se = q; sel = li; }
     else if (lf.kind == G3_K_NOISE && noise < 0) noise = q;
-    else if ((lf.kind == G3_K_COS || lf.kind == G3_K_SIN || lf.kind == G3_K_SM) && per < 0) per = q;
+    else if (is_per(lf.kind) && per < 0) { per = q; perl = li; }
     else return -1;
   }
   if (se < 0) return -1;
-  const g3_leaf& lf = p->leaf[p->prod[se].fac[0]];
+  const g3_leaf& lf = p->leaf[sel];
   if (lf.ndims != D) return -1;
   for (int k = 0; k < D; ++k) {
     if (lf.dims[k] != k) return -1;
@@ -371,9 +385,10 @@ static inline int g3h_match_fast(const g3_kernel_prog* p, int d, SeParams<T, D>*
   out->alpha = (T)lf.alpha;
   out->noise = T(0);
   out->pvar = T(0);
+  out->mul = mul;
   if (noise >= 0) out->noise = (T)p->leaf[p->prod[noise].fac[0]].var;
   if (per >= 0) {
-    const g3_leaf& pl = p->leaf[p->prod[per].fac[0]];
+    const g3_leaf& pl = p->leaf[perl];
     // instantiated for the stationary kinds and widths below (compile time); everything else is interpreted
     const bool have = (lf.kind == G3_K_SE || lf.kind == G3_K_MAT32 || lf.kind == G3_K_MAT52) &&
                       (D == 1 || D == 2 || D == 4 || D == 8);

@@ -302,7 +302,9 @@ static void test_match_and_validate() {
       CHECK(k == G3_K_SE || k == G3_K_OU || k == G3_K_MAT32 || k == G3_K_MAT52 || k == G3_K_RQ);
       CHECK(pk == -1 || ((pk == G3_K_COS || pk == G3_K_SIN || pk == G3_K_SM) && (k == G3_K_SE || k == G3_K_MAT32 || k == G3_K_MAT52) && (d == 1 || d == 2 || d == 4 || d == 8)));
       CHECK(p.nprod <= 3 && p.shift == 0.0);
-      for (int q = 0; q < p.nprod; ++q) CHECK(p.prod[q].nfac == 1 && p.prod[q].coef == 1.0);
+      int two = 0;
+      for (int q = 0; q < p.nprod; ++q) { CHECK((p.prod[q].nfac == 1 || p.prod[q].nfac == 2) && p.prod[q].coef == 1.0); two += p.prod[q].nfac == 2; }
+      CHECK(two <= 1 && (two == 0 || pk >= 0));      // a two-factor term is stationary * periodic, at most one
     }
   }
 }

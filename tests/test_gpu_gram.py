@@ -214,6 +214,27 @@ def test_gram_fast_path_stationary_plus_sin_or_sm(dev, per, d, stat):
         np.testing.assert_allclose(_gram(dev, spec, Xs, X, dtype=dtype), orc.kernel_cov(spec, Xs, X), rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize('per', ['COS', 'SIN', 'SM'])
+@pytest.mark.parametrize('d', [1, 4, 8])
+@pytest.mark.parametrize('order', [0, 1])
+def test_gram_fast_path_locally_periodic_product(dev, per, d, order):
+    """KernelProd of a stationary and a periodic leaf (kernels.py:225-226) -- the locally periodic form -- in the
+    compile-time Gram variants, either factor first, with and without the noise term, square and cross"""
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(5 * d + len(per) + order)
+    n, m = 180, 66
+    X = rng.uniform(0, n ** (1.0 / d), (n, d))
+    Xs = rng.uniform(0, n ** (1.0 / d), (m, d))
+    rate, freq, prate = rng.uniform(0.5, 1.5, d), rng.uniform(0.05, 0.4, d), rng.uniform(0.05, 0.3, d)
+    a = ('MAT52', 1.3, rate, None)
+    b = (per, 0.5, freq, None) if per == 'COS' else (per, 0.5, freq, prate, None)
+    core = ('prod', a, b) if order == 0 else ('prod', b, a)
+    for spec in (core, orc.with_noise(core, 0.1)):
+        np.testing.assert_allclose(_gram(dev, spec, X), orc.kernel_cov(spec, X), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(_gram(dev, spec, Xs, X), orc.kernel_cov(spec, Xs, X), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(_gram(dev, core, X, dtype=np.float32), orc.kernel_cov(core, X), rtol=3e-4, atol=3e-5)
+
+
 @pytest.mark.parametrize('d', [1, 2, 4, 8])
 @pytest.mark.parametrize('stat', ['SE', 'MAT32', 'MAT52'])
 @pytest.mark.parametrize('noise', [None, 0.1])
