@@ -33,6 +33,7 @@ class EllipticalProcess(StochasticProcess):
             self.f_kernel_noise = self.f_kernel
         self._cache = None
         self._workspace = None
+        self._dist = None
         kwargs['space'] = space
         super().__init__(*args, **kwargs)
 
@@ -41,6 +42,52 @@ class EllipticalProcess(StochasticProcess):
         if self._device is None:
             self._device = Device.default()
         return self._device
+
+    # ---------------------------------------------------------------- several GPUs
+    def distribute(self, dist, rank, world, nb=None, transport='rccl'):
+        """Evaluate this process on `world` GPUs, one process per GPU (SPMD: every rank runs the same program on the same
+        observations and calls the same methods in the same order).  The reference has no counterpart (its only
+        parallelism is a process pool over chains, stochastic.py:773-783).  From here on logp / loglike and every
+        statistic that comes from the posterior location and variance at `space` -- mean, median, variance, std,
+        quantiles, logpredictive -- are computed by the multi-GPU driver inside libg3hip (g3_dist_*: row-block-cyclic
+        covariance, library-owned RCCL communicators); each rank holds 1 / world of the covariance and gets the same
+        numbers back.  Full covariances, draws through `sampler` and `dlogp` need the whole factor on one device and
+        raise in this mode.  `dist`: an initialised torch.distributed (any backend; it only carries 256 bytes of
+        communicator ids, or everything with transport='callbacks', the one-GPU rehearsal)."""
+        self._dist = dict(dist=dist, rank=int(rank), world=int(world), nb=nb, transport=transport, dgp=None, shape=None)
+        self._cache = None
+        self._workspace = None
+        return self
+
+    def _dist_step(self, c, values, dl, space):
+        """one evaluation on all ranks: (stats, cross-solve results or None)"""
+        from ..distributed import NativeDistributedGP
+        ds, dev = self._dist, self.device
+        N, d = c['N'], c['d']
+        S = None if space is None else self._x(space)
+        M = 0 if S is None else S.shape[0]
+        shape = (N, d, M, self.dtype.str)
+        if ds['dgp'] is None or ds['shape'] != shape:
+            if ds['dgp'] is not None:
+                ds['dgp'].close()
+            nb = ds['nb'] or (1024 if ds['world'] <= 4 and N >= 16384 else 512 if N >= 4096 else 128)
+            ds['dgp'] = NativeDistributedGP(dev, ds['dist'], ds['rank'], ds['world'], N, d, M, nb=nb, dtype=self.dtype,
+                                            transport=ds['transport'])
+            ds['shape'] = shape
+        dgp = ds['dgp']
+        dvec = self._workspace['dvec']
+        dev.copy_in(dvec, np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
+        Sd = dev.upload(S) if M > 0 else c['Xd']
+        dgp.step(self.f_kernel_noise.spec(values, d), self.f_kernel.spec(values, d), c['Xd'], Sd, dvec)
+        last = dgp.last
+        st = dict(logdet=last['logdet'], quad=last['quad'], nonfinite=0 if np.isfinite(last['quad']) else 1,
+                  tries=last['tries'], fallback=last['fallback'], info=last['info'])
+        cross = None
+        if M > 0:
+            Mp = _lib.roundup(M, _lib.G3_RHS_PAD)
+            cross = dict(kid=(False, None), S=S.copy(), out=(None, np.asarray(last['mean'], dtype=self.dtype),
+                                                               np.asarray(last['ss'], dtype=self.dtype), M, Mp))
+        return st, cross
 
     def _check_hypers(self):
         """elliptical.py:35-52"""
@@ -99,10 +146,13 @@ class EllipticalProcess(StochasticProcess):
         # otherwise dominate small problems)
         ws = self._workspace
         if ws is None or ws['shape'] != X.shape or not np.array_equal(ws['X'], X):
-            ws = dict(shape=X.shape, X=X.copy(), Xd=dev.upload(X),
-                      Kd=dev.alloc(Np + _lib.G3_RHS_PAD, Np, self.dtype),   # + the right-hand-side block that carries delta
-                      ad=dev.alloc(1, Np, self.dtype), Wd=dev.alloc_inverses(Np, self.dtype),
-                      dvec=dev.alloc(1, N, self.dtype))
+            if self._dist is not None:      # several GPUs: the covariance lives in the driver, 1 / world of it per rank
+                ws = dict(shape=X.shape, X=X.copy(), Xd=dev.upload(X), Kd=None, ad=None, Wd=None, dvec=dev.alloc(1, N, self.dtype))
+            else:
+                ws = dict(shape=X.shape, X=X.copy(), Xd=dev.upload(X),
+                          Kd=dev.alloc(Np + _lib.G3_RHS_PAD, Np, self.dtype),   # + the right-hand-side block that carries delta
+                          ad=dev.alloc(1, Np, self.dtype), Wd=dev.alloc_inverses(Np, self.dtype),
+                          dvec=dev.alloc(1, N, self.dtype))
             self._workspace = ws
         Xd, Kd, ad, Wd = ws['Xd'], ws['Kd'], ws['ad'], ws['Wd']
         c = dict(key=key, X=X.copy(), y=y.copy(), N=N, d=d, Np=Np, Xd=Xd, Kd=Kd, Wd=Wd, ad=ad, mu=mu, det_m=det_m,
@@ -118,6 +168,15 @@ class EllipticalProcess(StochasticProcess):
         dev = self.device
         dl = c['delta'] if which == 'logp' else c['delta_post']
         finite = np.all(np.isfinite(dl))
+        if self._dist is not None:
+            # one multi-GPU evaluation gives the factor's scalars AND the cross solve at the process's own space
+            sp = getattr(self, 'space', None)         # (a process without a space holds the reference's 2-point dummy)
+            if sp is not None and self._x(sp).shape[1] != c['d']:
+                sp = None
+            st, cross = self._dist_step(c, values, dl, sp)
+            st['delta_finite'] = bool(finite)
+            c['stats'], c['which'], c['grad'], c['cross'] = st, which, None, cross
+            return st
         dvec = self._workspace['dvec']
         dev.copy_in(dvec, np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
         prog = self._prog(self.f_kernel_noise, values, c['d'])
@@ -139,6 +198,15 @@ class EllipticalProcess(StochasticProcess):
         # between them while factor, right-hand side, space and kernel stay the same
         kid = (bool(noise), id(kernel) if kernel is not None else None)
         cc = c.get('cross')
+        if self._dist is not None:
+            # the Noise term contributes nothing to a cross block (kernels.py:367-371): one cross solve serves both flags
+            if kernel is not None:
+                raise _lib.G3Error('cross kernels are not available on a distributed process')
+            if cc is None or cc['S'].shape != S.shape or not np.array_equal(cc['S'], S):
+                dl = c['delta'] if c['which'] == 'logp' else c['delta_post']
+                st, cc = self._dist_step(c, values, dl, S)          # another space than the process's own: one more evaluation
+                c['stats'], c['cross'] = dict(st, delta_finite=c['stats']['delta_finite']), cc
+            return cc['out']
         if cc is not None and cc['kid'] == kid and cc['S'].shape == S.shape and np.array_equal(cc['S'], S):
             return cc['out']
         Sd = dev.upload(S)
@@ -244,6 +312,9 @@ class EllipticalProcess(StochasticProcess):
         if prior:
             K, M, Mp = self._prior_gram(values, space, noise)
             return K, M, Mp
+        if self._dist is not None:
+            raise _lib.G3Error('the full posterior covariance (and draws from it) needs the whole factor on one device: '
+                               'not available on a distributed process (mean / variance / quantiles / logp are)')
         c = self._factor(values, inputs, outputs)
         self._solve(c, values, c['which'] or 'post')
         V, _, _, M, Mp = self._cross(c, values, space, noise)

@@ -84,6 +84,8 @@ class GaussianProcess(EllipticalProcess):
     def _dloglike(self, values, inputs, outputs, nat):
         """adds d loglike / d (natural-space hyper) into `nat`"""
         dev = self.device
+        if self._dist is not None:
+            raise _lib.G3Error('dlogp needs K^-1 on one device: not available on a distributed process')
         c = self._factor(values, inputs, outputs)
         st = self._solve(c, values, 'logp')
         N, d, Np = c['N'], c['d'], c['Np']

@@ -260,3 +260,50 @@ def native_worker(rank, world, port, N, d, M, nb, transport, spec_f, noise, out_
         dgp.close()
     finally:
         dist.destroy_process_group()
+
+
+def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
+    """the PUBLIC API on several ranks (SPMD): GaussianProcess.distribute(...) then logp / predict / logpredictive exactly
+    as on one GPU; rank 0 writes what it got"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        X, y, Xs = synth(N, d, M, 77)
+        if warped:
+            y = y - y.min() + 1.0
+            gp = g3.WarpedGaussianProcess(space=Xs, location=g3.Bias(), kernel=g3.SE(X), mapping=g3.BoxCoxLinear())
+        else:
+            gp = g3.GaussianProcess(space=Xs, location=g3.Bias(), kernel=g3.MAT52(X) + g3.COS(X))
+        gp.observed(X, y)
+        params = dict(gp.params)
+        for k in params:
+            if k.endswith('_var_log_') and 'Noise' not in k:
+                params[k] = np.log(1.1)
+            elif k.endswith('_rate_log_'):
+                params[k] = np.log(np.full(d, 0.9))
+            elif 'Noise' in k:
+                params[k] = np.log(0.1)
+            elif k.endswith('_freq_log_'):
+                params[k] = np.log(np.full(d, 0.2))
+        gp.distribute(dist, rank, world, nb=128, transport=transport)
+        lp = gp.logp(params)
+        pr = gp.predict(params, mean=True, var=True, std=True, median=True, quantiles=True)
+        lpred = gp.logpredictive(params, vector=np.asarray(pr.median) + 0.01)
+        lp2 = gp.logp(params)                               # cached factor: no second evaluation, same number
+        other = gp.mean(params, space=Xs[: max(M // 2, 1)])  # another space than the process's own
+        if rank == 0:
+            np.savez(out_path, logp=lp, logp2=lp2, mean=pr.mean, var=pr.variance, std=pr.std, median=pr.median,
+                     qu=pr.quantile_up, qd=pr.quantile_down, lpred=lpred, other=other)
+        try:
+            gp.kernel(params)
+            ok = False
+        except g3.G3Error:
+            ok = True
+        assert ok, 'the full covariance must refuse on a distributed process'
+        gp._dist['dgp'].close()
+    finally:
+        dist.destroy_process_group()

@@ -222,3 +222,42 @@ def test_native_driver_staircase_longer_than_one_launch(tmp_path, monkeypatch):
     assert abs(float(r['logp']) - ref) <= 1e-9 * abs(ref)
     Z = np.random.default_rng(5).standard_normal((M, 5))
     np.testing.assert_allclose(r['draws'], gp.sampler(Xs, X, y, rand=Z), atol=1e-7)
+
+
+@pytest.mark.parametrize('world,warped', [(1, False), (2, False), (3, True)])
+def test_public_api_on_several_ranks(tmp_path, world, warped):
+    """GaussianProcess.distribute(): the user API itself on `world` ranks (SPMD, callback transport on the one GPU):
+    logp, mean, variance, std, median, quantiles and logpredictive equal the one-GPU process's values"""
+    import torch.multiprocessing as mp
+    import g3py_amd as g3
+    from dist_helpers import api_worker
+    N, d, M = 900, 3, 150
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(api_worker, args=(world, _free_port(), N, d, M, 'callbacks', out, warped), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    if warped:
+        y = y - y.min() + 1.0
+        gp = g3.WarpedGaussianProcess(space=Xs, location=g3.Bias(), kernel=g3.SE(X), mapping=g3.BoxCoxLinear())
+    else:
+        gp = g3.GaussianProcess(space=Xs, location=g3.Bias(), kernel=g3.MAT52(X) + g3.COS(X))
+    gp.observed(X, y)
+    params = dict(gp.params)
+    for k in params:
+        if k.endswith('_var_log_') and 'Noise' not in k:
+            params[k] = np.log(1.1)
+        elif k.endswith('_rate_log_'):
+            params[k] = np.log(np.full(d, 0.9))
+        elif 'Noise' in k:
+            params[k] = np.log(0.1)
+        elif k.endswith('_freq_log_'):
+            params[k] = np.log(np.full(d, 0.2))
+    lp = gp.logp(params)
+    pr = gp.predict(params, mean=True, var=True, std=True, median=True, quantiles=True)
+    assert abs(float(r['logp']) - lp) <= 1e-10 * abs(lp) and float(r['logp2']) == float(r['logp'])
+    for key, want in (('mean', pr.mean), ('var', pr.variance), ('std', pr.std), ('median', pr.median),
+                      ('qu', pr.quantile_up), ('qd', pr.quantile_down)):
+        np.testing.assert_allclose(r[key], want, atol=1e-8, err_msg=key)
+    lpred = gp.logpredictive(params, vector=np.asarray(pr.median) + 0.01)
+    assert abs(float(r['lpred']) - lpred) <= 1e-8 * abs(lpred)
+    np.testing.assert_allclose(r['other'], gp.mean(params, space=Xs[: M // 2]), atol=1e-8)
