@@ -857,17 +857,27 @@ class NativeDistributedGP:
         self.last.update(logdet=logdet, quad=quad, info=int(out[2]), tries=int(out[3]), fallback=bool(out[4]), mean=mean, ss=ss)
         if Z is not None:
             loc = mean if loc_prior is None else np.asarray(loc_prior, dtype=np.float64) + mean
-            Zc = np.ascontiguousarray(Z, dtype=self.dtype)
-            S = Zc.shape[1]
-            locc = np.ascontiguousarray(loc, dtype=self.dtype)
-            draws = np.empty((M, S), dtype=self.dtype)
-            tries, fb = C.c_int(0), C.c_int(0)
-            self._chk(lib.g3_dist_posterior_draws(self.h, C.byref(pf), xsp, ldxs, locc.ctypes.data, Zc.ctypes.data, S,
-                                                  draws.ctypes.data, C.byref(tries), C.byref(fb)), 'g3_dist_posterior_draws')
-            self.last.update(draws=draws.astype(np.float64), cov_tries=tries.value, cov_fallback=bool(fb.value))
+            self.draws(spec_f, Xs, loc, Z)
         logp = -0.5 * self.N * np.log(2 * np.pi) - 0.5 * quad - logdet
         self.last['logp'] = logp
         return logp
+
+    def draws(self, spec_f, Xs, loc, Z):
+        """after step() with the same Xs: posterior covariance K_f(Xs, Xs) - V V^T, its robust Cholesky and the latent
+        draws loc + L_post Z (gaussian.py:75-97, before the mapping); every rank returns the same M x S matrix"""
+        C, lib = self._C, self.dev.lib
+        pf = self._compile(spec_f, self.d)
+        xsp, ldxs = self._ptr_ld(Xs)
+        M = self.M
+        Zc = np.ascontiguousarray(Z, dtype=self.dtype)
+        S = Zc.shape[1]
+        locc = np.ascontiguousarray(loc, dtype=self.dtype)
+        out = np.empty((M, S), dtype=self.dtype)
+        tries, fb = C.c_int(0), C.c_int(0)
+        self._chk(lib.g3_dist_posterior_draws(self.h, C.byref(pf), xsp, ldxs, locc.ctypes.data, Zc.ctypes.data, S,
+                                              out.ctypes.data, C.byref(tries), C.byref(fb)), 'g3_dist_posterior_draws')
+        self.last.update(draws=out.astype(np.float64), cov_tries=tries.value, cov_fallback=bool(fb.value))
+        return self.last['draws']
 
     def comm_stats(self):
         """per collective kind since the last call: calls, bytes sent + received by this rank, device milliseconds

@@ -51,8 +51,8 @@ class EllipticalProcess(StochasticProcess):
         statistic that comes from the posterior location and variance at `space` -- mean, median, variance, std,
         quantiles, logpredictive -- are computed by the multi-GPU driver inside libg3hip (g3_dist_*: row-block-cyclic
         covariance, library-owned RCCL communicators); each rank holds 1 / world of the covariance and gets the same
-        numbers back.  Full covariances, draws through `sampler` and `dlogp` need the whole factor on one device and
-        raise in this mode.  `dist`: an initialised torch.distributed (any backend; it only carries 256 bytes of
+        numbers back; `sampler` draws from the f posterior through the driver too (rank 0's normals).  Full covariances
+        and `dlogp` need the whole factor on one device and raise in this mode.  `dist`: an initialised torch.distributed (any backend; it only carries 256 bytes of
         communicator ids, or everything with transport='callbacks', the one-GPU rehearsal)."""
         self._dist = dict(dist=dist, rank=int(rank), world=int(world), nb=nb, transport=transport, dgp=None, shape=None)
         self._cache = None

@@ -299,6 +299,21 @@ class GaussianProcess(EllipticalProcess):
             rand = np.random.randn(M, samples)
         rand = np.asarray(rand, dtype=self.dtype)
         loc = self.location(params, space, inputs, outputs, prior=prior, noise=noise)
+        if self._dist is not None and not prior:
+            # several GPUs: every rank must use the SAME normals (rank 0's are broadcast), the posterior covariance of
+            # the f process is formed and factored by the driver (g3_dist_posterior_draws) from the cross solve that
+            # `location` has just left in it
+            if noise:
+                raise _lib.G3Error('draws with the noise term are not available on a distributed process')
+            ds = self._dist
+            if ds['world'] > 1:
+                box = [rand if ds['rank'] == 0 else None]
+                ds['dist'].broadcast_object_list(box, src=0)
+                rand = np.asarray(box[0], dtype=self.dtype)
+            values, _ = self._values(params)
+            S_ = self._x(space)
+            g = ds['dgp'].draws(self.f_kernel.spec(values, S_.shape[1]), self.device.upload(S_), np.asarray(loc, dtype=np.float64), rand)
+            return self.mapping(params, space, inputs, outputs=g.astype(self.dtype))
         Ld, _, _ = self._cholesky_dev(params, space, inputs, outputs, prior=prior, noise=noise)   # stays on the device
         g = self.device.gp_sample(Ld, M, loc, rand)                # loc + L Z, one call (g3_gp_sample)
         # the mapping is element-wise: one vectorised pass over the M x S draws instead of the

@@ -295,9 +295,12 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         lpred = gp.logpredictive(params, vector=np.asarray(pr.median) + 0.01)
         lp2 = gp.logp(params)                               # cached factor: no second evaluation, same number
         other = gp.mean(params, space=Xs[: max(M // 2, 1)])  # another space than the process's own
+        gp.mean(params)                                     # back to the process's own space: the driver holds its cross solve
+        Z = np.random.default_rng(100 + rank).standard_normal((M, 4))      # ranks draw DIFFERENT normals: rank 0's must win
+        smp = gp.sampler(params, samples=4, rand=Z)
         if rank == 0:
             np.savez(out_path, logp=lp, logp2=lp2, mean=pr.mean, var=pr.variance, std=pr.std, median=pr.median,
-                     qu=pr.quantile_up, qd=pr.quantile_down, lpred=lpred, other=other)
+                     qu=pr.quantile_up, qd=pr.quantile_down, lpred=lpred, other=other, smp=smp)
         try:
             gp.kernel(params)
             ok = False

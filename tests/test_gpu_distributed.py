@@ -261,3 +261,5 @@ def test_public_api_on_several_ranks(tmp_path, world, warped):
     lpred = gp.logpredictive(params, vector=np.asarray(pr.median) + 0.01)
     assert abs(float(r['lpred']) - lpred) <= 1e-8 * abs(lpred)
     np.testing.assert_allclose(r['other'], gp.mean(params, space=Xs[: M // 2]), atol=1e-8)
+    Z = np.random.default_rng(100).standard_normal((M, 4))
+    np.testing.assert_allclose(r['smp'], gp.sampler(params, samples=4, rand=Z), atol=1e-7)     # rank 0's normals, same draws
