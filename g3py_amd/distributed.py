@@ -898,9 +898,20 @@ class NativeDistributedGP:
         return {t: {'count': int(out[3 * i]), 'ms': out[3 * i + 1], 'work': out[3 * i + 2]} for i, t in enumerate(self._lib.PROF_TAGS)}
 
     def close(self):
-        if self.h:
+        """destroy the driver (communicators, streams, buffers).  Idempotent; a no-op once the device context it lives
+        on has been closed (Device.close() releases the context first only at interpreter exit)"""
+        if self.h and self.dev.ctx:
             self.dev.lib.g3_dist_destroy(self.h)
-            self.h = self._C.c_void_p()
+        self.h = self._C.c_void_p()
+
+    def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # --------------------------------------------------------------------------- replicas

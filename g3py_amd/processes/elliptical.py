@@ -59,6 +59,15 @@ class EllipticalProcess(StochasticProcess):
         self._workspace = None
         return self
 
+    def undistribute(self):
+        """back to one GPU: destroys the multi-GPU driver of this process (collective: call it on every rank)"""
+        if self._dist is not None and self._dist['dgp'] is not None:
+            self._dist['dgp'].close()
+        self._dist = None
+        self._cache = None
+        self._workspace = None
+        return self
+
     def _dist_step(self, c, values, dl, space):
         """one evaluation on all ranks: (stats, cross-solve results or None)"""
         from ..distributed import NativeDistributedGP

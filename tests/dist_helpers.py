@@ -307,6 +307,7 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         except g3.G3Error:
             ok = True
         assert ok, 'the full covariance must refuse on a distributed process'
-        gp._dist['dgp'].close()
+        gp.undistribute()
+        assert abs(gp.logp(params) - lp) <= 1e-10 * abs(lp)       # and the same process object works on one GPU again
     finally:
         dist.destroy_process_group()
