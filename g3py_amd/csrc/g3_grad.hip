@@ -484,29 +484,38 @@ struct SeGradParams {
   double w[D];      // 0.5 * rate^2 (OU: rate)
   double rate[D];
   double var, alpha;
-  // optional second term pvar * prod_k cos(2 pi freq_k dx_k) (COS, kernels.py:466-467): f = 2 pi freq
-  double f[D];
+  // optional periodic term (COS, SIN or SM: kernels.py:466-467, 471-472, 486-487), added to the stationary term or
+  // multiplied with it (mul): f = 2 pi freq, pr = the periodic leaf's rate
+  double f[D], pr[D];
   double pvar;
+  int mul;
 };
 
-// PK = G3_K_COS adds the periodic term: d/dpvar = prod_k cos(t_k), d/dfreq_k = -pvar 2 pi dx_k sin(t_k) prod_{k' != k} cos(t_k'),
-// t_k = 2 pi freq_k dx_k, with cos / sin of the angle DIFFERENCE from per-tile tables (as the Gram fast path).
-// Slots: [var, noise, alpha, rate_0..D-1, pvar, freq_0..D-1]
+// PK >= 0 adds the periodic term p = pvar * k2, t_k = 2 pi freq_k dx_k, with cos / sin of the angle DIFFERENCE from per-tile
+// tables (as the Gram fast path):
+//   COS  k2 = prod_k cos t_k                         dk2/dfreq_k = -2 pi dx_k sin t_k prod_{k' != k} cos t_k'
+//   SM   k2 = exp(-2 pi^2 sum dx_k^2 r_k^2) prod cos dk2/dfreq_k as COS times the envelope, dk2/dr_k = -4 pi^2 dx_k^2 r_k k2
+//   SIN  k2 = exp(2 sum_k r_k sin^2(t_k / 2))        dk2/dr_k = (1 - cos t_k) k2,  dk2/dfreq_k = 2 pi r_k dx_k sin t_k k2
+// se.mul: K = (var k1)(pvar k2) -- each term's derivatives carry the other term's value -- instead of var k1 + pvar k2.
+// Slots: [var, noise, alpha, rate_0..D-1, pvar, freq_0..D-1, prate_0..D-1 (SIN, SM)]
 template <typename T, int D, int FK, int PK>
 __global__ void __launch_bounds__(GG_THREADS)
 gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int64_t ldx, const T* __restrict__ G,
                     int64_t ldg, const T* __restrict__ alpha, double* __restrict__ partial) {
   constexpr bool PER = PK >= 0;
-  constexpr int NS = PER ? 2 * D + 4 : D + 3;
+  constexpr bool PRATE = PK == G3_K_SIN || PK == G3_K_SM;
+  constexpr int NS = !PER ? D + 3 : PRATE ? 3 * D + 4 : 2 * D + 4;
   constexpr int TS2 = 2 * D + 1;     // trig row stride (odd)
   __shared__ double xi_s[GG_T * (D | 1)], xj_s[GG_T * (D | 1)], ai_s[GG_T], aj_s[GG_T];
   __shared__ double ti_s[PER ? GG_T * TS2 : 1], tj_s[PER ? GG_T * TS2 : 1];
   __shared__ double red[NS * (GG_THREADS / 64)];
   constexpr int dp = D | 1;
   const int tid = threadIdx.x;
-  double g_var = 0.0, g_noise = 0.0, g_alpha = 0.0, g_rate[D], g_pvar = 0.0, g_freq[D];
+  double g_var = 0.0, g_noise = 0.0, g_alpha = 0.0, g_rate[D], g_pvar = 0.0, g_freq[D], g_prate[PRATE ? D : 1];
 #pragma unroll
   for (int k = 0; k < D; ++k) { g_rate[k] = 0.0; g_freq[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < (PRATE ? D : 1); ++k) g_prate[k] = 0.0;
   const int64_t nt = (N + GG_T - 1) / GG_T;
   const int64_t ntiles = nt * (nt + 1) / 2;
   for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
@@ -559,25 +568,6 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
         dm[k] = FK == G3_K_OU ? fabs(dx) : dx * dx;
         dd = fma(dm[k], se.w[k], dd);
       }
-      if constexpr (PER) {
-        double cs[D], sn[D], pre[D + 1];
-        pre[0] = 1.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const double ci = ti_s[rr * TS2 + 2 * k], si = ti_s[rr * TS2 + 2 * k + 1];
-          cs[k] = ci * cj[k] + si * sj[k];      // cos(theta_i - theta_j)
-          sn[k] = si * cj[k] - ci * sj[k];      // sin(theta_i - theta_j)
-          pre[k + 1] = pre[k] * cs[k];
-        }
-        g_pvar = fma(g, pre[D], g_pvar);
-        double suf = 1.0;
-        const double gp = -g * se.pvar * (2.0 * GG_PI);
-#pragma unroll
-        for (int k = D - 1; k >= 0; --k) {
-          g_freq[k] = fma(gp * dxs[k] * sn[k], pre[k] * suf, g_freq[k]);
-          suf *= cs[k];
-        }
-      }
       double kv, dkdd;              // unit-variance kernel value and its derivative with respect to d
       if constexpr (FK == G3_K_MAT32) {
         const double s3 = sqrt(3.0 * dd), e = exp(-s3);
@@ -596,9 +586,54 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
         kv = exp(-dd);
         dkdd = -kv;
       }
-      g_var = fma(g, kv, g_var);
+      double ms = 1.0;              // multiplier of the stationary term's derivatives (product form: pvar * k2)
+      if constexpr (PER) {
+        const double mp = se.mul ? se.var * kv : 1.0;     // ... and of the periodic term's
+        double cs[D], sn[D], pre[D + 1];
+        double q2 = 0.0;            // SM: sum dx^2 r^2;  SIN: sum r (1 - cos t) / 2
+        pre[0] = 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double ci = ti_s[rr * TS2 + 2 * k], si = ti_s[rr * TS2 + 2 * k + 1];
+          cs[k] = ci * cj[k] + si * sj[k];      // cos(theta_i - theta_j)
+          sn[k] = si * cj[k] - ci * sj[k];      // sin(theta_i - theta_j)
+          pre[k + 1] = pre[k] * cs[k];
+          if constexpr (PK == G3_K_SM) q2 = fma(dxs[k] * dxs[k], se.pr[k] * se.pr[k], q2);
+          if constexpr (PK == G3_K_SIN) q2 = fma(0.5 * (1.0 - cs[k]), se.pr[k], q2);
+        }
+        const double gm = g * mp;
+        if constexpr (PK == G3_K_SIN) {
+          const double k2 = exp(2.0 * q2);
+          g_pvar = fma(gm, k2, g_pvar);
+          const double gp = gm * se.pvar * k2;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            g_prate[k] = fma(gp, 1.0 - cs[k], g_prate[k]);
+            g_freq[k] = fma(gp * (2.0 * GG_PI) * se.pr[k], dxs[k] * sn[k], g_freq[k]);
+          }
+          if (se.mul) ms = se.pvar * k2;
+        } else {
+          const double env = PK == G3_K_SM ? exp(-2.0 * GG_PI * GG_PI * q2) : 1.0;
+          const double k2 = env * pre[D];
+          g_pvar = fma(gm, k2, g_pvar);
+          double suf = 1.0;
+          const double gp = -gm * se.pvar * env * (2.0 * GG_PI);
+#pragma unroll
+          for (int k = D - 1; k >= 0; --k) {
+            g_freq[k] = fma(gp * dxs[k] * sn[k], pre[k] * suf, g_freq[k]);
+            suf *= cs[k];
+          }
+          if constexpr (PK == G3_K_SM) {
+            const double gr = gm * se.pvar * k2 * (-4.0 * GG_PI * GG_PI);
+#pragma unroll
+            for (int k = 0; k < D; ++k) g_prate[k] = fma(gr * se.pr[k], dxs[k] * dxs[k], g_prate[k]);
+          }
+          if (se.mul) ms = se.pvar * k2;
+        }
+      }
+      g_var = fma(g * ms, kv, g_var);
       if (diag) g_noise += g;
-      const double gv = g * dkdd * se.var;
+      const double gv = g * ms * dkdd * se.var;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         if constexpr (FK == G3_K_OU) g_rate[k] = fma(gv, dm[k], g_rate[k]);
@@ -616,6 +651,10 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
     vals[D + 3] = g_pvar;
 #pragma unroll
     for (int k = 0; k < D; ++k) vals[D + 4 + k] = g_freq[k];
+    if constexpr (PRATE) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) vals[2 * D + 4 + k] = g_prate[k];
+    }
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -633,21 +672,34 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
 
 template <int D>
 static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, int* leaf_se, int* leaf_noise, int* leaf_per) {
-  // returns the stationary leaf's kind, or -1; *leaf_per = the COS leaf of the sum, or -1
+  // the shapes of the Gram fast path (g3h_match_fast): one stationary leaf, optionally one periodic leaf added to it or
+  // multiplied with it, optionally white noise.  Returns the stationary leaf's kind, or -1; *leaf_per = the periodic leaf, or -1
   *leaf_per = -1;
   if (d != D || p->nprod < 1 || p->nprod > 3 || p->shift != 0.0) return -1;
-  int se = -1, noise = -1, per = -1;
+  int se = -1, noise = -1, per = -1, mul = 0;
+  auto is_stat = [](int kd) { return kd == G3_K_SE || kd == G3_K_OU || kd == G3_K_MAT32 || kd == G3_K_MAT52 || kd == G3_K_RQ; };
+  auto is_per = [](int kd) { return kd == G3_K_COS || kd == G3_K_SIN || kd == G3_K_SM; };
   for (int q = 0; q < p->nprod; ++q) {
-    if (p->prod[q].nfac != 1 || p->prod[q].coef != 1.0) return -1;
+    if (p->prod[q].coef != 1.0) return -1;
+    if (p->prod[q].nfac == 2) {
+      const int l0 = p->prod[q].fac[0], l1 = p->prod[q].fac[1];
+      if (se >= 0 || per >= 0) return -1;
+      if (is_stat(p->leaf[l0].kind) && is_per(p->leaf[l1].kind)) { se = l0; per = l1; }
+      else if (is_stat(p->leaf[l1].kind) && is_per(p->leaf[l0].kind)) { se = l1; per = l0; }
+      else return -1;
+      mul = 1;
+      continue;
+    }
+    if (p->prod[q].nfac != 1) return -1;
     const int l = p->prod[q].fac[0];
     const int kd = p->leaf[l].kind;
-    const bool stat = kd == G3_K_SE || kd == G3_K_OU || kd == G3_K_MAT32 || kd == G3_K_MAT52 || kd == G3_K_RQ;
-    if (stat && se < 0) se = l;
+    if (is_stat(kd) && se < 0) se = l;
     else if (kd == G3_K_NOISE && noise < 0) noise = l;
-    else if (kd == G3_K_COS && per < 0) per = l;
+    else if (is_per(kd) && per < 0) per = l;
     else return -1;
   }
   if (se < 0) return -1;
+  out->mul = mul;
   if (per >= 0) {     // instantiated for SE / MAT32 / MAT52 and d in {1, 2, 4, 8}, as the Gram fast path
     const g3_leaf& pl = p->leaf[per];
     const int kd = p->leaf[se].kind;
@@ -655,11 +707,12 @@ static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, i
     for (int k = 0; k < D; ++k) {
       if (pl.dims[k] != k) return -1;
       out->f[k] = 2.0 * GG_PI * pl.freq[k];
+      out->pr[k] = pl.rate[k];
     }
     out->pvar = pl.var;
     *leaf_per = per;
   } else {
-    for (int k = 0; k < D; ++k) out->f[k] = 0.0;
+    for (int k = 0; k < D; ++k) { out->f[k] = 0.0; out->pr[k] = 0.0; }
     out->pvar = 0.0;
   }
   const g3_leaf& lf = p->leaf[se];
@@ -685,7 +738,9 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   const int kind = match_se_grad<D>(prog, D, &se, &lse, &lnoise, &lper);
   *handled = kind >= 0;
   if (!*handled) return G3_OK;
-  const int ns = lper >= 0 ? 2 * D + 4 : D + 3;
+  const int pkind = lper >= 0 ? prog->leaf[lper].kind : -1;
+  const bool prate = pkind == G3_K_SIN || pkind == G3_K_SM;
+  const int ns = lper < 0 ? D + 3 : prate ? 3 * D + 4 : 2 * D + 4;
   const int64_t nt = (N + GG_T - 1) / GG_T;
   const int64_t ntiles = nt * (nt + 1) / 2;
   const int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
@@ -706,11 +761,16 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   } while (0)
   if (lper >= 0) {
     if constexpr (D == 1 || D == 2 || D == 4 || D == 8) {
-      switch (kind) {
-        case G3_K_SE: G3_GRAD_FAST(G3_K_SE, G3_K_COS); break;
-        case G3_K_MAT32: G3_GRAD_FAST(G3_K_MAT32, G3_K_COS); break;
-        default: G3_GRAD_FAST(G3_K_MAT52, G3_K_COS); break;
-      }
+#define G3_GRAD_FAST_PK(PKIND)                                  \
+  switch (kind) {                                               \
+    case G3_K_SE: G3_GRAD_FAST(G3_K_SE, PKIND); break;          \
+    case G3_K_MAT32: G3_GRAD_FAST(G3_K_MAT32, PKIND); break;    \
+    default: G3_GRAD_FAST(G3_K_MAT52, PKIND); break;            \
+  }
+      if (pkind == G3_K_SIN) { G3_GRAD_FAST_PK(G3_K_SIN) }
+      else if (pkind == G3_K_SM) { G3_GRAD_FAST_PK(G3_K_SM) }
+      else { G3_GRAD_FAST_PK(G3_K_COS) }
+#undef G3_GRAD_FAST_PK
     }
   } else {
     switch (kind) {
@@ -739,6 +799,8 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
     if (map->var[lper] >= 0) out_host[map->var[lper]] = h[D + 3];
     if (map->freq[lper] >= 0)
       for (int k = 0; k < D; ++k) out_host[map->freq[lper] + k] = h[D + 4 + k];
+    if (prate && map->rate[lper] >= 0)
+      for (int k = 0; k < D; ++k) out_host[map->rate[lper] + k] = h[2 * D + 4 + k];
   }
   return G3_OK;
 }

@@ -12,9 +12,13 @@ rng = np.random.default_rng(0)
 X = dev.upload(rng.uniform(0, N ** (1 / d), (N, d)))
 G = dev.alloc(N, N, np.float64, zero=True)
 al = dev.upload(rng.standard_normal(N))
-for kind in ['SE', 'OU', 'MAT32', 'MAT52', 'RQ', 'MAT52+COS']:
+for kind in ['SE', 'OU', 'MAT32', 'MAT52', 'RQ', 'MAT52+COS', 'MAT52*SM', 'SE+SIN']:
     if kind == 'MAT52+COS':
         spec = ('sum', ('sum', ('MAT52', 1.0, np.ones(d), None), ('COS', 0.5, np.full(d, 0.125), None)), ('NOISE', 0.1))
+    elif kind == 'MAT52*SM':
+        spec = ('sum', ('prod', ('MAT52', 1.0, np.ones(d), None), ('SM', 0.5, np.full(d, 0.125), np.full(d, 0.1), None)), ('NOISE', 0.1))
+    elif kind == 'SE+SIN':
+        spec = ('sum', ('sum', ('SE', 1.0, np.ones(d), None), ('SIN', 0.5, np.full(d, 0.125), np.full(d, 0.1), None)), ('NOISE', 0.1))
     else:
         spec = ('sum', (kind, 1.0, np.ones(d), 2.0, None) if kind == 'RQ' else (kind, 1.0, np.ones(d), None), ('NOISE', 0.1))
     prog = compile_spec(spec, d)

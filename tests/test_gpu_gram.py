@@ -361,3 +361,38 @@ def test_gram_grad_fast_path_stationary_plus_periodic(dev, stat, d, noise):
             want = 0.5 * np.sum(Gfull * dK)
             scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
             assert abs(out[slot] - want) < tol * scale, (stat, d, leaf, pname, k, out[slot], want)
+
+
+@pytest.mark.parametrize('per', ['COS', 'SIN', 'SM'])
+@pytest.mark.parametrize('form', ['sum', 'prod'])
+@pytest.mark.parametrize('d', [1, 2, 4, 8])
+@pytest.mark.parametrize('stat', ['SE', 'MAT52'])
+def test_gram_grad_fast_path_every_periodic_shape(dev, per, form, d, stat):
+    """the gradient twin of every compile-time Gram variant: stationary (+ or *) COS / SIN / SM (+ noise).  In the product
+    form each factor's derivatives carry the other factor's value (kernels.py KernelProd); SIN and SM add their own rate
+    slots (kernels.py:471-472, 486-487 differentiated).  Every slot against the oracle's dK/dparam, fp64 and fp32"""
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    N = 140
+    rng = np.random.default_rng(13 * d + len(stat) + 3 * len(per) + len(form))
+    X = rng.uniform(0, 3, (N, d))
+    X[9] = X[4]
+    r, f, pr = rng.uniform(0.4, 1.3, d), rng.uniform(0.05, 0.4, d), rng.uniform(0.05, 0.3, d)
+    leaf = ('COS', 0.6, f, None) if per == 'COS' else (per, 0.6, f, pr, None)
+    spec = orc.with_noise((form, (stat, 1.3, r, None), leaf), 0.15)
+    A = rng.standard_normal((N, N))
+    G = (A + A.T) / 2
+    alpha = rng.standard_normal(N)
+    K, grads = orc.kernel_cov_grads(spec, X)
+    Gfull = np.outer(alpha, alpha) - G
+    prog = compile_spec(spec, d)
+    gmap = dev.grad_layout(prog)
+    assert gmap.nslots == len(grads) == 1 + d + 1 + d + (0 if per == 'COS' else d) + 1
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-4)):
+        out = dev.gram_grad(prog, gmap, dev.upload(X.astype(dtype)), N, d, dev.upload(np.tril(G).astype(dtype)),
+                            dev.upload(alpha.astype(dtype)))
+        for (lf, pname, k, dK) in grads:
+            slot = getattr(gmap, pname)[lf] + (0 if k is None else k)
+            want = 0.5 * np.sum(Gfull * dK)
+            scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
+            assert abs(out[slot] - want) < tol * scale, (stat, per, form, d, lf, pname, k, out[slot], want)
