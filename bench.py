@@ -447,6 +447,24 @@ def main():
             % (world, args.nb, ('RCCL' if (native_transport == 'rccl' if native else backend == 'nccl') else 'gloo, host-staged: rehearsal'),
                'libg3hip g3_dist_* (C++ loop, library-owned communicators)' if native else 'torch.distributed (' + str(driver) + ')')
 
+    # several ranks: a step that never returns (a collective one rank did not enter) must not hold the node until the
+    # launcher's limit -- every rank carries a watchdog over its whole run and leaves with a line that says so
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get('G3_BENCH_WATCHDOG_S', '900'))
+
+        def _expired():
+            sys.stderr.write('bench.py: rank %d made no progress for %.0f s (a collective some rank never entered?); '
+                             'G3_DIST_DRIVER=python selects the torch.distributed driver\n' % (rank, limit))
+            if rank == 0:
+                print(json.dumps({'metric': 'GP logp+predict end-to-end', 'value': None, 'n_gpus': world,
+                                  'error': 'watchdog: no progress for %.0f s' % limit}), flush=True)
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(limit, _expired)
+        watchdog.daemon = True
+        watchdog.start()
     for _ in range(args.warmup):
         step()
     # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
@@ -627,6 +645,8 @@ def main():
         dgp.close()                       # communicators and driver buffers, before the contexts they live on
     if world > 1 or solo_pg:
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
     # explicit teardown while the HIP runtime is alive (streams, events, pinned buffers, workspaces)
     g3.Device.close_all()
     if failed:

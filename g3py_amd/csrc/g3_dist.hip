@@ -886,6 +886,11 @@ extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f,
   for (size_t i = 0; i < mine.size(); ++i) {
     size_t t = 0;
     while (t < D->my_chunks.size() && D->my_chunks[t] != mine[i] + 1) ++t;
+    if (t == D->my_chunks.size()) {     // the two dealings (plan: c % P; here: (c + 1) % P of the Xs chunk) must agree
+      snprintf(D->err, sizeof(D->err), "posterior_draws: right-hand-side chunk %d is not on rank %d", mine[i] + 1, D->rank);
+      cleanup();
+      return G3_ERR_HIP;
+    }
     G3D_TRYH(hipMemcpyAsync(sendb + i * pad * Np * es, Aat(D, D->rows_mat + (int64_t)t * pad, 0), (size_t)pad * Np * es,
                             hipMemcpyDeviceToDevice, s));
   }
