@@ -103,6 +103,8 @@ _SIGS = {
     'g3_potri': ([_P, _P, _I64, _I64, _P, C.c_int, _P, _I64, _P, _I64], C.c_int),
     'g3_gram_grad': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, C.c_int, _P, _I64,
                       _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_gram_grad_rows': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, C.c_int, _I64, _I64,
+                           _P, _I64, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_dlogp': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _I64, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_dlogp_batched': ([_P, C.POINTER(KernelProg), C.c_int, C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64,
@@ -117,6 +119,9 @@ _SIGS = {
                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     'g3_dist_posterior_draws': ([_P, C.POINTER(KernelProg), _P, _I64, _P, _P, _I64, _P, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)], C.c_int),
+    'g3_dist_set_grad': ([_P, C.c_int], C.c_int),
+    'g3_dist_gp_dlogp': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, C.c_double, C.POINTER(C.c_double),
+                          C.POINTER(C.c_double)], C.c_int),
     'g3_dist_comm_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
     'g3_dist_prof_enable': ([_P, C.c_int], C.c_int),
     'g3_dist_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),

@@ -175,6 +175,13 @@ struct g3_dist {
   char* avec = nullptr;         // 1 x Np: a = L^-1 delta, broadcast for the mean
   char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss
   int* info_dev = nullptr;
+  // gradient mode (g3_dist_set_grad): N / P more right-hand-side rows -- the identity, which the sweep turns into the
+  // rank's rows of L^-T -- and the rank's rows of K^-1 = L^-T L^-1
+  bool grad = false, have_inv = false;
+  int64_t rows_inv = 0, cmax_all = 1;
+  char* Kinv = nullptr;         // rows_mat x Np
+  char* alpha_dev = nullptr;    // 1 x Np: alpha = K^-1 delta (scaled), global order
+  char* agath = nullptr;        // world x cmax_all x nb: gathered alpha pieces
   std::vector<hipEvent_t> ev;   // B_k events + stream joins
   // accounting: per collective kind calls, bytes (sent + received by this rank), device milliseconds
   double n_calls[G3_NCOLL] = {0, 0, 0}, n_bytes[G3_NCOLL] = {0, 0, 0};
@@ -389,9 +396,12 @@ extern "C" int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb
 }
 
 static void free_plan(g3_dist* D) {
-  void* bufs[] = {D->A, D->dbuf[0], D->dbuf[1], D->send[0], D->send[1], D->gath[0], D->gath[1], D->gath[2], D->avec, D->dots};
+  void* bufs[] = {D->A, D->dbuf[0], D->dbuf[1], D->send[0], D->send[1], D->gath[0], D->gath[1], D->gath[2], D->avec, D->dots,
+                  D->Kinv, D->alpha_dev, D->agath};
   for (void* b : bufs) if (b) (void)hipFree(b);
   D->A = D->dbuf[0] = D->dbuf[1] = D->send[0] = D->send[1] = D->gath[0] = D->gath[1] = D->gath[2] = D->avec = D->dots = nullptr;
+  D->Kinv = D->alpha_dev = D->agath = nullptr;
+  D->have_inv = false;
   for (hipEvent_t e : D->ev) (void)hipEventDestroy(e);
   D->ev.clear();
   D->planned = false;
@@ -442,7 +452,14 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   std::vector<int32_t> idx;
   D->cmax = D->nblk > 1 ? perm_of(D, 0, &idx) : 1;
   if (D->cmax < 1) D->cmax = 1;
-  const size_t rows = (size_t)(D->rows_mat + D->rows_rhs);
+  D->rows_inv = 0;
+  D->cmax_all = 1;
+  if (D->grad) {
+    D->rows_inv = D->rows_mat;
+    D->cmax_all = perm_of(D, -1, &idx);       // all blocks: the panels of L^-T reach from block 0 down
+    if (D->cmax < D->cmax_all) D->cmax = D->cmax_all;
+  }
+  const size_t rows = (size_t)(D->rows_mat + D->rows_rhs + D->rows_inv);
   G3D_HIP(hipMalloc((void**)&D->A, (rows ? rows : 1) * D->Np * D->es));
   G3D_HIP(hipMemsetAsync(D->A, 0, (rows ? rows : 1) * D->Np * D->es, D->ctx->stream));
   for (int i = 0; i < 2; ++i) {
@@ -454,6 +471,11 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   for (int i = 0; i < 3; ++i) G3D_HIP(hipMalloc((void**)&D->gath[i], (size_t)D->world * D->cmax * nb * nb * D->es));
   G3D_HIP(hipMalloc((void**)&D->avec, (size_t)D->Np * D->es));
   G3D_HIP(hipMalloc((void**)&D->dots, 2 * 128 * D->es));
+  if (D->grad) {
+    G3D_HIP(hipMalloc((void**)&D->Kinv, (size_t)(D->rows_mat ? D->rows_mat : 1) * D->Np * D->es));
+    G3D_HIP(hipMalloc((void**)&D->alpha_dev, (size_t)D->Np * D->es));
+    G3D_HIP(hipMalloc((void**)&D->agath, (size_t)D->world * D->cmax_all * nb * D->es));
+  }
   D->ev.resize(D->nblk + 5);
   for (auto& e : D->ev) G3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   G3D_HIP(hipStreamSynchronize(D->ctx->stream));
@@ -504,6 +526,11 @@ static int build(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* p
     int rc = rhs_rows(D, (int)t, D->my_chunks[t], prog_cross, X, ldx, Xs, ldxs, delta);
     if (rc) return rc;
   }
+  if (D->rows_inv > 0) {     // the identity, row block I of it stored like block I of the matrix
+    G3D_HIP(hipMemsetAsync(Aat(D, D->rows_mat + D->rows_rhs, 0), 0, (size_t)D->rows_inv * D->Np * D->es, D->ctx->stream));
+    for (int I : D->my_blocks)
+      G3D_RC(D->ctx, g3_diag_add(D->ctx, Aat(D, D->rows_mat + D->rows_rhs + D->loff[I], (int64_t)I * nb), nb, D->Np, D->dt, 1.0));
+  }
   // tt_to_cov (tensors.py:95-98): min over the WHOLE diagonal
   double g = isfinite(lmin) ? lmin : 1e300;
   int rc = do_allreduce(D, &g, 1, 1);
@@ -534,12 +561,16 @@ static int64_t rows_done(const g3_dist* D, int k) {   // local rows of the block
   return c;
 }
 
+// gradient mode: identity row block I is zero left of column block I, so it joins the sweep at panel I -- the active
+// identity rows at panel k are the local rows of the blocks <= k, a prefix of the identity region
+static int64_t inv_active(const g3_dist* D, int k) { return D->rows_inv > 0 ? rows_done(D, k) : 0; }
+
 // panel k: solve my rows below block k (right-hand-side rows included) against L_kk, then all-gather them into
 // gath[k % 3] -- all on the chain stream, which has nothing else to do until the panel is there
 static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const int64_t nb = D->nb, c0 = (int64_t)k * nb;
   const int64_t r_lo = rows_done(D, k);
-  const int64_t m = D->rows_mat + D->rows_rhs - r_lo;
+  const int64_t m = D->rows_mat + D->rows_rhs - r_lo + inv_active(D, k);
   if (m > 0) G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), m, D->Np, D->dt, Wof(D, k)));
   // the look-ahead of block k+1 needs these rows, not the gathered panel: it starts while the all-gather is in flight
   G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
@@ -575,18 +606,24 @@ static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_solved, 
   return G3_OK;
 }
 
-static int stair(g3_dist* D, g3_ctx* cx, int64_t row0, int64_t col0, int64_t kcol, const char* G, const std::vector<int64_t>& seg_rows,
-                 const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm, const std::vector<int64_t>* seg_diag = nullptr) {
-  // C[rows_s, col0 : col0 + seg_cols[s]) -= A[rows_s, kcol : kcol + nb) G[block table]^T, cut into launches of at
-  // most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
+static int stair_ptr(g3_dist* D, g3_ctx* cx, char* C, const char* A, const char* G, const std::vector<int64_t>& seg_rows,
+                     const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm, const std::vector<int64_t>* seg_diag,
+                     double alpha) {
+  // C[rows_s, 0 : seg_cols[s]) += alpha * A[rows_s, 0 : nb) G[block table]^T (C and A full-width local rows, ld = Np),
+  // cut into launches of at most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
   std::vector<G3hStairChunk> ch;
   g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch, seg_diag);
   for (const auto& c : ch) {
-    G3D_RC(cx, g3_gemm_nt_stair(cx, Aat(D, row0 + c.row0, col0 + c.col0), D->Np, Aat(D, row0 + c.row0, kcol), D->Np, G, D->nb, D->nb,
-                                c.rows.data(), c.cols.data(), (int)c.rows.size(), -1.0, 1.0, D->dt, D->nb, perm + c.blk0, c.nblk,
-                                seg_diag ? c.diag.data() : nullptr));
+    G3D_RC(cx, g3_gemm_nt_stair(cx, C + ((size_t)c.row0 * D->Np + c.col0) * D->es, D->Np, A + (size_t)c.row0 * D->Np * D->es, D->Np, G,
+                                D->nb, D->nb, c.rows.data(), c.cols.data(), (int)c.rows.size(), alpha, 1.0, D->dt, D->nb, perm + c.blk0,
+                                c.nblk, seg_diag ? c.diag.data() : nullptr));
   }
   return G3_OK;
+}
+static int stair(g3_dist* D, g3_ctx* cx, int64_t row0, int64_t col0, int64_t kcol, const char* G, const std::vector<int64_t>& seg_rows,
+                 const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm, const std::vector<int64_t>* seg_diag = nullptr) {
+  // C[rows_s, col0 : col0 + seg_cols[s]) -= A[rows_s, kcol : kcol + nb) G[block table]^T inside the local matrix
+  return stair_ptr(D, cx, Aat(D, row0, col0), Aat(D, row0, kcol), G, seg_rows, seg_cols, perm, nperm, seg_diag, -1.0);
 }
 
 static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X, int64_t ldx, const void* Xs,
@@ -618,6 +655,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
     perm_of(D, k, &perm);
     const char* G = D->gath[k % 3];
     hipEvent_t ev_k = nullptr;
+    const int64_t rr = D->rows_rhs + inv_active(D, k);     // right-hand-side rows panel k applies to
     // ---- bulk stream: everything beyond block column k+1 (after the gather of panel k, queued on the chain)
     rc = stream_after(D, sB, sA, ev_tmp);
     if (rc) return rc;
@@ -626,7 +664,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
       seg_rows.clear(); seg_cols.clear(); seg_diag.clear();
       int64_t lo = -1;
       for (int I : D->my_blocks) if (I >= k + 2) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back(nb); seg_diag.push_back(I == k + 2); }
-      if (D->rows_rhs > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back(nb); seg_diag.push_back(0); }
+      if (rr > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(rr); seg_cols.push_back(nb); seg_diag.push_back(0); }
       if (!seg_rows.empty()) {
         rc = stair(D, D->ctx_bulk, lo, c2, c0, G, seg_rows, seg_cols, perm.data() + 1, 1, &seg_diag);
         if (rc) return rc;
@@ -637,7 +675,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
       seg_rows.clear(); seg_cols.clear(); seg_diag.clear();
       lo = -1;
       for (int I : D->my_blocks) if (I >= k + 3) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back((int64_t)(I - k - 2) * nb); seg_diag.push_back(1); }
-      if (D->rows_rhs > 0 && nblk - k - 3 > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back((int64_t)(nblk - k - 3) * nb); seg_diag.push_back(0); }
+      if (rr > 0 && nblk - k - 3 > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(rr); seg_cols.push_back((int64_t)(nblk - k - 3) * nb); seg_diag.push_back(0); }
       if (!seg_rows.empty()) {
         rc = stair(D, D->ctx_bulk, lo, c3, c0, G, seg_rows, seg_cols, perm.data() + 2, (int)perm.size() - 2, &seg_diag);
         if (rc) return rc;
@@ -649,7 +687,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
       seg_rows.clear(); seg_cols.clear();
       int64_t lo = -1;
       for (int I : D->my_blocks) if (I >= k + 2) { if (lo < 0) lo = D->loff[I]; seg_rows.push_back(nb); seg_cols.push_back(nb); }
-      if (D->rows_rhs > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(D->rows_rhs); seg_cols.push_back(nb); }
+      if (rr > 0) { if (lo < 0) lo = D->rows_mat; seg_rows.push_back(rr); seg_cols.push_back(nb); }
       if (!seg_rows.empty()) {
         rc = stair(D, D->ctx, lo, c1, c0, G, seg_rows, seg_cols, perm.data(), 1);
         if (rc) return rc;
@@ -738,8 +776,19 @@ static int factor_robust(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel
       }
       if (D->rows_rhs > 0)
         G3D_RC(D->ctx, g3i_scale(D->ctx, Aat(D, D->rows_mat, 0), D->rows_rhs, D->N, D->Np, D->dt, 1.0 / c));
+      if (D->rows_inv > 0) {     // L^-T of the fallback factor: 1e10 on the valid diagonal, 1 on the padding
+        G3D_HIP(hipMemsetAsync(Aat(D, D->rows_mat + D->rows_rhs, 0), 0, (size_t)D->rows_inv * D->Np * D->es, D->ctx->stream));
+        for (int I : D->my_blocks) {
+          const int64_t nv0 = D->N - (int64_t)I * D->nb;
+          const int64_t nv = nv0 < 0 ? 0 : (nv0 < D->nb ? nv0 : D->nb);
+          char* Dg = Aat(D, D->rows_mat + D->rows_rhs + D->loff[I], (int64_t)I * D->nb);
+          if (nv > 0) G3D_RC(D->ctx, g3_diag_add(D->ctx, Dg, nv, D->Np, D->dt, 1.0 / c));
+          if (nv < D->nb) G3D_RC(D->ctx, g3_diag_add(D->ctx, Dg + ((size_t)nv * D->Np + nv) * D->es, D->nb - nv, D->Np, D->dt, 1.0));
+        }
+      }
     }
   }
+  D->have_inv = D->grad;
   D->last_info = info;
   D->last_tries = tries;
   D->last_fallback = fallback;
@@ -929,6 +978,148 @@ extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f,
   cleanup();
 #undef G3D_TRY
 #undef G3D_TRYH
+  return G3_OK;
+}
+
+// ---------------------------------------------------------------------------------------- gradient of logp
+// dlogp / dtheta = 1/2 sum_ij (alpha_i alpha_j - K^-1_ij) dK_ij / dtheta,  alpha = K^-1 delta  (the reference differentiates
+// through CholeskyRobust.grad, tensors.py:224-260; stochastic.py:308-309).  In gradient mode the factorisation carries the
+// identity as extra right-hand-side rows, so every rank ends up with ITS rows of X = L^-T (upper triangular: row block I
+// starts at column block I).  K^-1 = X X^T: for every column block k the ranks all-gather the panel X[:, k] (rows of the
+// blocks <= k) and add X[I, k] X[J, k]^T to the rows I <= k they own, columns J <= I -- the staircase launch of the
+// factorisation run backwards, N^3 / 3 flops over all ranks, no dependency between the steps (gather k + 1 overlaps the
+// product k).  alpha = X a; then one pass of the gradient kernel over the rank's rows of K^-1, and an all-reduce of the
+// parameter sums.
+template <typename T>
+__global__ void __launch_bounds__(256) rows_dot_kernel(const T* __restrict__ A, int64_t rows, int64_t cols, int64_t ld,
+                                                      const T* __restrict__ v, T* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (int64_t j = lane; j < cols; j += 64) acc = fma((double)A[r * ld + j], (double)v[j], acc);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[r] = (T)acc;
+}
+
+static int perm_upto(const g3_dist* D, int k, std::vector<int32_t>* idx) {   // blocks 0 .. k in the rank-major gather
+  const int P = D->world;
+  std::vector<int> cnt(P, 0), seen(P, 0);
+  for (int I = 0; I <= k; ++I) cnt[owner_of(D, I)]++;
+  int c = 1;
+  for (int q = 0; q < P; ++q) c = cnt[q] > c ? cnt[q] : c;
+  idx->clear();
+  for (int I = 0; I <= k; ++I) {
+    const int q = owner_of(D, I);
+    idx->push_back(q * c + seen[q]++);
+  }
+  return c;
+}
+
+extern "C" int g3_dist_set_grad(g3_dist* D, int on) {
+  if (!D) return -1;
+  const bool want = on != 0;
+  if (D->grad == want) return G3_OK;
+  D->grad = want;
+  D->have_inv = false;
+  if (!D->planned) return G3_OK;
+  return g3_dist_plan(D, D->N, D->d, D->M, D->nb, D->dt);     // the local matrix changes size
+}
+
+extern "C" int g3_dist_gp_dlogp(g3_dist* D, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev, int64_t ldx,
+                                double alpha_scale, double* slots_host, double* alpha_host) {
+  if (!D) return -1;
+  if (!D->planned || !D->grad || !D->have_inv) {
+    if (D) snprintf(D->err, sizeof(D->err), "g3_dist_gp_dlogp: g3_dist_set_grad(1) and g3_dist_gp_factor_predict first");
+    return -1;
+  }
+  if (!prog || g3i_validate_prog(prog, D->d)) return -2;
+  if (!map || map->nslots < 0 || map->nslots > G3_GRAD_MAXSLOTS) return -3;
+  if (!X_dev) return -4;
+  if (ldx < D->d) return -5;
+  if (!slots_host) return -7;
+  g3_dev_guard _dg(D->ctx);
+  const int64_t nb = D->nb, Np = D->Np;
+  const size_t es = D->es;
+  const int nblk = D->nblk;
+  hipStream_t sA = D->ctx->stream, sB = D->s_bulk;
+  hipEvent_t ev_tmp = D->ev[nblk], ev_join = D->ev[nblk + 1];
+  const char* Xinv = Aat(D, D->rows_mat + D->rows_rhs, 0);
+  // ---- alpha = X a (a = L^-1 delta: the broadcast copy stats() left in avec), gathered and put in global order
+  std::vector<int32_t> perm;
+  const int call = perm_upto(D, nblk - 1, &perm);
+  const int64_t apr = (int64_t)call * nb;               // alpha entries per rank in the padded gather
+  char* asend = D->send[0];                             // cmax >= cmax_all blocks of nb x nb: room for cmax_all * nb values
+  G3D_HIP(hipMemsetAsync(asend, 0, (size_t)apr * es, sA));
+  if (D->rows_inv > 0) {
+    const unsigned grid = (unsigned)((D->rows_inv + 3) / 4);
+    if (D->dt == G3_F64)
+      hipLaunchKernelGGL(rows_dot_kernel<double>, dim3(grid), dim3(256), 0, sA, (const double*)Xinv, D->rows_inv, Np, Np,
+                         (const double*)D->avec, (double*)asend);
+    else
+      hipLaunchKernelGGL(rows_dot_kernel<float>, dim3(grid), dim3(256), 0, sA, (const float*)Xinv, D->rows_inv, Np, Np,
+                         (const float*)D->avec, (float*)asend);
+    G3D_HIP(hipGetLastError());
+  }
+  int rc = do_allgather(D, asend, D->agath, (size_t)apr * es, sA);
+  if (rc) return rc;
+  std::vector<char> hg((size_t)D->world * apr * es), ha((size_t)Np * es);
+  G3D_HIP(hipMemcpyAsync(hg.data(), D->agath, hg.size(), hipMemcpyDeviceToHost, sA));
+  G3D_HIP(hipStreamSynchronize(sA));
+  for (int I = 0; I < nblk; ++I)
+    for (int64_t r = 0; r < nb; ++r) {
+      const size_t src = (size_t)perm[I] * nb + r, dst = (size_t)I * nb + r;
+      if (D->dt == G3_F64) {
+        const double v = ((const double*)hg.data())[src] * alpha_scale;
+        ((double*)ha.data())[dst] = v;
+        if (alpha_host && (int64_t)dst < D->N) alpha_host[dst] = v;
+      } else {
+        const float v = (float)(((const float*)hg.data())[src] * alpha_scale);
+        ((float*)ha.data())[dst] = v;
+        if (alpha_host && (int64_t)dst < D->N) alpha_host[dst] = (double)v;
+      }
+    }
+  G3D_HIP(hipMemcpyAsync(D->alpha_dev, ha.data(), ha.size(), hipMemcpyHostToDevice, sA));
+  // ---- my rows of K^-1 = X X^T, lower part
+  if (D->rows_mat > 0) G3D_HIP(hipMemsetAsync(D->Kinv, 0, (size_t)D->rows_mat * Np * es, sA));
+  std::vector<int64_t> seg_rows, seg_cols, seg_diag;
+  for (int k = 0; k < nblk; ++k) {
+    const int cnt = perm_upto(D, k, &perm);
+    const int64_t act = rows_done(D, k);
+    if (k >= 3) G3D_HIP(hipStreamWaitEvent(sA, D->ev[k - 3], 0));     // the product that read gath[k % 3] is done
+    if (act > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, D->send[k % 2], nb, Xinv + (size_t)k * nb * es, Np, act, nb, D->dt));
+    rc = do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * es, sA);
+    if (rc) return rc;
+    rc = stream_after(D, sB, sA, ev_tmp);
+    if (rc) return rc;
+    seg_rows.clear(); seg_cols.clear(); seg_diag.clear();
+    for (int I : D->my_blocks) if (I <= k) { seg_rows.push_back(nb); seg_cols.push_back((int64_t)(I + 1) * nb); seg_diag.push_back(1); }
+    if (!seg_rows.empty()) {
+      rc = stair_ptr(D, D->ctx_bulk, D->Kinv, Xinv + (size_t)k * nb * es, D->gath[k % 3], seg_rows, seg_cols, perm.data(), k + 1,
+                     &seg_diag, 1.0);
+      if (rc) return rc;
+    }
+    G3D_HIP(hipEventRecord(D->ev[k], sB));
+  }
+  rc = stream_after(D, sA, sB, ev_join);
+  if (rc) return rc;
+  // ---- the parameter sums over my rows, then over the ranks
+  const int ns = map->nslots;
+  std::vector<double> acc(ns > 0 ? ns : 1, 0.0), part(ns > 0 ? ns : 1, 0.0);
+  for (int I : D->my_blocks) {
+    const int64_t r0 = (int64_t)I * nb;
+    const int64_t nv = D->N - r0 < nb ? D->N - r0 : nb;
+    if (nv <= 0 || ns == 0) continue;
+    G3D_RC(D->ctx, g3i_gram_grad(D->ctx, prog, map, X_dev, D->N, ldx, D->d, D->dt, D->Kinv + (size_t)D->loff[I] * Np * es, Np,
+                                 D->alpha_dev, part.data(), r0, nv));
+    for (int q = 0; q < ns; ++q) acc[q] += part[q];
+  }
+  G3D_HIP(hipStreamSynchronize(sA));
+  if (ns > 0) {
+    rc = do_allreduce(D, acc.data(), ns, 0);
+    if (rc) return rc;
+  }
+  for (int q = 0; q < ns; ++q) slots_host[q] = acc[q];
   return G3_OK;
 }
 

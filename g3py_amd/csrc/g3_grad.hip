@@ -361,7 +361,8 @@ template <typename T>
 __global__ void __launch_bounds__(GG_THREADS)
 gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const T* __restrict__ X, int64_t N,
                  int64_t ldx, int d, const T* __restrict__ G, int64_t ldg, const T* __restrict__ alpha,
-                 double* __restrict__ partial, int lo, int width) {
+                 double* __restrict__ partial, int lo, int width, int64_t row0, int64_t row1) {
+  // rows [row0, row1) of the lower triangle (row0 a multiple of the tile edge); G holds those rows only
   extern __shared__ __attribute__((aligned(16))) char smem_gg[];
   const int dp = d | 1;
   double* xi_s = (double*)smem_gg;             // GG_T x dp
@@ -396,9 +397,10 @@ gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const
   }
   __syncthreads();
   const bool multi = need_lv != 0;
-  const int64_t nt = (N + GG_T - 1) / GG_T;
-  const int64_t ntiles = nt * (nt + 1) / 2;
-  for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
+  const int64_t bi0 = row0 / GG_T, bi1 = (row1 + GG_T - 1) / GG_T;
+  const int64_t id0 = bi0 * (bi0 + 1) / 2, ntiles = bi1 * (bi1 + 1) / 2 - id0;
+  for (int64_t idl = blockIdx.x; idl < ntiles; idl += gridDim.x) {
+    const int64_t id = id0 + idl;
     int64_t bi = (int64_t)((sqrt(1.0 + 8.0 * (double)id) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
     while (bi * (bi + 1) / 2 > id) --bi;
@@ -407,10 +409,10 @@ gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const
     __syncthreads();
     for (int e = tid; e < GG_T * d; e += GG_THREADS) {
       const int r = e / d, c = e - r * d;
-      xi_s[r * dp + c] = i0 + r < N ? (double)X[(i0 + r) * ldx + c] : 0.0;
+      xi_s[r * dp + c] = i0 + r < row1 ? (double)X[(i0 + r) * ldx + c] : 0.0;
       xj_s[r * dp + c] = j0 + r < N ? (double)X[(j0 + r) * ldx + c] : 0.0;
     }
-    if (tid < GG_T) ai_s[tid] = i0 + tid < N ? (double)alpha[i0 + tid] : 0.0;
+    if (tid < GG_T) ai_s[tid] = i0 + tid < row1 ? (double)alpha[i0 + tid] : 0.0;
     else if (tid < 2 * GG_T) aj_s[tid - GG_T] = j0 + tid - GG_T < N ? (double)alpha[j0 + tid - GG_T] : 0.0;
     __syncthreads();
     const int c = tid & (GG_T - 1);
@@ -418,11 +420,11 @@ gram_grad_kernel(const g3_kernel_prog* __restrict__ prog, g3_grad_map map, const
     const double* xj = xj_s + c * dp;
     for (int rr = tid >> 6; rr < GG_T; rr += GG_THREADS / GG_T) {
       const int64_t i = i0 + rr;
-      if (i >= N || j > i) continue;
+      if (i >= row1 || j > i) continue;
       const bool diag = i == j;
       const double* xi = xi_s + rr * dp;
       // G_ij with the symmetric pair (j, i) folded in
-      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj_s[c] - (double)G[i * ldg + j]);
+      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj_s[c] - (double)G[(i - row0) * ldg + j]);
       if (!multi) {
         for (int l = 0; l < nleaf; ++l)
           if (qconst[l] != 0.0) leaf_grad(sp.leaf[l], l, map, xi, xj, diag, g * qconst[l], add);
@@ -501,7 +503,7 @@ struct SeGradParams {
 template <typename T, int D, int FK, int PK>
 __global__ void __launch_bounds__(GG_THREADS)
 gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int64_t ldx, const T* __restrict__ G,
-                    int64_t ldg, const T* __restrict__ alpha, double* __restrict__ partial) {
+                    int64_t ldg, const T* __restrict__ alpha, double* __restrict__ partial, int64_t row0, int64_t row1) {
   constexpr bool PER = PK >= 0;
   constexpr bool PRATE = PK == G3_K_SIN || PK == G3_K_SM;
   constexpr int NS = !PER ? D + 3 : PRATE ? 3 * D + 4 : 2 * D + 4;
@@ -516,9 +518,10 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
   for (int k = 0; k < D; ++k) { g_rate[k] = 0.0; g_freq[k] = 0.0; }
 #pragma unroll
   for (int k = 0; k < (PRATE ? D : 1); ++k) g_prate[k] = 0.0;
-  const int64_t nt = (N + GG_T - 1) / GG_T;
-  const int64_t ntiles = nt * (nt + 1) / 2;
-  for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
+  const int64_t bi0 = row0 / GG_T, bi1 = (row1 + GG_T - 1) / GG_T;
+  const int64_t id0 = bi0 * (bi0 + 1) / 2, ntiles = bi1 * (bi1 + 1) / 2 - id0;
+  for (int64_t idl = blockIdx.x; idl < ntiles; idl += gridDim.x) {
+    const int64_t id = id0 + idl;
     int64_t bi = (int64_t)((sqrt(1.0 + 8.0 * (double)id) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
     while (bi * (bi + 1) / 2 > id) --bi;
@@ -527,10 +530,10 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
     __syncthreads();
     for (int e = tid; e < GG_T * D; e += GG_THREADS) {
       const int r = e / D, c = e - r * D;
-      xi_s[r * dp + c] = i0 + r < N ? (double)X[(i0 + r) * ldx + c] : 0.0;
+      xi_s[r * dp + c] = i0 + r < row1 ? (double)X[(i0 + r) * ldx + c] : 0.0;
       xj_s[r * dp + c] = j0 + r < N ? (double)X[(j0 + r) * ldx + c] : 0.0;
     }
-    if (tid < GG_T) ai_s[tid] = i0 + tid < N ? (double)alpha[i0 + tid] : 0.0;
+    if (tid < GG_T) ai_s[tid] = i0 + tid < row1 ? (double)alpha[i0 + tid] : 0.0;
     else if (tid < 2 * GG_T) aj_s[tid - GG_T] = j0 + tid - GG_T < N ? (double)alpha[j0 + tid - GG_T] : 0.0;
     __syncthreads();
     if constexpr (PER) {
@@ -557,9 +560,9 @@ gram_grad_se_kernel(SeGradParams<D> se, const T* __restrict__ X, int64_t N, int6
 #pragma unroll 4
     for (int rr = tid >> 6; rr < GG_T; rr += GG_THREADS / GG_T) {
       const int64_t i = i0 + rr;
-      if (i >= N || j > i) continue;
+      if (i >= row1 || j > i) continue;
       const bool diag = i == j;
-      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj - (double)G[i * ldg + j]);
+      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj - (double)G[(i - row0) * ldg + j]);
       double dm[D], dxs[D], dd = 0.0;       // dm: dx^2 (|dx| for OU)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
@@ -732,7 +735,7 @@ static int match_se_grad(const g3_kernel_prog* p, int d, SeGradParams<D>* out, i
 template <int D>
 static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N,
                         int64_t ldx, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
-                        bool* handled) {
+                        bool* handled, int64_t row0, int64_t row1) {
   SeGradParams<D> se;
   int lse = -1, lnoise = -1, lper = -1;
   const int kind = match_se_grad<D>(prog, D, &se, &lse, &lnoise, &lper);
@@ -741,23 +744,23 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
   const int pkind = lper >= 0 ? prog->leaf[lper].kind : -1;
   const bool prate = pkind == G3_K_SIN || pkind == G3_K_SM;
   const int ns = lper < 0 ? D + 3 : prate ? 3 * D + 4 : 2 * D + 4;
-  const int64_t nt = (N + GG_T - 1) / GG_T;
-  const int64_t ntiles = nt * (nt + 1) / 2;
+  const int64_t bi0 = row0 / GG_T, bi1 = (row1 + GG_T - 1) / GG_T;
+  const int64_t ntiles = bi1 * (bi1 + 1) / 2 - bi0 * (bi0 + 1) / 2;
   const int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
   const size_t pbytes = (size_t)nblocks * ns * sizeof(double);
   int rc = g3i_ensure_work(ctx, pbytes + 64 * sizeof(double));
   if (rc) return rc;
   double* partial = (double*)ctx->work;
   double* dout = (double*)((char*)ctx->work + pbytes);
-  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * (N + 1) / 2 * g3_esize(dt));
+  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (row0 == 0 && row1 == N ? (double)N * (N + 1) / 2 : (double)ntiles * GG_T * GG_T) * g3_esize(dt));
 #define G3_GRAD_FAST(KIND, PKIND)                                                                                   \
   do {                                                                                                              \
     if (dt == G3_F64)                                                                                               \
       hipLaunchKernelGGL((gram_grad_se_kernel<double, D, KIND, PKIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se, \
-                         (const double*)X, N, ldx, (const double*)G, ldg, (const double*)alpha, partial);           \
+                         (const double*)X, N, ldx, (const double*)G, ldg, (const double*)alpha, partial, row0, row1); \
     else                                                                                                            \
       hipLaunchKernelGGL((gram_grad_se_kernel<float, D, KIND, PKIND>), dim3(nblocks), dim3(GG_THREADS), 0, ctx->stream, se,  \
-                         (const float*)X, N, ldx, (const float*)G, ldg, (const float*)alpha, partial);              \
+                         (const float*)X, N, ldx, (const float*)G, ldg, (const float*)alpha, partial, row0, row1);  \
   } while (0)
   if (lper >= 0) {
     if constexpr (D == 1 || D == 2 || D == 4 || D == 8) {
@@ -806,9 +809,13 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_m
 }
 
 int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N,
-                  int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host) {
+                  int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
+                  int64_t row0, int64_t nrows) {
+  // nrows < 0: the whole lower triangle; otherwise rows [row0, row0 + nrows) of it, G = those rows (multi-GPU driver)
   const int nslots = map->nslots;
-  if (nslots == 0 || N == 0) {
+  const int64_t row1 = nrows < 0 ? N : (row0 + nrows < N ? row0 + nrows : N);
+  if (nrows < 0) row0 = 0;
+  if (nslots == 0 || N == 0 || row1 <= row0) {
     for (int s = 0; s < nslots; ++s) out_host[s] = 0.0;
     return G3_OK;
   }
@@ -821,12 +828,12 @@ int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* ma
     bool done = false;
     int r = G3_OK;
     switch (d) {
-      case 1: r = gram_grad_se<1>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
-      case 2: r = gram_grad_se<2>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
-      case 3: r = gram_grad_se<3>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
-      case 4: r = gram_grad_se<4>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
-      case 8: r = gram_grad_se<8>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
-      case 16: r = gram_grad_se<16>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done); break;
+      case 1: r = gram_grad_se<1>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done, row0, row1); break;
+      case 2: r = gram_grad_se<2>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done, row0, row1); break;
+      case 3: r = gram_grad_se<3>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done, row0, row1); break;
+      case 4: r = gram_grad_se<4>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done, row0, row1); break;
+      case 8: r = gram_grad_se<8>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done, row0, row1); break;
+      case 16: r = gram_grad_se<16>(ctx, prog, map, X, N, ldx, dt, G, ldg, alpha, out_host, &done, row0, row1); break;
       default: break;
     }
     if (r || done) return r;
@@ -841,8 +848,8 @@ int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* ma
   if (window > 32) window = 32;      // keeps two workgroups per CU for the usual d
   if (window > nslots) window = nslots;
   if (window < 1) return G3_ERR_NOMEM;
-  const int64_t nt = (N + GG_T - 1) / GG_T;
-  const int64_t ntiles = nt * (nt + 1) / 2;
+  const int64_t bi0 = row0 / GG_T, bi1 = (row1 + GG_T - 1) / GG_T;
+  const int64_t ntiles = bi1 * (bi1 + 1) / 2 - bi0 * (bi0 + 1) / 2;
   const int nblocks = (int)(ntiles < 2048 ? ntiles : 2048);
   const size_t pbytes = (size_t)nblocks * window * sizeof(double);
   const size_t obytes = (size_t)g3_roundup(nslots, 32) * sizeof(double);
@@ -855,15 +862,15 @@ int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* ma
     G3_HIP(hipFuncSetAttribute((const void*)gram_grad_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else
     G3_HIP(hipFuncSetAttribute((const void*)gram_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)N * (N + 1) / 2 * g3_esize(dt));
+  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (row0 == 0 && row1 == N ? (double)N * (N + 1) / 2 : (double)ntiles * GG_T * GG_T) * g3_esize(dt));
   for (int lo = 0; lo < nslots; lo += window) {
     const int width = nslots - lo < window ? nslots - lo : window;
     if (dt == G3_F64)
       hipLaunchKernelGGL((gram_grad_kernel<double>), dim3(nblocks), dim3(GG_THREADS), lds, ctx->stream, dprog, *map,
-                         (const double*)X, N, ldx, d, (const double*)G, ldg, (const double*)alpha, partial, lo, width);
+                         (const double*)X, N, ldx, d, (const double*)G, ldg, (const double*)alpha, partial, lo, width, row0, row1);
     else
       hipLaunchKernelGGL((gram_grad_kernel<float>), dim3(nblocks), dim3(GG_THREADS), lds, ctx->stream, dprog, *map,
-                         (const float*)X, N, ldx, d, (const float*)G, ldg, (const float*)alpha, partial, lo, width);
+                         (const float*)X, N, ldx, d, (const float*)G, ldg, (const float*)alpha, partial, lo, width, row0, row1);
     G3_LAUNCH_CHECK();
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(width), dim3(256), 0, ctx->stream, partial, nblocks, width, dout + lo);
     G3_LAUNCH_CHECK();
@@ -902,6 +909,28 @@ extern "C" int g3_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_gr
   if (!alpha_dev && N > 0) return -11;
   if (!out_host) return -12;
   return g3i_gram_grad(ctx, prog, map, X_dev, N, ldx, d, dt, G_dev, ldg, alpha_dev, out_host);
+}
+
+// rows [row0, row0 + nrows) of the same sum: G_rows_dev holds those rows of K^-1 (columns 0 .. row0 + nrows are read).
+// The partial sums of disjoint row ranges add up to g3_gram_grad's; the multi-GPU driver calls this per row block.
+extern "C" int g3_gram_grad_rows(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev,
+                                 int64_t N, int64_t ldx, int d, g3_dtype dt, int64_t row0, int64_t nrows,
+                                 const void* G_rows_dev, int64_t ldg, const void* alpha_dev, double* out_host) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!prog || prog->nleaf < 0 || prog->nleaf > G3_MAXLEAF || prog->nprod < 0 || prog->nprod > G3_MAXPROD) return -2;
+  if (!map || check_map(prog, map)) return -3;
+  if (!X_dev && N > 0) return -4;
+  if (N < 0) return -5;
+  if (d < 1 || d > G3_MAXCOLS) return -7;
+  if (ldx < d) return -6;
+  if (row0 < 0 || row0 % GG_T) return -9;
+  if (nrows < 0 || row0 + nrows > N) return -10;
+  if (!G_rows_dev && nrows > 0) return -11;
+  if (ldg < row0 + nrows) return -12;
+  if (!alpha_dev && N > 0) return -13;
+  if (!out_host) return -14;
+  return g3i_gram_grad(ctx, prog, map, X_dev, N, ldx, d, dt, G_rows_dev, ldg, alpha_dev, out_host, row0, nrows);
 }
 
 // Fused: K^-1 and alpha from a factor produced by g3_gp_factor, then the hyper-parameter sums.

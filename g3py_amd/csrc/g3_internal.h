@@ -147,7 +147,8 @@ int g3i_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, doubl
 // A[0:rows, 0:cols) *= factor (stream-ordered)
 int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_dtype dt, double factor);
 int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N, int64_t ldx,
-                  int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host);
+                  int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
+                  int64_t row0 = 0, int64_t nrows = -1);
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt);
 int g3i_ensure_work(g3_ctx* ctx, size_t bytes);
 int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr);

@@ -344,6 +344,15 @@ class Device:
         _check(self, rc, 'g3_gram_grad')
         return np.array(out[:gmap.nslots])
 
+    def gram_grad_rows(self, prog, gmap, X, N, d, row0, nrows, Kinv_rows, alpha):
+        """rows [row0, row0 + nrows) of gram_grad's sum; Kinv_rows holds those rows of K^-1"""
+        out = (C.c_double * max(gmap.nslots, 1))()
+        rc = self.lib.g3_gram_grad_rows(self.ctx, C.byref(prog), C.byref(gmap), X.ptr, N, X.ld, d,
+                                        _lib.dtype_code(Kinv_rows.dtype), row0, nrows, Kinv_rows.ptr, Kinv_rows.ld,
+                                        alpha.ptr, out)
+        _check(self, rc, 'g3_gram_grad_rows')
+        return np.array(out[:gmap.nslots])
+
     def gp_dlogp(self, prog, gmap, X, N, d, L, W, a, Y, Kinv, alpha):
         """after gp_factor: K^-1, alpha = K^-1 delta and 1/2 sum G_ij dK_ij/dparam per slot"""
         out = (C.c_double * max(gmap.nslots, 1))()

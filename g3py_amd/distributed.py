@@ -739,6 +739,7 @@ class NativeDistributedGP:
         self.dtype = np.dtype(dtype)
         self._dt = _lib.dtype_code(self.dtype)
         self.last = {}
+        self.grad = False
         self.h = C.c_void_p()
         lib = dev.lib
         if transport == 'rccl':
@@ -878,6 +879,26 @@ class NativeDistributedGP:
                                               out.ctypes.data, C.byref(tries), C.byref(fb)), 'g3_dist_posterior_draws')
         self.last.update(draws=out.astype(np.float64), cov_tries=tries.value, cov_fallback=bool(fb.value))
         return self.last['draws']
+
+    def set_grad(self, on=True):
+        """gradient mode: every factorisation also carries the identity as right-hand-side rows (the rank's rows of
+        L^-T), which `dlogp` needs; costs N^3 / 3 more flops per step over all ranks and doubles the local matrix"""
+        self._chk(self.dev.lib.g3_dist_set_grad(self.h, 1 if on else 0), 'g3_dist_set_grad')
+        self.grad = bool(on)
+
+    def dlogp(self, spec_noise, X, alpha_scale=1.0):
+        """after step() in gradient mode: (prog, gmap, slots, alpha) -- the per-leaf parameter sums
+        1/2 sum_ij (alpha_i alpha_j - K^-1_ij) dK_ij/dparam of g3_gp_dlogp and alpha = alpha_scale * K^-1 delta,
+        identical on every rank (stochastic.py:308-309 through tensors.py:224-260 in the reference)"""
+        C, lib = self._C, self.dev.lib
+        pn = self._compile(spec_noise, self.d)
+        gmap = self.dev.grad_layout(pn)
+        xp, ldx = self._ptr_ld(X)
+        slots = (C.c_double * max(gmap.nslots, 1))()
+        alpha = np.zeros(self.N)
+        self._chk(lib.g3_dist_gp_dlogp(self.h, C.byref(pn), C.byref(gmap), xp, ldx, float(alpha_scale), slots,
+                                       alpha.ctypes.data_as(C.POINTER(C.c_double))), 'g3_dist_gp_dlogp')
+        return pn, gmap, np.array(slots[:gmap.nslots]), alpha
 
     def comm_stats(self):
         """per collective kind since the last call: calls, bytes sent + received by this rank, device milliseconds

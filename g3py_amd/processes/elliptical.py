@@ -51,10 +51,13 @@ class EllipticalProcess(StochasticProcess):
         statistic that comes from the posterior location and variance at `space` -- mean, median, variance, std,
         quantiles, logpredictive -- are computed by the multi-GPU driver inside libg3hip (g3_dist_*: row-block-cyclic
         covariance, library-owned RCCL communicators); each rank holds 1 / world of the covariance and gets the same
-        numbers back; `sampler` draws from the f posterior through the driver too (rank 0's normals).  Full covariances
-        and `dlogp` need the whole factor on one device and raise in this mode.  `dist`: an initialised torch.distributed (any backend; it only carries 256 bytes of
-        communicator ids, or everything with transport='callbacks', the one-GPU rehearsal)."""
-        self._dist = dict(dist=dist, rank=int(rank), world=int(world), nb=nb, transport=transport, dgp=None, shape=None)
+        numbers back; `sampler` draws from the f posterior through the driver too (rank 0's normals).  `dlogp` (and so
+        `find_MAP`) works too: from the first gradient on, the factorisation carries the identity as right-hand-side rows
+        and K^-1 is formed row block by row block where the rows live (g3_dist_gp_dlogp).  Full covariances need the
+        whole factor on one device and raise in this mode.  `dist`: an initialised torch.distributed (any backend; it
+        only carries 256 bytes of communicator ids, or everything with transport='callbacks', the one-GPU rehearsal)."""
+        self._dist = dict(dist=dist, rank=int(rank), world=int(world), nb=nb, transport=transport, dgp=None, shape=None,
+                          grad=False)
         self._cache = None
         self._workspace = None
         return self
@@ -83,6 +86,8 @@ class EllipticalProcess(StochasticProcess):
             ds['dgp'] = NativeDistributedGP(dev, ds['dist'], ds['rank'], ds['world'], N, d, M, nb=nb, dtype=self.dtype,
                                             transport=ds['transport'])
             ds['shape'] = shape
+            if ds.get('grad'):
+                ds['dgp'].set_grad(True)
         dgp = ds['dgp']
         dvec = self._workspace['dvec']
         dev.copy_in(dvec, np.where(np.isfinite(dl), dl, 0).astype(self.dtype))

@@ -84,14 +84,24 @@ class GaussianProcess(EllipticalProcess):
     def _dloglike(self, values, inputs, outputs, nat):
         """adds d loglike / d (natural-space hyper) into `nat`"""
         dev = self.device
-        if self._dist is not None:
-            raise _lib.G3Error('dlogp needs K^-1 on one device: not available on a distributed process')
         c = self._factor(values, inputs, outputs)
+        ds = self._dist
+        if ds is not None and not ds.get('grad'):
+            # several GPUs: from the first gradient on, every evaluation of this process carries the identity as
+            # right-hand-side rows (the rank's rows of L^-T, g3_dist_set_grad); an evaluation cached without them is redone
+            ds['grad'] = True
+            if ds['dgp'] is not None:
+                ds['dgp'].set_grad(True)
+            c['which'] = None
         st = self._solve(c, values, 'logp')
         N, d, Np = c['N'], c['d'], c['Np']
         # d logp / d beta = -s / 2 with beta = |L^-1 delta|^2: s = 1 for the Gaussian density; the
         # Student-t density supplies its own s (and its degrees-of-freedom term) through the hook
         s = float(self._dlogp_scale(values, c, st, nat))
+        if c.get('grad') is None and ds is not None:
+            # K^-1 never exists in one place: gathered panels of L^-T, the rank's rows of K^-1, one all-reduce of the sums
+            prog, gmap, slots, alpha = ds['dgp'].dlogp(self.f_kernel_noise.spec(values, d), c['Xd'], np.sqrt(s))
+            c['grad'] = dict(prog=prog, gmap=gmap, slots=slots, alpha=np.sqrt(s) * alpha)
         if c.get('grad') is None:
             prog = self._prog(self.f_kernel_noise, values, d)
             gmap = dev.grad_layout(prog)

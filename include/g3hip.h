@@ -309,6 +309,15 @@ int g3_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map
                  int64_t N, int64_t ldx, int d, g3_dtype dt, const void* Kinv_dev, int64_t ldc,
                  const void* alpha_dev, double* out_host);
 
+/* The same sum restricted to rows [row0, row0 + nrows) of the lower triangle (row0 a multiple of 64, row0 + nrows <= N):
+ * Kinv_rows_dev holds THOSE rows of K^-1 (row r of the buffer = global row row0 + r; columns 0 .. row0 + nrows - 1 are
+ * read), alpha_dev all N entries.  Disjoint row ranges add up to g3_gram_grad's result: a rank of the multi-GPU
+ * driver calls this once per row block it owns (g3_dist_gp_dlogp).  No counterpart in the reference (its gradient is
+ * Theano autodiff through CholeskyRobust.grad, g3py/libs/tensors.py:224-260). */
+int g3_gram_grad_rows(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev,
+                      int64_t N, int64_t ldx, int d, g3_dtype dt, int64_t row0, int64_t nrows,
+                      const void* Kinv_rows_dev, int64_t ldc, const void* alpha_dev, double* out_host);
+
 /* Fused: after g3_gp_factor (L_dev = its K_dev, invd_dev, a_dev = L^-1 delta, roundup(N,128) long):
  * g3_potri, alpha_dev <- L^-T a (roundup(N,128) entries), then g3_gram_grad.  Y_dev and Kinv_dev
  * are roundup(N,128)-square workspaces / outputs. */
@@ -395,6 +404,20 @@ int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog_noise, cons
 int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f, const void* Xs_dev, int64_t ldxs,
                             const void* loc_host, const void* Z_host, int64_t S, void* out_host, int* tries_host,
                             int* fallback_host);
+/* Gradient mode.  g3_dist_set_grad(D, 1): every later g3_dist_gp_factor_predict also carries the IDENTITY as
+ * right-hand-side rows, dealt like the matrix's row blocks, which the sweep turns into the rank's rows of L^-T (N^3 / 3
+ * more flops over all ranks; the local matrix doubles; a planned driver is re-planned).  g3_dist_gp_dlogp then returns
+ * what g3_gp_dlogp returns on one GPU -- slots_host[map->nslots] = 1/2 sum_ij (alpha_i alpha_j - K^-1_ij) dK_ij/dparam
+ * and alpha_host[N] = alpha_scale * K^-1 delta (NULL: not wanted), identical on every rank -- from the last
+ * factorisation: alpha = L^-T a; K^-1 = L^-T L^-1 by one all-gathered panel of L^-T + one staircase GEMM per column
+ * block (no dependency between the steps); g3_gram_grad_rows over the rank's row blocks; one all-reduce of the sums.
+ * prog must be the (noise-wrapped) program the factorisation was built from.  alpha_scale: sqrt(s) of a density whose
+ * d logp / d|L^-1 delta|^2 is -s/2 (1 for the Gaussian).  Replaces gradient(th_logp) (g3py/processes/stochastic.py:
+ * 308-309) through CholeskyRobust.grad (g3py/libs/tensors.py:224-260) for a covariance no single GPU holds. */
+int g3_dist_set_grad(g3_dist* D, int on);
+int g3_dist_gp_dlogp(g3_dist* D, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X_dev, int64_t ldx,
+                     double alpha_scale, double* slots_host, double* alpha_host);
+
 /* out_host[3k .. 3k+2] for k = 0 broadcast, 1 all-gather, 2 all-reduce: calls, bytes sent + received by this rank,
  * device milliseconds inside the collective calls (HIP events on the stream each ran on).  Resets the counters. */
 int g3_dist_comm_stats(g3_dist* D, double out_host[9]);

@@ -224,7 +224,7 @@ def chain_worker(rank, world, port, N, d, rows, out_path):
         dist.destroy_process_group()
 
 
-def native_worker(rank, world, port, N, d, M, nb, transport, spec_f, noise, out_path, dup=False, draws=0, dtype='f64'):
+def native_worker(rank, world, port, N, d, M, nb, transport, spec_f, noise, out_path, dup=False, draws=0, dtype='f64', grad=False):
     """one rank of the driver INSIDE libg3hip (g3_dist_*): transport 'callbacks' lets `world` ranks share cuda:0 over
     gloo (host-staged collectives), 'rccl' is the product transport (one rank per GPU: world 1 on a one-GPU box)"""
     import torch
@@ -251,11 +251,24 @@ def native_worker(rank, world, port, N, d, M, nb, transport, spec_f, noise, out_
         lp2 = dgp.step(spec_n, spec_f, Xd, Xsd, yd)          # a second evaluation on the same plan: same numbers
         assert lp2 == lp or (np.isnan(lp) and np.isnan(lp2)), (lp, lp2)
         cs = dgp.comm_stats()
+        slots, alpha, lp3, names = np.zeros(0), np.zeros(0), lp, []
+        if grad:
+            # gradient mode: the same step with the identity riding along, then the parameter sums and alpha
+            dgp.set_grad(True)
+            lp3 = dgp.step(spec_n, spec_f, Xd, Xsd, yd)
+            mean3 = dgp.last['mean'].copy()
+            prog, gmap, slots, alpha = dgp.dlogp(spec_n, Xd)
+            _, _, slots2, _ = dgp.dlogp(spec_n, Xd)              # repeatable from the same factorisation
+            assert np.array_equal(slots, slots2)
+            dgp.set_grad(False)
+            lp4 = dgp.step(spec_n, spec_f, Xd, Xsd, yd)          # and back: the plain plan again
+            assert lp4 == lp, (lp4, lp)
+            assert np.allclose(mean3, dgp.last['mean'], rtol=1e-9, atol=1e-11)
         if rank == 0:
             prior = np.diag(orc.kernel_cov(spec_f, Xs))
             np.savez(out_path, logp=lp, mean=dgp.last['mean'], var=np.maximum(prior - dgp.last['ss'], 0),
                      tries=dgp.last['tries'], fallback=dgp.last['fallback'],
-                     draws=dgp.last['draws'] if draws else np.zeros(0),
+                     draws=dgp.last['draws'] if draws else np.zeros(0), slots=slots, alpha=alpha, logp_grad=lp3,
                      comm_calls=sum(v['calls'] for v in cs.values()), comm_bytes=sum(v['bytes'] for v in cs.values()))
         dgp.close()
     finally:
@@ -298,9 +311,14 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         gp.mean(params)                                     # back to the process's own space: the driver holds its cross solve
         Z = np.random.default_rng(100 + rank).standard_normal((M, 4))      # ranks draw DIFFERENT normals: rank 0's must win
         smp = gp.sampler(params, samples=4, rand=Z)
+        grad = np.asarray(gp.dlogp(params))                 # switches the driver to gradient mode (identity rows ride along)
+        lp3 = gp.logp(params)
+        assert abs(lp3 - lp) <= 1e-11 * abs(lp), (lp3, lp)
+        p2 = {k: (v + 0.05) for k, v in params.items()}     # another parameter vector in gradient mode: logp and dlogp again
+        lp_b, grad_b = gp.logp(p2), np.asarray(gp.dlogp(p2))
         if rank == 0:
             np.savez(out_path, logp=lp, logp2=lp2, mean=pr.mean, var=pr.variance, std=pr.std, median=pr.median,
-                     qu=pr.quantile_up, qd=pr.quantile_down, lpred=lpred, other=other, smp=smp)
+                     qu=pr.quantile_up, qd=pr.quantile_down, lpred=lpred, other=other, smp=smp, grad=grad)
         try:
             gp.kernel(params)
             ok = False
@@ -309,5 +327,9 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         assert ok, 'the full covariance must refuse on a distributed process'
         gp.undistribute()
         assert abs(gp.logp(params) - lp) <= 1e-10 * abs(lp)       # and the same process object works on one GPU again
+        g1, g1b = np.asarray(gp.dlogp(params)), np.asarray(gp.dlogp(p2))      # ... where K^-1 is one matrix
+        assert abs(gp.logp(p2) - lp_b) <= 1e-10 * abs(lp_b)
+        np.testing.assert_allclose(grad, g1, rtol=1e-7, atol=1e-8 * np.abs(g1).max())
+        np.testing.assert_allclose(grad_b, g1b, rtol=1e-7, atol=1e-8 * np.abs(g1b).max())
     finally:
         dist.destroy_process_group()

@@ -224,10 +224,76 @@ def test_native_driver_staircase_longer_than_one_launch(tmp_path, monkeypatch):
     np.testing.assert_allclose(r['draws'], gp.sampler(Xs, X, y, rand=Z), atol=1e-7)
 
 
+def _grad_reference(spec_n, X, y):
+    """slots of g3_gp_dlogp from the oracle's dK/dparam tensors: 1/2 sum_ij (alpha alpha^T - K^-1)_ij dK_ij"""
+    from oracle import g3_oracle as orc
+    K, grads = orc.kernel_cov_grads(spec_n, X)
+    Kinv = np.linalg.inv(K)
+    alpha = Kinv @ y
+    G = np.outer(alpha, alpha) - Kinv
+    return alpha, [(leaf, pname, k, 0.5 * np.sum(G * dK), 0.5 * np.sum(np.abs(G * dK)) + 1e-30) for (leaf, pname, k, dK) in grads]
+
+
+@pytest.mark.parametrize('world,N,nb,M,kern', [(1, 900, 256, 40, 'se'), (2, 900, 256, 40, 'se'), (2, 1100, 128, 130, 'm52cos'),
+                                               (3, 700, 128, 0, 'rq'), (4, 1000, 128, 20, 'se'), (5, 640, 128, 129, 'm52cos')])
+def test_native_driver_gradient(tmp_path, world, N, nb, M, kern):
+    """g3_dist_set_grad + g3_dist_gp_dlogp: the identity rides through the factorisation as right-hand-side rows (the
+    rank's rows of L^-T), K^-1 rows by gathered panels + staircase products, the gradient kernel over the rank's row
+    blocks, one all-reduce -- parameter sums and alpha = K^-1 delta against the oracle (tensors.py:224-260 is what the
+    reference differentiates through), ragged N, up to five ranks on the one GPU"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    from g3py_amd.device import compile_spec
+    import g3py_amd as g3
+    d = 3
+    r_ = np.array([0.9, 1.1, 0.7])
+    spec_f = {'se': ('SE', 1.2, r_, None), 'rq': ('RQ', 0.8, r_, 1.7, None),
+              'm52cos': ('sum', ('MAT52', 1.1, r_, None), ('COS', 0.4, np.array([0.2, 0.15, 0.1]), None))}[kern]
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, max(M, 1), nb, 'callbacks', spec_f, 0.1, out, False, 0, 'f64', True),
+             nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, max(M, 1), 77)
+    spec_n = orc.with_noise(spec_f, 0.1)
+    alpha, ref = _grad_reference(spec_n, X, y)
+    assert abs(float(r['logp_grad']) - float(r['logp'])) <= 1e-11 * abs(float(r['logp']))
+    np.testing.assert_allclose(r['alpha'], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+    gmap = g3.Device(0).grad_layout(compile_spec(spec_n, d))
+    assert len(r['slots']) == gmap.nslots == len(ref)
+    for (leaf, pname, k, want, scale) in ref:
+        got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
+        assert abs(got - want) < 1e-8 * scale, (leaf, pname, k, got, want)
+
+
+def test_gram_grad_rows_add_up():
+    """g3_gram_grad_rows over disjoint row ranges (ragged last range) sums to g3_gram_grad, fast path and interpreter"""
+    import g3py_amd as g3
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    dev = g3.Device(0)
+    N, d = 700, 4
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 3, (N, d))
+    A = rng.standard_normal((N, N))
+    G = np.tril((A + A.T) / 2)
+    alpha = rng.standard_normal(N)
+    Xd, ad = dev.upload(X), dev.upload(alpha)
+    for spec in (orc.with_noise(('MAT52', 1.3, np.full(d, 0.8), None), 0.2),
+                 ('sum', ('prod', ('SE', 1.0, np.full(d, 0.7), None), ('SINC', 0.7, np.full(d, 0.2), None)), ('NOISE', 0.2))):
+        prog = compile_spec(spec, d)
+        gmap = dev.grad_layout(prog)
+        full = dev.gram_grad(prog, gmap, Xd, N, d, dev.upload(G), ad)
+        tot = np.zeros_like(full)
+        for r0 in range(0, N, 256):
+            nr = min(256, N - r0)
+            tot += dev.gram_grad_rows(prog, gmap, Xd, N, d, r0, nr, dev.upload(np.ascontiguousarray(G[r0:r0 + nr])), ad)
+        np.testing.assert_allclose(tot, full, rtol=1e-12, atol=1e-12 * np.abs(full).max())
+
+
 @pytest.mark.parametrize('world,warped', [(1, False), (2, False), (3, True)])
 def test_public_api_on_several_ranks(tmp_path, world, warped):
     """GaussianProcess.distribute(): the user API itself on `world` ranks (SPMD, callback transport on the one GPU):
-    logp, mean, variance, std, median, quantiles and logpredictive equal the one-GPU process's values"""
+    logp, mean, variance, std, median, quantiles, logpredictive and dlogp equal the one-GPU process's values"""
     import torch.multiprocessing as mp
     import g3py_amd as g3
     from dist_helpers import api_worker
@@ -263,3 +329,5 @@ def test_public_api_on_several_ranks(tmp_path, world, warped):
     np.testing.assert_allclose(r['other'], gp.mean(params, space=Xs[: M // 2]), atol=1e-8)
     Z = np.random.default_rng(100).standard_normal((M, 4))
     np.testing.assert_allclose(r['smp'], gp.sampler(params, samples=4, rand=Z), atol=1e-7)     # rank 0's normals, same draws
+    g1 = np.asarray(gp.dlogp(params))          # dlogp on the distributed process = the one-GPU gradient (kernel, location, warping hypers)
+    np.testing.assert_allclose(r['grad'], g1, rtol=1e-7, atol=1e-8 * np.abs(g1).max())
