@@ -505,6 +505,32 @@ def main():
         else:
             comm_all = [mine]
 
+    dist_grad = None
+    if use_dist and native and args.grad and S == 0:
+        # dlogp on the distributed covariance (collective: every rank): one step in gradient mode -- the identity rides
+        # through the factorisation as N / world more right-hand-side rows per rank -- then g3_dist_gp_dlogp
+        dgp.set_grad(True)
+        dgp.step(spec_n, spec_f, Xd, Xsd, dd)              # the re-planned buffers' first touch
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        lp_g = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        _, gmap_g, slots_g, alpha_g = dgp.dlogp(spec_n, Xd)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        dgp.set_grad(False)
+        tt = torch.tensor([t2 - t1, t3 - t2], dtype=torch.float64, device=tdev if (world > 1 and dist.get_backend() == 'nccl') else 'cpu')
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist_grad = {'step_grad_mode_ms': float(tt[0]) * 1e3, 'dlogp_ms': float(tt[1]) * 1e3, 'nslots': int(gmap_g.nslots),
+                     'logp_grad_mode': float(lp_g), 'grad_natural': [float(v) for v in slots_g],
+                     'alpha_norm': float(np.linalg.norm(alpha_g)),
+                     'note': 'gradient mode: the factorisation also turns the identity into the rank\'s rows of L^-T (N^3/3 more '
+                             'flops over all ranks); dlogp = alpha + K^-1 row blocks (N^3/3, gathered panels + staircase GEMMs) + '
+                             'g3_gram_grad_rows + one all-reduce; after the timed region, not part of value'}
     failed = None
     if rank == 0:
         sec = elapsed / args.steps
@@ -574,6 +600,8 @@ def main():
                                'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],
                                'note': 'HIP events per launch on the launching stream; launches on the two '
                                        'look-ahead streams overlap, so summed launch time exceeds wall time'}
+        if dist_grad is not None:
+            out['dlogp'] = dist_grad
         if not use_dist and args.grad:
             gmap = dev.grad_layout(prog_n)
             Yt = torch.empty((Np, Np), dtype=tdt, device=tdev)

@@ -265,6 +265,28 @@ def test_native_driver_gradient(tmp_path, world, N, nb, M, kern):
         assert abs(got - want) < 1e-8 * scale, (leaf, pname, k, got, want)
 
 
+def test_native_driver_gradient_one_rank_through_rccl(tmp_path):
+    """gradient mode with the product transport: the panels of L^-T and the alpha pieces go through ncclAllGather, the
+    parameter sums through ncclAllReduce (world 1: all a one-GPU box allows)"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    from g3py_amd.device import compile_spec
+    import g3py_amd as g3
+    N, d, M, nb = 1300, 3, 60, 256
+    spec_f = ('MAT32', 1.2, np.array([0.9, 1.1, 0.7]), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(native_worker, args=(1, _free_port(), N, d, M, nb, 'rccl', spec_f, 0.1, out, False, 0, 'f64', True), nprocs=1, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    spec_n = orc.with_noise(spec_f, 0.1)
+    alpha, ref = _grad_reference(spec_n, X, y)
+    np.testing.assert_allclose(r['alpha'], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+    gmap = g3.Device(0).grad_layout(compile_spec(spec_n, d))
+    for (leaf, pname, k, want, scale) in ref:
+        got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
+        assert abs(got - want) < 1e-8 * scale, (leaf, pname, k, got, want)
+
+
 def test_gram_grad_rows_add_up():
     """g3_gram_grad_rows over disjoint row ranges (ragged last range) sums to g3_gram_grad, fast path and interpreter"""
     import g3py_amd as g3
