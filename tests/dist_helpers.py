@@ -333,3 +333,37 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         np.testing.assert_allclose(grad_b, g1b, rtol=1e-7, atol=1e-8 * np.abs(g1b).max())
     finally:
         dist.destroy_process_group()
+
+
+def tp_worker(rank, world, port, N, d, M, out_path):
+    """Student-t process on several ranks: logp, variance (posterior scaling) and dlogp -- the density hands the driver
+    sqrt(s) through alpha_scale (d logp / d beta = -s / 2, studentT.py:114-135) -- equal the same object on one GPU"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        X, y, Xs = synth(N, d, M, 77)
+        tp = g3.StudentTProcess(space=Xs, location=g3.Bias(), kernel=g3.SE(X))
+        tp.observed(X, y)
+        params = dict(tp.params)
+        for k in params:
+            if k.endswith('_var_log_') and 'Noise' not in k:
+                params[k] = np.log(1.1)
+            elif k.endswith('_rate_log_'):
+                params[k] = np.log(np.full(d, 0.9))
+            elif 'Noise' in k:
+                params[k] = np.log(0.1)
+        tp.distribute(dist, rank, world, nb=128, transport='callbacks')
+        lp, var, g = tp.logp(params), np.asarray(tp.variance(params)), np.asarray(tp.dlogp(params))
+        tp.undistribute()
+        lp1, var1, g1 = tp.logp(params), np.asarray(tp.variance(params)), np.asarray(tp.dlogp(params))
+        assert abs(lp - lp1) <= 1e-10 * abs(lp1), (lp, lp1)
+        np.testing.assert_allclose(var, var1, atol=1e-8)
+        np.testing.assert_allclose(g, g1, rtol=1e-7, atol=1e-8 * np.abs(g1).max())
+        if rank == 0:
+            np.savez(out_path, logp=lp, grad=g, ok=1)
+    finally:
+        dist.destroy_process_group()

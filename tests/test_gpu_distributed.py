@@ -353,3 +353,15 @@ def test_public_api_on_several_ranks(tmp_path, world, warped):
     np.testing.assert_allclose(r['smp'], gp.sampler(params, samples=4, rand=Z), atol=1e-7)     # rank 0's normals, same draws
     g1 = np.asarray(gp.dlogp(params))          # dlogp on the distributed process = the one-GPU gradient (kernel, location, warping hypers)
     np.testing.assert_allclose(r['grad'], g1, rtol=1e-7, atol=1e-8 * np.abs(g1).max())
+
+
+def test_student_t_process_on_two_ranks(tmp_path):
+    """logp, the scaled posterior variance and dlogp of a StudentTProcess on two ranks (callback transport on the one GPU)
+    equal the same object evaluated on one GPU: the Student-t density's s = (nu + n) / (nu - 2 + beta) reaches the
+    distributed gradient through alpha_scale"""
+    import torch.multiprocessing as mp
+    from dist_helpers import tp_worker
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(tp_worker, args=(2, _free_port(), 700, 3, 40, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert int(r['ok']) == 1 and np.all(np.isfinite(r['grad']))
