@@ -119,6 +119,7 @@ _SIGS = {
                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     'g3_dist_posterior_draws': ([_P, C.POINTER(KernelProg), _P, _I64, _P, _P, _I64, _P, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)], C.c_int),
+    'g3_dist_posterior_cov': ([_P, C.POINTER(KernelProg), _P, _I64, _P, _I64], C.c_int),
     'g3_dist_set_grad': ([_P, C.c_int], C.c_int),
     'g3_dist_gp_dlogp': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, C.c_double, C.POINTER(C.c_double),
                           C.POINTER(C.c_double)], C.c_int),

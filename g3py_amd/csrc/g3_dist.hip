@@ -886,10 +886,108 @@ extern "C" int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog,
 // ---------------------------------------------------------------------------------------- posterior covariance + draws
 // BASELINE config 5's extra work: K(Xs, Xs) - V V^T (elliptical.py:86-91), its robust Cholesky (elliptical.py:88,92;
 // tensors.py:197-222) and loc + L_post Z (gaussian.py:75-97, before the mapping).  V = K(Xs, X) L^-T sits in the
-// right-hand-side chunks, full rows per chunk.  All-gather V (M x N: 1 GiB at config 5), every rank forms the
-// covariance rows of ITS chunks with one staircase launch against the gathered V (rank-major: block table), the
-// M x M covariance is all-gathered (64 MiB) and factored redundantly on every rank -- M^3/3 flops, nothing to
-// exchange -- so all ranks hold the same draws.
+// right-hand-side chunks, full rows per chunk.  All-gather V (M x N: 1 GiB at config 5), every rank forms the LOWER part
+// of the covariance rows of ITS chunks with one staircase launch against the gathered V (rank-major: block table) -- the
+// prior part from g3_gram_rows, i.e. with the square-case semantics of NOISE / WN leaves (kernels.py:360-385) -- the
+// M x M covariance is all-gathered (64 MiB), mirrored, and (draws) factored redundantly on every rank -- M^3/3 flops,
+// nothing to exchange -- so all ranks hold the same matrix and the same draws.
+template <typename T>
+__global__ void __launch_bounds__(256) mirror_lower_kernel(T* __restrict__ A, int64_t n, int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j < n && j > i) A[i * ld + j] = A[j * ld + i];
+}
+
+static int posterior_cov(g3_dist* D, const g3_kernel_prog* prog, const void* Xs_dev, int64_t ldxs, char* cov, int64_t ldc) {
+  const int P = D->world;
+  const int64_t M = D->M, Mp = D->Mp, Np = D->Np, pad = 128;
+  const int nch = (int)(Mp / pad);
+  std::vector<int> own(nch), cntq(P, 0), mine;
+  for (int c = 0; c < nch; ++c) { own[c] = (c + 1) % P; cntq[own[c]]++; if (own[c] == D->rank) mine.push_back(c); }
+  int cmax = 1;
+  for (int q = 0; q < P; ++q) cmax = cntq[q] > cmax ? cntq[q] : cmax;
+  hipStream_t s = D->ctx->stream;
+  char *sendb = nullptr, *Vall = nullptr, *rows = nullptr, *call = nullptr;
+  int rc = G3_OK;
+  auto cleanup = [&]() {
+    void* b[] = {sendb, Vall, rows, call};
+    (void)hipStreamSynchronize(s);
+    for (void* p : b) if (p) (void)hipFree(p);
+  };
+#define G3D_TRY(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
+#define G3D_TRYH(x) do { if ((x) != hipSuccess) { snprintf(D->err, sizeof(D->err), "%s:%d %s", __FILE__, __LINE__, #x); cleanup(); return G3_ERR_HIP; } } while (0)
+  const size_t es = D->es;
+  G3D_TRYH(hipMalloc((void**)&sendb, (size_t)cmax * pad * Np * es));
+  G3D_TRYH(hipMalloc((void**)&Vall, (size_t)P * cmax * pad * Np * es));
+  G3D_TRYH(hipMalloc((void**)&rows, (size_t)cmax * pad * Mp * es));
+  G3D_TRYH(hipMalloc((void**)&call, (size_t)P * cmax * pad * Mp * es));
+  G3D_TRYH(hipMemsetAsync(sendb, 0, (size_t)cmax * pad * Np * es, s));
+  G3D_TRYH(hipMemsetAsync(rows, 0, (size_t)cmax * pad * Mp * es, s));
+  // my V chunks, in chunk order (chunk c of Xs = right-hand-side chunk c + 1)
+  for (size_t i = 0; i < mine.size(); ++i) {
+    size_t t = 0;
+    while (t < D->my_chunks.size() && D->my_chunks[t] != mine[i] + 1) ++t;
+    if (t == D->my_chunks.size()) {     // the two dealings (plan: c % P; here: (c + 1) % P of the Xs chunk) must agree
+      snprintf(D->err, sizeof(D->err), "posterior covariance: right-hand-side chunk %d is not on rank %d", mine[i] + 1, D->rank);
+      cleanup();
+      return G3_ERR_HIP;
+    }
+    G3D_TRYH(hipMemcpyAsync(sendb + i * pad * Np * es, Aat(D, D->rows_mat + (int64_t)t * pad, 0), (size_t)pad * Np * es,
+                            hipMemcpyDeviceToDevice, s));
+  }
+  G3D_TRY(do_allgather(D, sendb, Vall, (size_t)cmax * pad * Np * es, s));
+  std::vector<int32_t> perm(nch);
+  {
+    std::vector<int> seen(P, 0);
+    for (int c = 0; c < nch; ++c) perm[c] = own[c] * cmax + seen[own[c]]++;
+  }
+  // lower part of the covariance rows of my chunks: K(Xs)[rows of c, columns <= the chunk's last row] - V_c Vall^T
+  // (prior part: the plain kernel.cov(Xs), not scrubbed)
+  std::vector<int64_t> sr, sc, sd;
+  for (size_t i = 0; i < mine.size(); ++i) {
+    const int64_t c = mine[i];
+    const int64_t m = M - c * pad < pad ? M - c * pad : pad;
+    if (m > 0)
+      G3D_TRY(g3_gram_rows(D->ctx, prog, Xs_dev, M, ldxs, D->d, c * pad, m, D->dt, rows + i * pad * Mp * es, Mp, 0));
+    sr.push_back(pad);
+    sc.push_back((c + 1) * pad);
+    sd.push_back(1);
+  }
+  if (!mine.empty()) {
+    std::vector<G3hStairChunk> ch;
+    g3h_stair_chunks(sr, sc, pad, nch, &ch, &sd);
+    for (const auto& cc : ch)
+      G3D_TRY(g3_gemm_nt_stair(D->ctx, rows + ((size_t)cc.row0 * Mp + cc.col0) * es, Mp, sendb + (size_t)cc.row0 * Np * es, Np, Vall, Np, Np,
+                               cc.rows.data(), cc.cols.data(), (int)cc.rows.size(), -1.0, 1.0, D->dt, pad, perm.data() + cc.blk0, cc.nblk,
+                               cc.diag.data()));
+  }
+  G3D_TRY(do_allgather(D, rows, call, (size_t)cmax * pad * Mp * es, s));
+  for (int c = 0; c < nch; ++c)
+    G3D_TRYH(hipMemcpy2DAsync(cov + (size_t)c * pad * ldc * es, (size_t)ldc * es, call + (size_t)perm[c] * pad * Mp * es, (size_t)Mp * es,
+                              (size_t)Mp * es, pad, hipMemcpyDeviceToDevice, s));
+  {
+    const dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp);
+    if (D->dt == G3_F64) hipLaunchKernelGGL(mirror_lower_kernel<double>, grid, dim3(256), 0, s, (double*)cov, Mp, ldc);
+    else hipLaunchKernelGGL(mirror_lower_kernel<float>, grid, dim3(256), 0, s, (float*)cov, Mp, ldc);
+    G3D_TRYH(hipGetLastError());
+  }
+  cleanup();
+#undef G3D_TRY
+#undef G3D_TRYH
+  return G3_OK;
+}
+
+extern "C" int g3_dist_posterior_cov(g3_dist* D, const g3_kernel_prog* prog, const void* Xs_dev, int64_t ldxs, void* cov_dev, int64_t ldc) {
+  if (!D) return -1;
+  if (!D->planned || D->M <= 0) return -1;
+  if (!prog || g3i_validate_prog(prog, D->d)) return -2;
+  if (!Xs_dev) return -3;
+  if (ldxs < D->d) return -4;
+  if (!cov_dev) return -5;
+  if (ldc < D->Mp) return -6;
+  g3_dev_guard _dg(D->ctx);
+  return posterior_cov(D, prog, Xs_dev, ldxs, (char*)cov_dev, ldc);
+}
+
 extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f, const void* Xs_dev, int64_t ldxs,
                                        const void* loc_host, const void* Z_host, int64_t S, void* out_host, int* tries_host,
                                        int* fallback_host) {
@@ -904,81 +1002,36 @@ extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f,
   if (!out_host) return -8;
   if (g3i_validate_prog(prog_f, D->d)) return -2;
   g3_dev_guard _dg(D->ctx);
-  const int P = D->world;
-  const int64_t M = D->M, Mp = D->Mp, Np = D->Np, pad = 128;
-  const int nch = (int)(Mp / pad);
-  std::vector<int> own(nch), cntq(P, 0), mine;
-  for (int c = 0; c < nch; ++c) { own[c] = (c + 1) % P; cntq[own[c]]++; if (own[c] == D->rank) mine.push_back(c); }
-  int cmax = 1;
-  for (int q = 0; q < P; ++q) cmax = cntq[q] > cmax ? cntq[q] : cmax;
-  hipStream_t s = D->ctx->stream;
-  char *sendb = nullptr, *Vall = nullptr, *rows = nullptr, *call = nullptr, *cov = nullptr, *Lp = nullptr;
-  int rc = G3_OK;
-  auto cleanup = [&]() {
-    void* b[] = {sendb, Vall, rows, call, cov, Lp};
-    (void)hipStreamSynchronize(s);
-    for (void* p : b) if (p) (void)hipFree(p);
-  };
-#define G3D_TRY(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
-#define G3D_TRYH(x) do { if ((x) != hipSuccess) { snprintf(D->err, sizeof(D->err), "%s:%d %s", __FILE__, __LINE__, #x); cleanup(); return G3_ERR_HIP; } } while (0)
+  const int64_t M = D->M, Mp = D->Mp;
   const size_t es = D->es;
-  G3D_TRYH(hipMalloc((void**)&sendb, (size_t)cmax * pad * Np * es));
-  G3D_TRYH(hipMalloc((void**)&Vall, (size_t)P * cmax * pad * Np * es));
-  G3D_TRYH(hipMalloc((void**)&rows, (size_t)cmax * pad * Mp * es));
-  G3D_TRYH(hipMalloc((void**)&call, (size_t)P * cmax * pad * Mp * es));
-  G3D_TRYH(hipMalloc((void**)&cov, (size_t)Mp * Mp * es));
-  G3D_TRYH(hipMalloc((void**)&Lp, (size_t)Mp * Mp * es));
-  G3D_TRYH(hipMemsetAsync(sendb, 0, (size_t)cmax * pad * Np * es, s));
-  G3D_TRYH(hipMemsetAsync(rows, 0, (size_t)cmax * pad * Mp * es, s));
-  G3D_TRYH(hipMemsetAsync(Lp, 0, (size_t)Mp * Mp * es, s));
-  // my V chunks, in chunk order (chunk c of Xs = right-hand-side chunk c + 1)
-  for (size_t i = 0; i < mine.size(); ++i) {
-    size_t t = 0;
-    while (t < D->my_chunks.size() && D->my_chunks[t] != mine[i] + 1) ++t;
-    if (t == D->my_chunks.size()) {     // the two dealings (plan: c % P; here: (c + 1) % P of the Xs chunk) must agree
-      snprintf(D->err, sizeof(D->err), "posterior_draws: right-hand-side chunk %d is not on rank %d", mine[i] + 1, D->rank);
-      cleanup();
-      return G3_ERR_HIP;
-    }
-    G3D_TRYH(hipMemcpyAsync(sendb + i * pad * Np * es, Aat(D, D->rows_mat + (int64_t)t * pad, 0), (size_t)pad * Np * es,
-                            hipMemcpyDeviceToDevice, s));
+  hipStream_t s = D->ctx->stream;
+  char *cov = nullptr, *Lp = nullptr;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(s);
+    if (cov) (void)hipFree(cov);
+    if (Lp) (void)hipFree(Lp);
+  };
+  if (hipMalloc((void**)&cov, (size_t)Mp * Mp * es) != hipSuccess || hipMalloc((void**)&Lp, (size_t)Mp * Mp * es) != hipSuccess ||
+      hipMemsetAsync(Lp, 0, (size_t)Mp * Mp * es, s) != hipSuccess) {
+    snprintf(D->err, sizeof(D->err), "posterior_draws: out of device memory for two %lld x %lld matrices", (long long)Mp, (long long)Mp);
+    cleanup();
+    return G3_ERR_NOMEM;
   }
-  G3D_TRY(do_allgather(D, sendb, Vall, (size_t)cmax * pad * Np * es, s));
-  std::vector<int32_t> perm(nch);
-  {
-    std::vector<int> seen(P, 0);
-    for (int c = 0; c < nch; ++c) perm[c] = own[c] * cmax + seen[own[c]]++;
-  }
-  // covariance rows of my chunks: K(Xs_c, Xs) - V_c Vall^T  (prior part: the plain f_kernel.cov, not scrubbed)
-  for (size_t i = 0; i < mine.size(); ++i) {
-    const int64_t c = mine[i];
-    const int64_t m = M - c * pad < pad ? M - c * pad : pad;
-    if (m > 0)
-      G3D_TRY(g3_gram(D->ctx, prog_f, (const char*)Xs_dev + (size_t)c * pad * ldxs * es, m, ldxs, Xs_dev, M, ldxs, D->d, D->dt,
-                      rows + i * pad * Mp * es, Mp, m, M, 0));
-  }
-  if (!mine.empty()) {
-    std::vector<int64_t> sr{(int64_t)mine.size() * pad}, sc{Mp};
-    std::vector<G3hStairChunk> ch;
-    g3h_stair_chunks(sr, sc, pad, nch, &ch);
-    for (const auto& cc : ch)
-      G3D_TRY(g3_gemm_nt_stair(D->ctx, rows + (size_t)cc.col0 * es, Mp, sendb, Np, Vall, Np, Np, cc.rows.data(), cc.cols.data(),
-                               (int)cc.rows.size(), -1.0, 1.0, D->dt, pad, perm.data() + cc.blk0, cc.nblk, nullptr));
-  }
-  G3D_TRY(do_allgather(D, rows, call, (size_t)cmax * pad * Mp * es, s));
-  for (int c = 0; c < nch; ++c)
-    G3D_TRYH(hipMemcpyAsync(cov + (size_t)c * pad * Mp * es, call + (size_t)perm[c] * pad * Mp * es, (size_t)pad * Mp * es,
-                            hipMemcpyDeviceToDevice, s));
+  int rc = posterior_cov(D, prog_f, Xs_dev, ldxs, cov, Mp);
   int tries = 0, fb = 0;
   double jit = 0;
-  G3D_TRY(g3_potrf_robust(D->ctx, cov, Mp, Lp, Mp, M, D->dt, 20, &tries, &fb, &jit));
-  G3D_TRY(g3_gp_sample(D->ctx, Lp, M, Mp, loc_host, Z_host, S, D->dt, out_host));
+  if (!rc) {
+    rc = g3_potrf_robust(D->ctx, cov, Mp, Lp, Mp, M, D->dt, 20, &tries, &fb, &jit);
+    if (rc) snprintf(D->err, sizeof(D->err), "posterior_draws: g3_potrf_robust -> %d %s", rc, D->ctx->err);
+  }
+  if (!rc) {
+    rc = g3_gp_sample(D->ctx, Lp, M, Mp, loc_host, Z_host, S, D->dt, out_host);
+    if (rc) snprintf(D->err, sizeof(D->err), "posterior_draws: g3_gp_sample -> %d %s", rc, D->ctx->err);
+  }
   if (tries_host) *tries_host = tries;
   if (fallback_host) *fallback_host = fb;
   cleanup();
-#undef G3D_TRY
-#undef G3D_TRYH
-  return G3_OK;
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------- gradient of logp

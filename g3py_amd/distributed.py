@@ -880,6 +880,16 @@ class NativeDistributedGP:
         self.last.update(draws=out.astype(np.float64), cov_tries=tries.value, cov_fallback=bool(fb.value))
         return self.last['draws']
 
+    def posterior_cov(self, spec, Xs, out):
+        """after step() with the same Xs: the posterior covariance K(Xs, Xs) - V V^T (elliptical.py:86-91) into the device
+        matrix `out` (roundup(M, 128) square) on every rank; spec with or without the Noise term"""
+        C, lib = self._C, self.dev.lib
+        pk = self._compile(spec, self.d)
+        xsp, ldxs = self._ptr_ld(Xs)
+        op, ldo = self._ptr_ld(out)
+        self._chk(lib.g3_dist_posterior_cov(self.h, C.byref(pk), xsp, ldxs, op, ldo), 'g3_dist_posterior_cov')
+        return out
+
     def set_grad(self, on=True):
         """gradient mode: every factorisation also carries the identity as right-hand-side rows (the rank's rows of
         L^-T), which `dlogp` needs; costs N^3 / 3 more flops per step over all ranks and doubles the local matrix"""

@@ -53,8 +53,9 @@ class EllipticalProcess(StochasticProcess):
         covariance, library-owned RCCL communicators); each rank holds 1 / world of the covariance and gets the same
         numbers back; `sampler` draws from the f posterior through the driver too (rank 0's normals).  `dlogp` (and so
         `find_MAP`) works too: from the first gradient on, the factorisation carries the identity as right-hand-side rows
-        and K^-1 is formed row block by row block where the rows live (g3_dist_gp_dlogp).  Full covariances need the
-        whole factor on one device and raise in this mode.  `dist`: an initialised torch.distributed (any backend; it
+        and K^-1 is formed row block by row block where the rows live (g3_dist_gp_dlogp).  The M x M posterior covariance
+        (`covariance`, `cholesky`, `predict(cov=True)`) is formed in row chunks and gathered on every rank
+        (g3_dist_posterior_cov); cross kernels (`cross_mean`) are not available.  `dist`: an initialised torch.distributed (any backend; it
         only carries 256 bytes of communicator ids, or everything with transport='callbacks', the one-GPU rehearsal)."""
         self._dist = dict(dist=dist, rank=int(rank), world=int(world), nb=nb, transport=transport, dgp=None, shape=None,
                           grad=False)
@@ -326,11 +327,16 @@ class EllipticalProcess(StochasticProcess):
         if prior:
             K, M, Mp = self._prior_gram(values, space, noise)
             return K, M, Mp
-        if self._dist is not None:
-            raise _lib.G3Error('the full posterior covariance (and draws from it) needs the whole factor on one device: '
-                               'not available on a distributed process (mean / variance / quantiles / logp are)')
         c = self._factor(values, inputs, outputs)
         self._solve(c, values, c['which'] or 'post')
+        if self._dist is not None:
+            # several GPUs: V = K(space, X) L^-T lives in the driver's right-hand-side rows; every rank forms the rows of
+            # its chunks, the M x M matrix is gathered on all of them (g3_dist_posterior_cov)
+            _, _, _, M, Mp = self._cross(c, values, space, noise)        # the driver's last evaluation is at this space
+            K = dev.alloc(Mp, Mp, self.dtype)
+            kern = self.f_kernel_noise if noise else self.f_kernel
+            self._dist['dgp'].posterior_cov(kern.spec(values, c['d']), dev.upload(self._x(space)), K)
+            return K, M, Mp
         V, _, _, M, Mp = self._cross(c, values, space, noise)
         K, _, _ = self._prior_gram(values, space, noise, pad=True)
         dev.gemm_nt(K, V, V, Mp, Mp, c['Np'], alpha=-1.0, beta=1.0)        # elliptical.py:86-91

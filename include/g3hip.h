@@ -398,6 +398,14 @@ int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb, g3_dtype d
 int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog_noise, const g3_kernel_prog* prog_cross,
                               const void* X_dev, int64_t ldx, const void* delta_dev, const void* Xs_dev, int64_t ldxs,
                               double out_host[5], double* mean_host, double* ss_host);
+/* The posterior covariance itself, K(Xs, Xs) - V V^T (elliptical.py:86-91; prog with the Noise term for the noisy
+ * covariance, without for the f process -- NOISE / WN leaves act on the true diagonal as in kernel.cov(Xs)), from the
+ * last g3_dist_gp_factor_predict at the same Xs: every rank forms the lower part of the rows of its chunks, the matrix
+ * is all-gathered and mirrored, and EVERY rank's cov_dev (roundup(M,128) square, row stride ldc, zero outside M x M)
+ * receives the full symmetric matrix. */
+int g3_dist_posterior_cov(g3_dist* D, const g3_kernel_prog* prog, const void* Xs_dev, int64_t ldxs, void* cov_dev,
+                          int64_t ldc);
+
 /* After g3_dist_gp_factor_predict: posterior covariance K_f(Xs, Xs) - V V^T, its robust Cholesky and the latent draws
  * loc + L_post Z (gaussian.py:75-97, elliptical.py:86-92).  loc_host (M), Z_host (M x S), out_host (M x S) are host
  * arrays of the plan's dtype; every rank returns the same draws. */

@@ -319,12 +319,11 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         if rank == 0:
             np.savez(out_path, logp=lp, logp2=lp2, mean=pr.mean, var=pr.variance, std=pr.std, median=pr.median,
                      qu=pr.quantile_up, qd=pr.quantile_down, lpred=lpred, other=other, smp=smp, grad=grad)
-        try:
-            gp.kernel(params)
-            ok = False
-        except g3.G3Error:
-            ok = True
-        assert ok, 'the full covariance must refuse on a distributed process'
+        cov = np.asarray(gp.kernel(params))              # formed in row chunks, gathered on every rank
+        cov_n = np.asarray(gp.kernel(params, noise=True))
+        chol = np.asarray(gp.cholesky(params))
+        if rank == 0:
+            np.savez(out_path.replace('.npz', '_cov.npz'), cov=cov, cov_n=cov_n, chol=chol)
         gp.undistribute()
         assert abs(gp.logp(params) - lp) <= 1e-10 * abs(lp)       # and the same process object works on one GPU again
         g1, g1b = np.asarray(gp.dlogp(params)), np.asarray(gp.dlogp(p2))      # ... where K^-1 is one matrix

@@ -351,6 +351,11 @@ def test_public_api_on_several_ranks(tmp_path, world, warped):
     np.testing.assert_allclose(r['other'], gp.mean(params, space=Xs[: M // 2]), atol=1e-8)
     Z = np.random.default_rng(100).standard_normal((M, 4))
     np.testing.assert_allclose(r['smp'], gp.sampler(params, samples=4, rand=Z), atol=1e-7)     # rank 0's normals, same draws
+    rc = np.load(out.replace('.npz', '_cov.npz'))        # the full posterior covariance, f and noisy, and its Cholesky factor
+    np.testing.assert_allclose(rc['cov'], np.asarray(gp.kernel(params)), atol=1e-8)
+    np.testing.assert_allclose(rc['cov_n'], np.asarray(gp.kernel(params, noise=True)), atol=1e-8)
+    np.testing.assert_allclose(rc['cov'], rc['cov'].T, atol=0)
+    np.testing.assert_allclose(rc['chol'], np.asarray(gp.cholesky(params)), atol=1e-6)
     g1 = np.asarray(gp.dlogp(params))          # dlogp on the distributed process = the one-GPU gradient (kernel, location, warping hypers)
     np.testing.assert_allclose(r['grad'], g1, rtol=1e-7, atol=1e-8 * np.abs(g1).max())
 
