@@ -214,7 +214,8 @@ def test_native_driver_staircase_longer_than_one_launch(tmp_path, monkeypatch):
     world, N, d, M, nb = 2, 2300, 4, 300, 128
     spec_f = ('SE', 1.0, np.ones(d), None)
     out = str(tmp_path / 'res.npz')
-    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, 0.1, out, False, 5), nprocs=world, join=True)
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, 0.1, out, False, 5, 'f64', True),
+             nprocs=world, join=True)
     r = np.load(out)
     X, y, Xs = synth(N, d, M, 77)
     gp = orc.GP(spec_f, 0.1)
@@ -222,6 +223,15 @@ def test_native_driver_staircase_longer_than_one_launch(tmp_path, monkeypatch):
     assert abs(float(r['logp']) - ref) <= 1e-9 * abs(ref)
     Z = np.random.default_rng(5).standard_normal((M, 5))
     np.testing.assert_allclose(r['draws'], gp.sampler(Xs, X, y, rand=Z), atol=1e-7)
+    # the gradient stage's staircase launches (K^-1 row blocks, diagonal blocks cut at the diagonal) are chunked too
+    alpha, ref_g = _grad_reference(orc.with_noise(spec_f, 0.1), X, y)
+    np.testing.assert_allclose(r['alpha'], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+    from g3py_amd.device import compile_spec
+    import g3py_amd as g3
+    gmap = g3.Device(0).grad_layout(compile_spec(orc.with_noise(spec_f, 0.1), d))
+    for (leaf, pname, k, want, scale) in ref_g:
+        got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
+        assert abs(got - want) < 1e-8 * scale, (leaf, pname, k, got, want)
 
 
 def _grad_reference(spec_n, X, y):
@@ -285,6 +295,29 @@ def test_native_driver_gradient_one_rank_through_rccl(tmp_path):
     for (leaf, pname, k, want, scale) in ref:
         got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
         assert abs(got - want) < 1e-8 * scale, (leaf, pname, k, got, want)
+
+
+def test_native_driver_gradient_fp32(tmp_path):
+    """the gradient stage in fp32 (config 5's arithmetic) on three ranks: alpha and the parameter sums to fp32 accuracy"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    from g3py_amd.device import compile_spec
+    import g3py_amd as g3
+    world, N, d, M, nb = 3, 600, 3, 30, 128
+    spec_f = ('SE', 1.2, np.array([0.9, 1.1, 0.7]), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, 0.3, out, False, 0, 'f32', True),
+             nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    spec_n = orc.with_noise(spec_f, 0.3)
+    X32, y32 = X.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64)
+    alpha, ref = _grad_reference(spec_n, X32, y32)
+    np.testing.assert_allclose(r['alpha'], alpha, rtol=2e-3, atol=2e-3 * np.abs(alpha).max())
+    gmap = g3.Device(0).grad_layout(compile_spec(spec_n, d))
+    for (leaf, pname, k, want, scale) in ref:
+        got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
+        assert abs(got - want) < 5e-3 * scale, (leaf, pname, k, got, want)
 
 
 def test_gram_grad_rows_add_up():
