@@ -39,6 +39,8 @@ Gram: every rank builds exactly its own rows from the replicated N x d input: no
 Scalars (log det, a^T a, posterior mean / variance pieces): one broadcast of a = L^-1 delta and one all-reduce of a
 short vector.  Only broadcast, all_gather and all_reduce are used.
 """
+import sys as _sys
+
 import numpy as np
 
 
@@ -936,10 +938,9 @@ class NativeDistributedGP:
         self.h = self._C.c_void_p()
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
-        try:
+        try:                              # (no import here: at interpreter shutdown the import machinery is already gone)
+            if _sys is None or _sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass
