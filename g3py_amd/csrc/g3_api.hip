@@ -20,12 +20,12 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   int prev_dev = -1;                       // like every other entry: the caller's current device is restored
   if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority
-    e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
-  }
+  int lo = 0, hi = 0;
+  if (e == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority, hi = greatest
+  // the chain runs on the context's stream at the greatest priority, the bulk updates on the side stream at the least:
+  // measured, a bulk stream WITHOUT the low priority costs 2 % (N = 8192) to 10 % (N = 32768) of the step
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, G3_MAX_BATCH * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, G3_PROG_SLOTS * sizeof(g3_kernel_prog));
