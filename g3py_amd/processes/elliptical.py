@@ -55,7 +55,7 @@ class EllipticalProcess(StochasticProcess):
         `find_MAP`) works too: from the first gradient on, the factorisation carries the identity as right-hand-side rows
         and K^-1 is formed row block by row block where the rows live (g3_dist_gp_dlogp).  The M x M posterior covariance
         (`covariance`, `cholesky`, `predict(cov=True)`) is formed in row chunks and gathered on every rank
-        (g3_dist_posterior_cov); cross kernels (`cross_mean`) are not available.  `dist`: an initialised torch.distributed (any backend; it
+        (g3_dist_posterior_cov); `cross_mean` passes its cross kernel to the driver.  `dist`: an initialised torch.distributed (any backend; it
         only carries 256 bytes of communicator ids, or everything with transport='callbacks', the one-GPU rehearsal)."""
         self._dist = dict(dist=dist, rank=int(rank), world=int(world), nb=nb, transport=transport, dgp=None, shape=None,
                           grad=False)
@@ -72,8 +72,9 @@ class EllipticalProcess(StochasticProcess):
         self._workspace = None
         return self
 
-    def _dist_step(self, c, values, dl, space):
-        """one evaluation on all ranks: (stats, cross-solve results or None)"""
+    def _dist_step(self, c, values, dl, space, cross_kernel=None):
+        """one evaluation on all ranks: (stats, cross-solve results or None); cross_kernel: the kernel of the cross
+        covariance K(space, X) when it is not the process's own (th_cross_mean, gaussian.py:99-112)"""
         from ..distributed import NativeDistributedGP
         ds, dev = self._dist, self.device
         N, d = c['N'], c['d']
@@ -93,14 +94,16 @@ class EllipticalProcess(StochasticProcess):
         dvec = self._workspace['dvec']
         dev.copy_in(dvec, np.where(np.isfinite(dl), dl, 0).astype(self.dtype))
         Sd = dev.upload(S) if M > 0 else c['Xd']
-        dgp.step(self.f_kernel_noise.spec(values, d), self.f_kernel.spec(values, d), c['Xd'], Sd, dvec)
+        kc = cross_kernel if cross_kernel is not None else self.f_kernel
+        dgp.step(self.f_kernel_noise.spec(values, d), kc.spec(values, d), c['Xd'], Sd, dvec)
         last = dgp.last
         st = dict(logdet=last['logdet'], quad=last['quad'], nonfinite=0 if np.isfinite(last['quad']) else 1,
                   tries=last['tries'], fallback=last['fallback'], info=last['info'])
         cross = None
         if M > 0:
             Mp = _lib.roundup(M, _lib.G3_RHS_PAD)
-            cross = dict(kid=(False, None), S=S.copy(), out=(None, np.asarray(last['mean'], dtype=self.dtype),
+            cross = dict(kid=(False, id(cross_kernel) if cross_kernel is not None else None), S=S.copy(),
+                         out=(None, np.asarray(last['mean'], dtype=self.dtype),
                                                                np.asarray(last['ss'], dtype=self.dtype), M, Mp))
         return st, cross
 
@@ -215,11 +218,10 @@ class EllipticalProcess(StochasticProcess):
         cc = c.get('cross')
         if self._dist is not None:
             # the Noise term contributes nothing to a cross block (kernels.py:367-371): one cross solve serves both flags
-            if kernel is not None:
-                raise _lib.G3Error('cross kernels are not available on a distributed process')
-            if cc is None or cc['S'].shape != S.shape or not np.array_equal(cc['S'], S):
+            kd = id(kernel) if kernel is not None else None
+            if cc is None or cc['kid'][1] != kd or cc['S'].shape != S.shape or not np.array_equal(cc['S'], S):
                 dl = c['delta'] if c['which'] == 'logp' else c['delta_post']
-                st, cc = self._dist_step(c, values, dl, S)          # another space than the process's own: one more evaluation
+                st, cc = self._dist_step(c, values, dl, S, cross_kernel=kernel)   # another space / cross kernel: one more evaluation
                 c['stats'], c['cross'] = dict(st, delta_finite=c['stats']['delta_finite']), cc
             return cc['out']
         if cc is not None and cc['kid'] == kid and cc['S'].shape == S.shape and np.array_equal(cc['S'], S):

@@ -311,6 +311,10 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         gp.mean(params)                                     # back to the process's own space: the driver holds its cross solve
         Z = np.random.default_rng(100 + rank).standard_normal((M, 4))      # ranks draw DIFFERENT normals: rank 0's must win
         smp = gp.sampler(params, samples=4, rand=Z)
+        k2 = g3.OU(X, var=0.7, metric=g3.ARD_L1(X, rate=np.full(d, 0.8)))
+        cm = np.asarray(gp.cross_mean(params, cross_kernel=k2))   # another kernel for K(space, X) (gaussian.py:99-112)
+        m_again = np.asarray(gp.mean(params))                      # ... must not poison the cached cross solve
+        assert np.allclose(m_again, np.asarray(pr.mean), rtol=0, atol=1e-12)
         grad = np.asarray(gp.dlogp(params))                 # switches the driver to gradient mode (identity rows ride along)
         lp3 = gp.logp(params)
         assert abs(lp3 - lp) <= 1e-11 * abs(lp), (lp3, lp)
@@ -327,6 +331,7 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
         gp.undistribute()
         assert abs(gp.logp(params) - lp) <= 1e-10 * abs(lp)       # and the same process object works on one GPU again
         g1, g1b = np.asarray(gp.dlogp(params)), np.asarray(gp.dlogp(p2))      # ... where K^-1 is one matrix
+        np.testing.assert_allclose(cm, np.asarray(gp.cross_mean(params, cross_kernel=k2)), atol=1e-8)
         assert abs(gp.logp(p2) - lp_b) <= 1e-10 * abs(lp_b)
         np.testing.assert_allclose(grad, g1, rtol=1e-7, atol=1e-8 * np.abs(g1).max())
         np.testing.assert_allclose(grad_b, g1b, rtol=1e-7, atol=1e-8 * np.abs(g1b).max())
