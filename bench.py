@@ -283,6 +283,7 @@ def main():
         # all ranks are on ONE node (the bench contract): RCCL's bootstrap sockets go over loopback, whatever the
         # container's hostname / interfaces resolve to (checked with one rank: profiles/r03_bench_dist1_nccl.json)
         os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')    # the gloo group (ids, barriers, timing) too
     # One rank per GPU.  G3_DIST_DRIVER=native (default): the multi-GPU driver INSIDE libg3hip (g3_dist_*: the library
     # owns the RCCL communicators, streams and the per-panel loop); torch.distributed over gloo only carries the
     # 2 x 128 communicator-id bytes, the barriers and the max-over-ranks of the timing.  G3_DIST_DRIVER=python: the
