@@ -73,3 +73,43 @@ def test_random_shape_matches_oracle(dev, case):
     assert abs(lp - lp_ref) <= 1e-8 * max(1.0, abs(lp_ref)), (N, d, M, spec_f[0])
     np.testing.assert_allclose(dev.download(mu, 1, M)[0], mean_ref, atol=1e-8, rtol=1e-8)
     np.testing.assert_allclose(np.maximum(prior - dev.download(ss, 1, M)[0], 0), var_ref, atol=1e-8, rtol=1e-8)
+
+
+GRAD_SIZES = [1, 2, 63, 64, 65, 127, 129, 255, 257, 511, 513, 700, 1023, 1025, 1300, 1537]
+
+
+@pytest.mark.parametrize('case', range(len(GRAD_SIZES)))
+def test_random_shape_gradient_matches_oracle(dev, case):
+    """g3_gp_dlogp (g3_potri + alpha + g3_gram_grad after g3_gp_factor) at ragged sizes around the 64-wide pair tiles of
+    the gradient kernels and the 128 / 256-wide blocks of the inverse, random kernel expressions (fast paths and the
+    interpreter): every parameter sum 1/2 sum_ij (alpha alpha^T - K^-1)_ij dK_ij/dtheta and alpha against the oracle"""
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    rng = np.random.default_rng(7000 + case)
+    N = GRAD_SIZES[case]
+    d = int(rng.integers(1, 5))
+    noise = float(rng.choice([0.1, 0.5]))
+    X = rng.uniform(0, max(N, 2) ** (1.0 / d), (N, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N)
+    spec_n = orc.with_noise(_specs(rng, d), noise)
+    K, grads = orc.kernel_cov_grads(spec_n, X)
+    Kinv = np.linalg.inv(K)
+    alpha_ref = Kinv @ y
+    G = np.outer(alpha_ref, alpha_ref) - Kinv
+    prog = compile_spec(spec_n, d)
+    gmap = dev.grad_layout(prog)
+    assert gmap.nslots == len(grads)
+    Np = _lib.roundup(N)
+    Kd = dev.alloc(Np + 128, Np, np.float64)
+    W, a = dev.alloc_inverses(Np, np.float64), dev.alloc(1, Np, np.float64)
+    Xd = dev.upload(X)
+    st = dev.gp_factor(prog, Xd, N, d, dev.upload(y), Kd, W, a)
+    assert st['info'] == 0
+    Y, Ki, al = dev.alloc(Np, Np, np.float64), dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64)
+    slots = dev.gp_dlogp(prog, gmap, Xd, N, d, Kd, W, a, Y, Ki, al)
+    np.testing.assert_allclose(dev.download(al, 1, N)[0], alpha_ref, rtol=1e-7, atol=1e-8 * max(np.abs(alpha_ref).max(), 1e-30))
+    for (leaf, pname, k, dK) in grads:
+        want, scale = 0.5 * np.sum(G * dK), 0.5 * np.sum(np.abs(G * dK)) + 1e-30
+        got = slots[getattr(gmap, pname)[leaf] + (0 if k is None else k)]
+        assert abs(got - want) < 1e-8 * scale, (N, d, spec_n, leaf, pname, k, got, want)
