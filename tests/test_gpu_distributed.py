@@ -130,7 +130,8 @@ def test_native_driver_matches_oracle(tmp_path, world, N, nb, M):
     d = 4
     spec_f = ('SE', 1.0, np.ones(d), None)
     out = str(tmp_path / 'res.npz')
-    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, 0.1, out), nprocs=world, join=True)
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, 0.1, out, False, 0, 'f64', True),
+             nprocs=world, join=True)
     r = np.load(out)
     X, y, Xs = synth(N, d, M, 77)
     gp = orc.GP(spec_f, 0.1)
@@ -138,6 +139,8 @@ def test_native_driver_matches_oracle(tmp_path, world, N, nb, M):
     assert abs(float(r['logp']) - ref) <= 1e-10 * abs(ref)
     np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-8)
     np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
+    # the same ranks then switched to gradient mode (g3_dist_set_grad + g3_dist_gp_dlogp): parameter sums and alpha
+    _check_gradient(r, orc.with_noise(spec_f, 0.1), X, y, d)
 
 
 def test_native_driver_one_rank_through_rccl(tmp_path):
@@ -244,8 +247,20 @@ def _grad_reference(spec_n, X, y):
     return alpha, [(leaf, pname, k, 0.5 * np.sum(G * dK), 0.5 * np.sum(np.abs(G * dK)) + 1e-30) for (leaf, pname, k, dK) in grads]
 
 
-@pytest.mark.parametrize('world,N,nb,M,kern', [(1, 900, 256, 40, 'se'), (2, 900, 256, 40, 'se'), (2, 1100, 128, 130, 'm52cos'),
-                                               (3, 700, 128, 0, 'rq'), (4, 1000, 128, 20, 'se'), (5, 640, 128, 129, 'm52cos')])
+def _check_gradient(r, spec_n, X, y, d, rtol=1e-8):
+    from g3py_amd.device import compile_spec
+    import g3py_amd as g3
+    alpha, ref = _grad_reference(spec_n, X, y)
+    assert abs(float(r['logp_grad']) - float(r['logp'])) <= 1e-11 * abs(float(r['logp']))
+    np.testing.assert_allclose(r['alpha'], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+    gmap = g3.Device(0).grad_layout(compile_spec(spec_n, d))
+    assert len(r['slots']) == gmap.nslots == len(ref)
+    for (leaf, pname, k, want, scale) in ref:
+        got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
+        assert abs(got - want) < rtol * scale, (leaf, pname, k, got, want)
+
+
+@pytest.mark.parametrize('world,N,nb,M,kern', [(2, 1100, 128, 130, 'm52cos'), (3, 700, 128, 0, 'rq')])   # SE, 1 - 5 ranks: in test_native_driver_matches_oracle
 def test_native_driver_gradient(tmp_path, world, N, nb, M, kern):
     """g3_dist_set_grad + g3_dist_gp_dlogp: the identity rides through the factorisation as right-hand-side rows (the
     rank's rows of L^-T), K^-1 rows by gathered panels + staircase products, the gradient kernel over the rank's row
@@ -264,15 +279,7 @@ def test_native_driver_gradient(tmp_path, world, N, nb, M, kern):
              nprocs=world, join=True)
     r = np.load(out)
     X, y, Xs = synth(N, d, max(M, 1), 77)
-    spec_n = orc.with_noise(spec_f, 0.1)
-    alpha, ref = _grad_reference(spec_n, X, y)
-    assert abs(float(r['logp_grad']) - float(r['logp'])) <= 1e-11 * abs(float(r['logp']))
-    np.testing.assert_allclose(r['alpha'], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
-    gmap = g3.Device(0).grad_layout(compile_spec(spec_n, d))
-    assert len(r['slots']) == gmap.nslots == len(ref)
-    for (leaf, pname, k, want, scale) in ref:
-        got = r['slots'][getattr(gmap, pname)[leaf] + (0 if k is None else k)]
-        assert abs(got - want) < 1e-8 * scale, (leaf, pname, k, got, want)
+    _check_gradient(r, orc.with_noise(spec_f, 0.1), X, y, d)
 
 
 def test_native_driver_gradient_one_rank_through_rccl(tmp_path):
