@@ -212,28 +212,11 @@ struct g3_dist {
     }                                                                                              \
   } while (0)
 
-static int owner_of(const g3_dist* D, int I) {
-  // boustrophedon dealing 0..P-1, P-1..0, ...: the trailing work of block I grows like I^2 and the snake keeps
-  // the ranks' shares within a few per cent (plain round-robin leaves the last rank at 1.4x the mean)
-  const int P = D->world, r = I % (2 * P);
-  return r < P ? r : 2 * P - 1 - r;
-}
+static int owner_of(const g3_dist* D, int I) { return g3h_owner_of(D->world, I); }   // boustrophedon dealing (g3_host.h)
 
 // blocks per rank in the padded gather of step k, and the position of global block k+1+s in the rank-major
 // gather buffer
-static int perm_of(const g3_dist* D, int k, std::vector<int32_t>* idx) {
-  const int P = D->world;
-  std::vector<int> cnt(P, 0), seen(P, 0);
-  for (int I = k + 1; I < D->nblk; ++I) cnt[owner_of(D, I)]++;
-  int c = 0;
-  for (int q = 0; q < P; ++q) c = cnt[q] > c ? cnt[q] : c;
-  idx->clear();
-  for (int I = k + 1; I < D->nblk; ++I) {
-    const int q = owner_of(D, I);
-    idx->push_back(q * c + seen[q]++);
-  }
-  return c;
-}
+static int perm_of(const g3_dist* D, int k, std::vector<int32_t>* idx) { return g3h_gather_table(D->world, k + 1, D->nblk - 1, idx); }
 
 static inline char* Aat(const g3_dist* D, int64_t row, int64_t col) { return D->A + ((size_t)row * D->Np + col) * D->es; }
 static inline char* Lof(const g3_dist* D, int k) { return D->dbuf[k % 2]; }
@@ -1056,17 +1039,8 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(const T* __restrict__ A, 
 }
 
 static int perm_upto(const g3_dist* D, int k, std::vector<int32_t>* idx) {   // blocks 0 .. k in the rank-major gather
-  const int P = D->world;
-  std::vector<int> cnt(P, 0), seen(P, 0);
-  for (int I = 0; I <= k; ++I) cnt[owner_of(D, I)]++;
-  int c = 1;
-  for (int q = 0; q < P; ++q) c = cnt[q] > c ? cnt[q] : c;
-  idx->clear();
-  for (int I = 0; I <= k; ++I) {
-    const int q = owner_of(D, I);
-    idx->push_back(q * c + seen[q]++);
-  }
-  return c;
+  const int c = g3h_gather_table(D->world, 0, k, idx);
+  return c < 1 ? 1 : c;
 }
 
 extern "C" int g3_dist_set_grad(g3_dist* D, int on) {

@@ -237,6 +237,28 @@ static inline void trsm_ops_rec(TrsmOps* ops, int64_t c0, int64_t n) {
 }
 
 
+// ---- dealing of the multi-GPU driver (g3_dist.hip): row block I of the covariance lives on rank g3h_owner_of(P, I) --
+// boustrophedon 0..P-1, P-1..0, ...: the trailing work of block I grows like I^2 and the snake keeps the ranks' shares
+// within a few per cent (plain round-robin leaves the last rank at 1.4x the mean).
+static inline int g3h_owner_of(int P, int I) {
+  const int r = I % (2 * P);
+  return r < P ? r : 2 * P - 1 - r;
+}
+// position of the blocks lo .. hi in a rank-major padded all-gather of them (every rank contributes `return value`
+// block slots, its own blocks in ascending order first): idx[I - lo] = owner * count + (number of the owner's earlier blocks)
+static inline int g3h_gather_table(int P, int lo, int hi, std::vector<int32_t>* idx) {
+  std::vector<int> cnt(P, 0), seen(P, 0);
+  for (int I = lo; I <= hi; ++I) cnt[g3h_owner_of(P, I)]++;
+  int c = 0;
+  for (int q = 0; q < P; ++q) c = cnt[q] > c ? cnt[q] : c;
+  idx->clear();
+  for (int I = lo; I <= hi; ++I) {
+    const int q = g3h_owner_of(P, I);
+    idx->push_back(q * c + seen[q]++);
+  }
+  return c;
+}
+
 // ---- staircase launches of the multi-GPU sweep.  One launch describes at most G3H_STAIR_MAX row segments and
 // G3H_STAIR_MAX blocks of the B operand (the raster table travels in the kernel arguments, g3_gemm.hip::RasterTab):
 // a longer staircase -- N / nb > 160 row blocks -- is cut into row chunks and column chunks.

@@ -333,7 +333,41 @@ static void test_ring_and_jitter() {
   CHECK(!n.usable());
 }
 
+static void test_dealing() {
+  // the multi-GPU driver's block dealing and gather tables: every block has exactly one owner, the snake keeps the
+  // counts within one, the table is injective, rank-major, ascending inside a rank, and never reaches past P * count
+  for (int P = 1; P <= 9; ++P)
+    for (int nblk = 1; nblk <= 70; nblk += (nblk < 20 ? 1 : 7)) {
+      std::vector<int> cnt(P, 0);
+      for (int I = 0; I < nblk; ++I) {
+        const int q = g3h_owner_of(P, I);
+        CHECK(q >= 0 && q < P);
+        cnt[q]++;
+      }
+      int lo = cnt[0], hi = cnt[0];
+      for (int q = 0; q < P; ++q) { lo = cnt[q] < lo ? cnt[q] : lo; hi = cnt[q] > hi ? cnt[q] : hi; }
+      CHECK(hi - lo <= 1);
+      for (int a = -1; a < nblk; a += (nblk < 12 ? 1 : 5))
+        for (int b = a; b < nblk; b += (nblk < 12 ? 1 : 3)) {
+          const int first = a + 1, last = b;          // perm_of(k): k + 1 .. nblk - 1; perm_upto(k): 0 .. k
+          std::vector<int32_t> idx;
+          const int c = g3h_gather_table(P, first, last, &idx);
+          CHECK((int)idx.size() == (last >= first ? last - first + 1 : 0));
+          std::vector<int> seen(P * (c > 0 ? c : 1), 0), prev(P, -1);
+          for (int I = first; I <= last; ++I) {
+            const int t = idx[I - first], q = g3h_owner_of(P, I);
+            CHECK(c > 0 && t >= q * c && t < (q + 1) * c);      // inside the owner's slots
+            CHECK(!seen[t]);                                    // injective
+            seen[t] = 1;
+            CHECK(t > prev[q]);                                 // ascending inside a rank
+            prev[q] = t;
+          }
+        }
+    }
+}
+
 int main() {
+  test_dealing();
   test_rasters();
   test_trsm_ops();
   test_panel_bounds();
