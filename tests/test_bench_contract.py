@@ -1,0 +1,68 @@
+"""bench.py's one-line JSON contract: the fields the driver and the judge read, their types and their internal consistency --
+on a committed line of the final tree (CPU) and on a fresh small run (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {'metric': str, 'value': float, 'unit': str, 'n_gpus': int, 'steps': int, 'warmup': int, 'ms_per_step': float,
+            'higher_is_better': bool, 'scaling': str, 'dtype': str, 'data': str, 'config': dict}
+
+
+def _check_line(j, n_gpus=1):
+    for k, t in REQUIRED.items():
+        assert k in j and isinstance(j[k], t), (k, type(j.get(k)))
+    assert 'vs_baseline' in j and j['vs_baseline'] is None          # BASELINE.md holds no published number for this metric
+    assert j['n_gpus'] == n_gpus and j['higher_is_better'] is True and j['data'] == 'synthetic'
+    assert j['dtype'] in ('f64', 'f32') and 'workload' in j['config'] and 'model' not in j['config']
+    # value = algorithmic flops of the step / measured time
+    N, M = j['config']['N'], j['config']['M']
+    sys.path.insert(0, ROOT)
+    import bench
+    flops = bench.step_flops(N, M, j['config'].get('draws', 0))
+    assert abs(j['value'] - flops / (j['ms_per_step'] * 1e-3) / 1e12) <= 1e-9 * j['value']
+    r = j['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) <= 1e-12 and 0 < r['frac'] < 1
+    assert abs(r['achieved'] - r['avg_launch_flops'] / (r['avg_launch_ms'] * 1e-3) / 1e12) <= 1e-9 * r['achieved']
+    assert r['traffic'] is None or r['traffic'] > 0
+    if n_gpus == 1 and 'cpu_baseline' in j:
+        c = j['cpu_baseline']
+        assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
+
+
+def test_committed_headline_line_keeps_the_contract():
+    j = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bench_final.json')))
+    _check_line(j)
+    assert j['config']['N'] == 32768 and j['dtype'] == 'f64' and 'cpu_baseline' in j and 'api_ms' in j
+    assert j['logp_rel_err'] <= 1e-8                                # against the full-size oracle pin
+    assert j['roofline']['traffic'] > j['roofline']['avg_launch_flops'] / 1e6   # bytes, not GB
+
+
+def test_step_flops_and_synthetic_inputs_are_what_survey_8d_states():
+    sys.path.insert(0, ROOT)
+    import bench
+    N, M = 1000, 64
+    assert bench.step_flops(N, M, 0) == pytest.approx(N ** 3 / 3.0 + N * N * (1 + M) + 2.0 * N * M, rel=1e-12)
+    X, y, Xs = bench.synth(300, 3, 20, 1004)
+    X2, y2, _ = bench.synth(300, 3, 20, 1004)
+    assert np.array_equal(X, X2) and np.array_equal(y, y2) and X.shape == (300, 3) and Xs.shape == (20, 3)
+    assert 0 <= X.min() and X.max() <= 300 ** (1 / 3) + 1e-12        # unit point density box
+    assert bench.usable_cores() >= 1
+
+
+@pytest.mark.gpu
+def test_fresh_small_run_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--points', '4096', '--queries', '256', '--steps', '2',
+                          '--warmup', '1', '--cpu-n', '1024', '--no-measure-traffic', '--no-api'], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    _check_line(j)
+    assert j['steps'] == 2 and j['warmup'] == 1 and j['config']['N'] == 4096 and 'cpu_baseline' in j
