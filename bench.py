@@ -588,6 +588,20 @@ def main():
             kern = ('gemm_nt_kernel<%s,*>: rank 0, every staircase launch of the bulk stream + a 1-in-16 sample of the chain ' \
                     "stream's MFMA GEMM launches" if native else 'gemm_nt_kernel<%s,*>: 1-in-16 sample of the MFMA GEMM launches of ' \
                     'rank 0 (trailing updates and panel solves of its row blocks)') % ('float' if args.f32 else 'double')
+        launches_div = args.steps
+        if not use_dist and not g['count'] and not args.no_prof:
+            # a size without a single >= 4096-tile launch (N < ~12000): one more, UNTIMED pass with HIP events around every
+            # MFMA GEMM launch -- the dominant kernel class is then all of them (their events would perturb a timed small step)
+            dev.prof_enable(2)
+            dev.prof_reset()
+            step()
+            torch.cuda.synchronize()
+            p2 = dev.prof_collect()
+            dev.prof_enable(False)
+            g = {k: sum(p2[t][k] for t in ('gemm_bulk', 'gemm_mid', 'gemm_small')) for k in ('count', 'ms', 'work')}
+            launches_div = 1
+            kern = 'gemm_nt_kernel<%s,*>: every MFMA GEMM launch of one extra, untimed pass (no launch of this size reaches ' \
+                   '4096 tiles; panel updates and stripe solves)' % ('float' if args.f32 else 'double')
         if g['count'] and g['ms'] > 0:
             ach = g['work'] / (g['ms'] * 1e-3) / 1e12
             peak = FP32_MATRIX_PEAK_TFLOPS if args.f32 else FP64_MATRIX_PEAK_TFLOPS
@@ -597,7 +611,7 @@ def main():
                                'traffic_source': 'profiles/r*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
                                                  'passes of this command (not measured in this run)',
                                'kernel': kern,
-                               'launches_per_step': g['count'] / args.steps,
+                               'launches_per_step': g['count'] / launches_div,
                                'avg_launch_ms': g['ms'] / g['count'], 'avg_launch_flops': g['work'] / g['count'],
                                'note': 'HIP events per launch on the launching stream; launches on the two '
                                        'look-ahead streams overlap, so summed launch time exceeds wall time'}
