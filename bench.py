@@ -674,7 +674,7 @@ def main():
                 out['roofline']['traffic_source'] += '; live measurement unavailable: ' + note
         if args.api and world == 1 and not use_dist and S == 0:
             out['api_ms'] = _api_timing(g3, X, y, Xs, d, args.kernel, npdt)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
         if ref is not None and not out['logp_rel_err'] <= tol:
             failed = 'bench.py: logp %.12f differs from the oracle pin %.12f by more than %g relative' % (out['logp'], ref, tol)
     # every rank learns the verdict BEFORE the group is torn down, so a failed pin ends all ranks at once
@@ -684,12 +684,19 @@ def main():
         dist.broadcast(flag, src=0)
         if int(flag.item()) and not failed:
             failed = 'bench.py: rank 0 reported a failed oracle pin'
+    if watchdog is not None:
+        # the line is out (or the verdict known): from here on a stuck teardown must neither print a second line nor hold
+        # the node -- the run watchdog is replaced by one that just ends the process with the status already decided
+        watchdog.cancel()
+        import threading
+        sys.stdout.flush()
+        td = threading.Timer(120.0, lambda: os._exit(1 if failed else 0))
+        td.daemon = True
+        td.start()
     if use_dist and native:
         dgp.close()                       # communicators and driver buffers, before the contexts they live on
     if world > 1 or solo_pg:
         dist.destroy_process_group()
-    if watchdog is not None:
-        watchdog.cancel()
     # explicit teardown while the HIP runtime is alive (streams, events, pinned buffers, workspaces)
     g3.Device.close_all()
     if failed:
