@@ -180,6 +180,23 @@ def step_flops(N, M, S=0):
     return f
 
 
+class _StdoutToStderr:
+    """fd 1 points at stderr inside the block: gloo and RCCL announce themselves on the C stdout (connection counts, the
+    version banner at the first communicator), and the bench's stdout carries exactly ONE line"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def usable_cores():
     """CPU cores this process may actually use: the cgroup quota when there is one (a GPU box hands a
     one-GPU job a share of the host), else the affinity mask"""
@@ -313,12 +330,17 @@ def main():
                 s_.bind(('127.0.0.1', 0))
                 os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
     if world > 1 or solo_pg:
-        if driver == 'native':
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        elif backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # gloo announces its connections on the C stdout: the bench's stdout carries ONE line, so fd 1 points at stderr
+        # while the group comes up
+        with _StdoutToStderr():
+            if driver == 'native':
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+            elif backend == 'nccl':
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            if dist.get_backend() == 'gloo':
+                dist.barrier()
 
     tdev0 = torch.device('cuda', local_rank)
     import g3py_amd as g3
@@ -414,7 +436,8 @@ def main():
         if driver == 'native':
             why = ''
             try:
-                dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, dtype=npdt, transport=native_transport)
+                with _StdoutToStderr():
+                    dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, dtype=npdt, transport=native_transport)
             except Exception as e:       # noqa: BLE001 -- any failure on any rank sends ALL ranks to the python driver
                 why = '%s: %s' % (type(e).__name__, e)
             ok = torch.tensor([0 if dgp is None else 1], dtype=torch.int32)
@@ -466,8 +489,9 @@ def main():
         watchdog = threading.Timer(limit, _expired)
         watchdog.daemon = True
         watchdog.start()
-    for _ in range(args.warmup):
-        step()
+    with _StdoutToStderr():             # (the first collective of a communicator prints RCCL's banner)
+        for _ in range(args.warmup):
+            step()
     # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
     dev.prof_enable(0 if args.no_prof else (3 if use_dist else 1))
     dev.prof_reset()
