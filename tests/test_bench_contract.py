@@ -61,8 +61,24 @@ def test_fresh_small_run_prints_one_contract_line():
                           '--warmup', '1', '--cpu-n', '1024', '--no-measure-traffic', '--no-api'], capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), lines[:5]      # stdout carries the one line and nothing else
     j = json.loads(lines[0])
     _check_line(j)
     assert j['steps'] == 2 and j['warmup'] == 1 and j['config']['N'] == 4096 and 'cpu_baseline' in j
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl_keeps_stdout_to_the_one_line():
+    """G3_FORCE_DIST=1: the multi-GPU driver with one rank creates RCCL communicators, whose banner goes to the C stdout
+    unless bench.py redirects it -- the line must still be alone, and carry the comm block"""
+    env = dict(os.environ, G3_FORCE_DIST='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--points', '4096', '--queries', '256', '--steps', '1',
+                          '--warmup', '1', '--cpu-n', '0', '--no-measure-traffic', '--no-api'], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), lines[:5]
+    j = json.loads(lines[0])
+    assert j['comm']['driver'] == 'native' and j['comm']['per_rank'][0]['allgather']['calls_per_step'] > 0
+    assert j['logp_ref'] is None if 'logp_ref' in j else True
