@@ -371,3 +371,35 @@ def tp_worker(rank, world, port, N, d, M, out_path):
             np.savez(out_path, logp=lp, grad=g, ok=1)
     finally:
         dist.destroy_process_group()
+
+
+def native_multi_worker(rank, world, port, cases, out_path):
+    """several seeded random shapes through ONE process group: cases = [(N, d, M, nb, seed), ...]; rank 0 writes logp, mean,
+    ss, gradient sums and alpha of every case (driver re-created per case: plan, buffers, streams come and go)"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        from g3py_amd.distributed import NativeDistributedGP
+        from oracle import g3_oracle as orc
+        dev = g3.Device(0)
+        res = {}
+        for ci, (N, d, M, nb, seed) in enumerate(cases):
+            X, y, Xs = synth(N, d, M, seed)
+            spec_f = ('MAT32', 1.1, np.linspace(0.7, 1.2, d), None)
+            spec_n = orc.with_noise(spec_f, 0.2)
+            dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, dtype=np.float64, transport='callbacks')
+            Xd, Xsd, yd = dev.upload(X), dev.upload(Xs), dev.upload(y)
+            dgp.set_grad(True)
+            lp = dgp.step(spec_n, spec_f, Xd, Xsd, yd)
+            _, _, slots, alpha = dgp.dlogp(spec_n, Xd)
+            res['logp%d' % ci], res['mean%d' % ci], res['ss%d' % ci] = lp, dgp.last['mean'].copy(), dgp.last['ss'].copy()
+            res['slots%d' % ci], res['alpha%d' % ci] = slots, alpha
+            dgp.close()
+        if rank == 0:
+            np.savez(out_path, **res)
+    finally:
+        dist.destroy_process_group()

@@ -410,3 +410,33 @@ def test_student_t_process_on_two_ranks(tmp_path):
     mp.spawn(tp_worker, args=(2, _free_port(), 700, 3, 40, out), nprocs=2, join=True)
     r = np.load(out)
     assert int(r['ok']) == 1 and np.all(np.isfinite(r['grad']))
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_native_driver_random_shapes(tmp_path, world):
+    """seeded random shapes (ragged N around the block height, M around the 128-row chunks incl. M < world chunks, several
+    block heights) through one process group per world size: logp, posterior mean / variance and the gradient against the
+    oracle -- what the fixed cases cannot see: an off-by-one in the dealing of blocks, chunks or identity rows"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    from dist_helpers import native_multi_worker
+    rng = np.random.default_rng(400 + world)
+    cases = []
+    for _ in range(4):
+        nb = int(rng.choice([128, 256]))
+        N = int(rng.choice([nb - 1, nb + 1, 2 * nb, 3 * nb + 17, 5 * nb - 3, 7 * nb + 1]))
+        cases.append((N, int(rng.integers(1, 4)), int(rng.choice([1, 127, 128, 129, 260])), nb, int(rng.integers(1, 1000))))
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(native_multi_worker, args=(world, _free_port(), cases, out), nprocs=world, join=True)
+    r = np.load(out)
+    for ci, (N, d, M, nb, seed) in enumerate(cases):
+        X, y, Xs = synth(N, d, M, seed)
+        spec_f = ('MAT32', 1.1, np.linspace(0.7, 1.2, d), None)
+        gp = orc.GP(spec_f, 0.2)
+        ref = gp.logp(X, y)
+        assert abs(float(r['logp%d' % ci]) - ref) <= 1e-10 * abs(ref), (cases[ci], float(r['logp%d' % ci]), ref)
+        np.testing.assert_allclose(r['mean%d' % ci], gp.mean(Xs, X, y), atol=1e-8, err_msg=str(cases[ci]))
+        prior = np.diag(orc.kernel_cov(spec_f, Xs))
+        np.testing.assert_allclose(np.maximum(prior - r['ss%d' % ci], 0), gp.variance(Xs, X, y), atol=1e-8, err_msg=str(cases[ci]))
+        rr = {'logp': r['logp%d' % ci], 'logp_grad': r['logp%d' % ci], 'alpha': r['alpha%d' % ci], 'slots': r['slots%d' % ci]}
+        _check_gradient(rr, orc.with_noise(spec_f, 0.2), X, y, d)
