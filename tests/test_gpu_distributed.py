@@ -202,12 +202,29 @@ def test_native_driver_jitter_and_fallback(tmp_path, world):
     N, d, M, nb = 500, 1, 20, 256
     spec_f = ('SIN', 1.0, np.full(d, 0.37), np.full(d, 40.0), None)
     out = str(tmp_path / 'res2.npz')
-    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, None, out), nprocs=world, join=True)
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, None, out, False, 0, 'f64', True),
+             nprocs=world, join=True)
     r = np.load(out)
     X, y, Xs = synth(N, d, M, 77)
     assert bool(r['fallback']) and int(r['tries']) == 20
     ref = orc.GP(spec_f, None).logp(X, y)
     assert abs(float(r['logp']) - ref) <= 1e-8 * abs(ref)
+    # gradient mode on the fallback factor 1e-10 * I: L^-T = 1e10 * I rides in the identity rows; the sums equal what the
+    # one-GPU g3_gp_dlogp makes of the same fallback factor
+    import g3py_amd as g3
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    dev = g3.Device(0)
+    prog = compile_spec(spec_f, d)
+    Np = _lib.roundup(N)
+    Kd, W, a = dev.alloc(Np + 128, Np, np.float64), dev.alloc_inverses(Np, np.float64), dev.alloc(1, Np, np.float64)
+    Xd = dev.upload(X)
+    st = dev.gp_factor(prog, Xd, N, d, dev.upload(y), Kd, W, a)
+    assert st['fallback']
+    Y, Ki, al = dev.alloc(Np, Np, np.float64), dev.alloc(Np, Np, np.float64), dev.alloc(1, Np, np.float64)
+    one = dev.gp_dlogp(prog, dev.grad_layout(prog), Xd, N, d, Kd, W, a, Y, Ki, al)
+    np.testing.assert_allclose(r['slots'], one, rtol=1e-9)
+    np.testing.assert_allclose(r['alpha'], dev.download(al, 1, N)[0], rtol=1e-9)
 
 
 def test_native_driver_staircase_longer_than_one_launch(tmp_path, monkeypatch):
