@@ -13,6 +13,7 @@
 // flat right-looking sweep over panels with one-panel look-ahead on two streams.
 #include "g3_internal.h"
 #include <vector>
+#include <algorithm>
 #include "g3_host.h"
 #include "g3_mfma.h"
 #include <stdlib.h>
@@ -1300,3 +1301,178 @@ extern "C" int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void
   return robust_t<float>(ctx, (const float*)K_dev, ldk, (float*)L_dev, ldl, n, dt, maxtries,
                          tries_host, fallback_host, jitter_host);
 }
+
+#ifdef G3_PROBE
+// ---------------------------------------------------------------------------------------
+// Measurement build only (scripts/build_variant.sh probe g3_potrf.hip -DG3_PROBE): does a workgroup that holds a whole
+// CU (by its LDS request) run the fused 256-wide diagonal kernel at its stand-alone speed while a bulk update streams
+// through the other CUs, and what does a flag round trip between a stream and a resident kernel cost?
+template <typename T>
+__global__ void __launch_bounds__(512) probe_potrf_loop(T* Aall, const T* A0, int64_t ld, T* Wall, int* info, int reps,
+                                                        unsigned long long* ts) {
+  extern __shared__ __attribute__((aligned(16))) char smem_probe[];
+  DiagLds<T>& S = *reinterpret_cast<DiagLds<T>*>(smem_probe);
+  T* A = Aall + (int64_t)blockIdx.x * 256 * ld;
+  T* W = Wall + (int64_t)blockIdx.x * 2 * G3_LB * G3_LB;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = wv < 4 ? wv : 11 - wv;
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int e = threadIdx.x; e < 256 * 256; e += 512) A[(int64_t)(e >> 8) * ld + (e & 255)] = A0[(int64_t)(e >> 8) * ld + (e & 255)];
+    __threadfence_block();
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    switch (w) {
+      case 0: potrf256_wave<T, 0>(A, ld, W, info, 0, S, lane); break;
+      case 1: potrf256_wave<T, 1>(A, ld, W, info, 0, S, lane); break;
+      case 2: potrf256_wave<T, 2>(A, ld, W, info, 0, S, lane); break;
+      case 3: potrf256_wave<T, 3>(A, ld, W, info, 0, S, lane); break;
+      case 4: potrf256_wave<T, 4>(A, ld, W, info, 0, S, lane); break;
+      case 5: potrf256_wave<T, 5>(A, ld, W, info, 0, S, lane); break;
+      case 6: potrf256_wave<T, 6>(A, ld, W, info, 0, S, lane); break;
+      default: potrf256_wave<T, 7>(A, ld, W, info, 0, S, lane); break;
+    }
+    __syncthreads();
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) {
+      ts[((int64_t)blockIdx.x * reps + rep) * 2] = t0;
+      ts[((int64_t)blockIdx.x * reps + rep) * 2 + 1] = t1;
+    }
+  }
+}
+
+__global__ void probe_post(unsigned* flag, unsigned v) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void probe_wait(const unsigned* flag, unsigned v, unsigned* err) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 200000000ull) { atomicExch(err, 1u); break; }   // 2 s
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
+// resident echo: out <- i as soon as in >= i, for i = 1 .. n
+__global__ void probe_echo(const unsigned* in, unsigned* out, unsigned n, unsigned* err) {
+  extern __shared__ __attribute__((aligned(16))) char smem_probe[];
+  if (threadIdx.x != 0) return;
+  for (unsigned i = 1; i <= n; ++i) {
+    const unsigned long long t0 = wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 200000000ull) { atomicExch(err, 2u); ok = false; break; }
+    }
+    if (!ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(out, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// mode 0: potrf256 loop on E workgroups asking for lds_bytes of LDS (160 KB: a CU each), `load` bulk updates
+//         (16384^2 x 1024 lower, fp64) queued on the side stream first; out[0..3] = median / min / max / mean us per
+//         factorisation, out[4] = ms the load took
+// mode 1: n = reps flag round trips stream -> resident kernel -> stream; out[0] = us per round trip
+extern "C" int g3x_probe(g3_ctx* ctx, int mode, int E, int lds_bytes, int reps, int load, double* out) {
+  g3_dev_guard _dg(ctx);
+  const int64_t NL = 16384, KL = 1024;
+  double *C = nullptr, *P = nullptr;
+  hipEvent_t e0, e1, l0, l1;
+  G3_HIP(hipEventCreate(&e0)); G3_HIP(hipEventCreate(&e1)); G3_HIP(hipEventCreate(&l0)); G3_HIP(hipEventCreate(&l1));
+  if (load > 0) {
+    G3_HIP(hipMalloc(&C, NL * NL * 8));
+    G3_HIP(hipMalloc(&P, NL * KL * 8));
+    G3_HIP(hipMemset(C, 0, NL * NL * 8));
+    G3_HIP(hipMemset(P, 0, NL * KL * 8));
+  }
+  hipStream_t sS;
+  G3_HIP(hipStreamCreateWithFlags(&sS, hipStreamNonBlocking));
+  unsigned* flags;
+  G3_HIP(hipMalloc(&flags, 4096));
+  G3_HIP(hipMemset(flags, 0, 4096));
+  G3_HIP(hipMemset(ctx->d_info, 0, sizeof(int)));
+  G3_HIP(hipDeviceSynchronize());
+  auto start_load = [&]() -> int {
+    hipStream_t sA = ctx->stream;
+    ctx->stream = ctx->side_stream;
+    G3_HIP(hipEventRecord(l0, ctx->side_stream));
+    int rc = 0;
+    for (int i = 0; i < load && !rc; ++i) rc = g3i_gemm_nt(ctx, C, NL, P, KL, P, KL, NL, NL, KL, -1.0, 1.0, G3_F64, 1);
+    G3_HIP(hipEventRecord(l1, ctx->side_stream));
+    ctx->stream = sA;
+    return rc;
+  };
+  int rc = 0;
+  if (mode == 0) {
+    const int64_t ld = 256;
+    std::vector<double> h(256 * 256);
+    for (int i = 0; i < 256; ++i)
+      for (int j = 0; j < 256; ++j) h[i * 256 + j] = (i == j ? 2.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+    double *A0, *A, *W;
+    unsigned long long* ts;
+    G3_HIP(hipMalloc(&A0, 256 * 256 * 8));
+    G3_HIP(hipMalloc(&A, (size_t)E * 256 * 256 * 8));
+    G3_HIP(hipMalloc(&W, (size_t)E * 2 * 128 * 128 * 8));
+    G3_HIP(hipMalloc(&ts, (size_t)E * reps * 16));
+    G3_HIP(hipMemcpy(A0, h.data(), 256 * 256 * 8, hipMemcpyHostToDevice));
+    auto kern = probe_potrf_loop<double>;
+    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds_bytes < (int)sizeof(DiagLds<double>)) lds_bytes = (int)sizeof(DiagLds<double>);
+    // the resident workgroups first (they need empty CUs), then the load
+    hipLaunchKernelGGL(kern, dim3(E), dim3(512), lds_bytes, sS, A, A0, ld, W, ctx->d_info, reps, ts);
+    G3_LAUNCH_CHECK();
+    rc = start_load();
+    G3_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> t((size_t)E * reps * 2);
+    G3_HIP(hipMemcpy(t.data(), ts, t.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> us;
+    for (int b = 0; b < E; ++b)
+      for (int r = 2; r < reps; ++r) us.push_back((double)(t[((size_t)b * reps + r) * 2 + 1] - t[((size_t)b * reps + r) * 2]) * 0.01);
+    std::sort(us.begin(), us.end());
+    double mean = 0;
+    for (double u : us) mean += u;
+    out[0] = us[us.size() / 2]; out[1] = us.front(); out[2] = us.back(); out[3] = mean / us.size();
+    float ms = 0;
+    if (load > 0) G3_HIP(hipEventElapsedTime(&ms, l0, l1));
+    out[4] = ms;
+    out[5] = (double)(t[((size_t)0 * reps + reps - 1) * 2 + 1] - t[0]) * 0.01;   // span of workgroup 0's loop, us
+    int info = 0;
+    G3_HIP(hipMemcpy(&info, ctx->d_info, 4, hipMemcpyDeviceToHost));
+    out[6] = info;
+    (void)hipFree(A0); (void)hipFree(A); (void)hipFree(W); (void)hipFree(ts);
+  } else {
+    auto kern = probe_echo;
+    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    unsigned* fin = flags, *fout = flags + 64, *err = flags + 128;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds_bytes, sS, fin, fout, (unsigned)reps, err);
+    G3_LAUNCH_CHECK();
+    rc = start_load();
+    G3_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 1; i <= reps; ++i) {
+      hipLaunchKernelGGL(probe_post, dim3(1), dim3(64), 0, ctx->stream, fin, (unsigned)i);
+      hipLaunchKernelGGL(probe_wait, dim3(1), dim3(64), 0, ctx->stream, fout, (unsigned)i, err);
+    }
+    G3_HIP(hipEventRecord(e1, ctx->stream));
+    G3_HIP(hipDeviceSynchronize());
+    float ms = 0;
+    G3_HIP(hipEventElapsedTime(&ms, e0, e1));
+    out[0] = ms * 1000.0 / reps;
+    unsigned herr = 0;
+    G3_HIP(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    out[1] = herr;
+    float lms = 0;
+    if (load > 0) G3_HIP(hipEventElapsedTime(&lms, l0, l1));
+    out[4] = lms;
+  }
+  (void)hipStreamDestroy(sS);
+  (void)hipFree(flags);
+  if (C) (void)hipFree(C);
+  if (P) (void)hipFree(P);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(l0); (void)hipEventDestroy(l1);
+  return rc;
+}
+#endif
