@@ -26,6 +26,16 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   // measured, a bulk stream WITHOUT the low priority costs 2 % (N = 8192) to 10 % (N = 32768) of the step
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
+  // chain server (g3_potrf.hip): the chain of a sweep on resident workgroups.  OFF unless G3_CHAIN=1: what it gains
+  // (the 512-block chain step 0.45 -> 0.24 ms in-sweep, N <= 8192 4 ... 15 % faster) depends on which compute pipe the
+  // hardware queues of its streams land on, which HIP gives no control over -- an unlucky placement costs 2x (DESIGN.md
+  // section 4).  The knobs are read ONCE here: G3_CHAIN_WGS workgroups of a server launch, G3_CHAIN_LDS bytes of LDS each
+  // asks for, G3_CHAIN_MIN_N / G3_CHAIN_MAX_N the matrices it is used for.
+  // (its streams and control block are created at the first chain sweep, g3_potrf.hip)
+  ctx->chain_wgs = g3h_env_int("G3_CHAIN", 0) ? g3h_env_int("G3_CHAIN_WGS", 16) : 0;
+  ctx->chain_lds = g3h_env_int("G3_CHAIN_LDS", 0);
+  ctx->chain_min_n = g3h_env_int("G3_CHAIN_MIN_N", 0);
+  ctx->chain_max_n = g3h_env_int("G3_CHAIN_MAX_N", 10240);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, G3_MAX_BATCH * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, G3_PROG_SLOTS * sizeof(g3_kernel_prog));
@@ -70,6 +80,14 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
     for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
     free(ctx->la_ev);
   }
+  for (hipStream_t* st : {&ctx->chain_stream, &ctx->chain_stream2, &ctx->chain_sA, &ctx->chain_sB})
+    if (*st) {
+      (void)hipStreamSynchronize(*st);
+      (void)hipStreamDestroy(*st);
+    }
+  for (hipEvent_t* ev : {&ctx->chain_ev, &ctx->chain_ev2, &ctx->chain_ev3})
+    if (*ev) (void)hipEventDestroy(*ev);
+  if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -611,6 +629,10 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     G3_HIP(hipStreamSynchronize(ctx->stream));
     *info = *ctx->h_info;
+    if (g3i_chain_gave_up(ctx, *info)) {   // (cannot happen twice: the server is off after the first time)
+      snprintf(ctx->err, sizeof(ctx->err), "chain server gave up inside a jitter retry");
+      return G3_ERR_HIP;
+    }
     return G3_OK;
   };
   // scalars of the evaluation: log-determinant, quadratic form, guards (and mean / sum of squares per query)
@@ -645,6 +667,19 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     rc = finish();
     if (rc) return rc;
     info = (int)st4[4];
+    if (g3i_chain_gave_up(ctx, info)) {
+      // the resident chain workgroups ran into their wall-clock limit (they are off from now on): this evaluation is
+      // redone with the launch-per-kernel sweep
+      rc = g3i_reset_info(ctx);
+      if (!rc) rc = build();
+      if (rc) return rc;
+      const int pr2 = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)N * N * N / 3.0 + (double)N * N * (1 + M));
+      rc = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, E);
+      g3i_prof_end(ctx, pr2);
+      if (!rc) rc = finish();
+      if (rc) return rc;
+      info = (int)st4[4];
+    }
   }
   double tries = 0, fallback = 0;
   const int info0 = info;

@@ -22,6 +22,15 @@ struct g3_ctx {
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
   bool adopted;            // stream belongs to the caller
   bool bulk_role;          // this context's stream carries bulk updates beside another context's chain (multi-GPU driver)
+  // chain server (g3_potrf.hip): the critical-path chain of a sweep on resident workgroups
+  unsigned* chain_ctl;     // device: counters and per-panel flags of the running server
+  hipStream_t chain_sA, chain_sB;            // the chain sweep's own chain / bulk streams (created with the two below)
+  hipStream_t chain_stream, chain_stream2;   // streams of the server's two kernels (diagonal workgroup, workers)
+  hipEvent_t chain_ev, chain_ev2, chain_ev3; // bracket of the caller's stream, end of the two server kernels
+  int chain_wgs;           // workgroups of the server (< 2: off)
+  int chain_lds;           // LDS bytes a server workgroup asks for (0: what it needs)
+  int64_t chain_min_n, chain_max_n;   // matrices the server is used for
+  bool chain_broken;       // a server gave up (wall-clock limit): launches per kernel from then on
   // batch mode (g3_gp_factor_batched): every MFMA GEMM and diagonal-block launch of a sweep acts on
   // `batch` matrices at once (grid.y); operands inside the block-inverse buffer [bw_base, +bw_bytes)
   // are `bstride_w` elements apart, everything else `bstride` elements
@@ -114,6 +123,11 @@ static inline int64_t g3_bstride_of(const g3_ctx* ctx, const void* p) {
   return (ctx->bw_base && c >= ctx->bw_base && c < ctx->bw_base + ctx->bw_bytes) ? ctx->bstride_w : ctx->bstride;
 }
 
+// launches issued now go to a low-priority bulk stream (classic sweep: side_stream; chain sweep: chain_sB)
+static inline bool g3_on_bulk_stream(const g3_ctx* ctx) {
+  return ctx->stream == ctx->side_stream || (ctx->chain_sB && ctx->stream == ctx->chain_sB);
+}
+
 static inline size_t g3_esize(g3_dtype dt) { return dt == G3_F64 ? 8 : 4; }
 static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
@@ -143,6 +157,9 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
                  int64_t ldb, g3_dtype dt, const void* invd);
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd);
 int g3i_reset_info(g3_ctx* ctx);
+// true when `info` says the chain server gave up: it is switched off for this context (one line on stderr)
+bool g3i_chain_gave_up(g3_ctx* ctx, int info);
+#define G3_INFO_CHAIN 0x40000000   // pivot-flag value: the chain server gave up (never a pivot index)
 int g3i_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value);
 // A[0:rows, 0:cols) *= factor (stream-ordered)
 int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_dtype dt, double factor);
