@@ -210,6 +210,20 @@ def usable_cores():
     return n
 
 
+def cpu_default_n(N):
+    """size of the default CPU-baseline pass: the whole workload when it fits the host's free memory (N x N fp64 plus
+    a few row tiles and the LAPACK copies: ~3.5 matrices) and the default run's time budget (N <= 32768), else 16384"""
+    if N > 32768:
+        return 16384
+    try:
+        import psutil
+        free = psutil.virtual_memory().available
+    except Exception:
+        free = 0
+    need = 3.5 * 8.0 * N * N
+    return N if (N <= 16384 or free >= max(need, 48e9 if N > 16384 else 0)) else 16384
+
+
 def cpu_baseline(N, d, M, seed, n_cpu):
     """the CPU oracle (NumPy/SciPy restatement: same LAPACK entry points as the reference) on a bounded
     sample of the workload, with the BLAS pool sized to the cores this job may use"""
@@ -231,11 +245,13 @@ def cpu_baseline(N, d, M, seed, n_cpu):
         dt = time.perf_counter() - t0
     threads = max(blas) if blas else cores
     scale = (float(N) / n_cpu) ** 3
+    what = 'one pass of the WHOLE workload' if n_cpu >= N else 'one pass of the same workload cut to N=%d' % n_cpu
     return dict(value=step_flops(n_cpu, M) / dt / 1e12, unit='TFLOP/s', cores=int(min(threads, cores)), kind='port',
-                sample='one pass of the same workload cut to N=%d (d=%d, M=%d, same generator and seed), '
-                       'oracle.cpu_hot_path: NumPy Gram + scipy dpotrf + solve_triangular; BLAS threads %s, '
-                       'host reports %d CPUs, cgroup/affinity allows %d'
-                       % (n_cpu, d, M, blas, os.cpu_count() or 0, cores),
+                sample='%s (N=%d, d=%d, M=%d, same generator and seed), '
+                       'oracle.cpu_hot_path: NumPy Gram + scipy dpotrf (tensors.py:198; above N=16384 as a sweep over 8192-wide '
+                       'panels of dpotrf / dtrsm / dgemm: one call over the 8.6 GB matrix segfaults in this OpenBLAS) + '
+                       'solve_triangular; BLAS threads %s, host reports %d CPUs, cgroup/affinity allows %d'
+                       % (what, n_cpu, d, M, blas, os.cpu_count() or 0, cores),
                 seconds=dt, potrf_gflops=(n_cpu ** 3 / 3.0) / tm['potrf'] / 1e9, phases_sec=tm,
                 full_size_seconds_extrapolated=dt * scale if n_cpu < N else dt,
                 extrapolation='N^3 from the sample (flagged: not measured)' if n_cpu < N else None), lp
@@ -252,7 +268,7 @@ def main():
     ap.add_argument('--kernel', default='se', choices=['se', 'mat52cos'],
                     help='se: BASELINE configs 2/4; mat52cos: MAT52 + periodic COS sum kernel (config 3)')
     ap.add_argument('--f32', action='store_true', help='float32 arithmetic (config 5 runs in fp32)')
-    ap.add_argument('--cpu-n', type=int, default=16384, help='N of the bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-n', type=int, default=-1, help='N of the CPU-baseline pass (0 = skip; default: the whole workload up to N=32768 -- about 75 s on 16 cores -- or a 16384 sample when the host has less than 48 GB free)')
     ap.add_argument('--skip-events', dest='no_prof', action='store_true', help='do not record HIP events in the timed region')
     ap.add_argument('--measure-traffic', dest='measure_traffic', action='store_true', default=None,
                     help='measure roofline.traffic now: two rocprofv3 --pmc child passes of this workload (~10 s).  Default: on for '
@@ -266,7 +282,7 @@ def main():
     ap.add_argument('--api', action='store_true', default=None, help='also time GaussianProcess.logp + predict through the public API '
                                                                      'from host NumPy inputs ("api_ms"; default: on for the one-GPU run)')
     ap.add_argument('--no-api', dest='api', action='store_false')
-    ap.add_argument('--panel', dest='nb', type=int, default=0, help='row-block height of the multi-GPU distribution (0 = 1024 up to 4 GPUs, 512 beyond)')
+    ap.add_argument('--panel', dest='nb', type=int, default=0, help='row-block height of the multi-GPU distribution (0 = 1024)')
     args = ap.parse_args()
 
     if args.api is None:
@@ -386,6 +402,25 @@ def main():
     Xt, Xst, dt_ = tens(X), tens(Xs), tens(delta[None, :])
     Xd, Xsd, dd = wrap(Xt, N, d), wrap(Xst, M, d), wrap(dt_, 1, N)
 
+    # several ranks: a step -- or the driver's own start-up handshake -- that never returns (a collective one rank did not
+    # enter) must not hold the node until the launcher's limit: every rank carries a watchdog from BEFORE the driver is
+    # built to the end of its run and leaves with a line that says so
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get('G3_BENCH_WATCHDOG_S', '900'))
+
+        def _expired():
+            sys.stderr.write('bench.py: rank %d made no progress for %.0f s (a collective some rank never entered?); '
+                             'G3_DIST_DRIVER=python selects the torch.distributed driver\n' % (rank, limit))
+            if rank == 0:
+                print(json.dumps({'metric': 'GP logp+predict end-to-end', 'value': None, 'n_gpus': world,
+                                  'error': 'watchdog: no progress for %.0f s' % limit}), flush=True)
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(limit, _expired)
+        watchdog.daemon = True
+        watchdog.start()
     # G3_FORCE_DIST=1: run the multi-GPU driver with one rank (development: its overhead over the in-library sweep)
     use_dist = world > 1 or os.environ.get('G3_FORCE_DIST', '0') == '1'
     if not use_dist:
@@ -431,8 +466,9 @@ def main():
     else:
         from g3py_amd.distributed import DistributedGP, NativeDistributedGP
         if args.nb <= 0:
-            args.nb = 1024 if world <= 4 else 512
+            args.nb = 1024      # measured (replay transport, profiles/r04_replay_*): 1024-row blocks are faster than 512 at every P for configs 4 and 5
         dgp = None
+        driver_fallback = None       # reason when the native driver was asked for and could not be used
         if driver == 'native':
             why = ''
             try:
@@ -448,6 +484,7 @@ def main():
                     dgp.close()
                     dgp = None
                 driver = 'python (native driver unavailable%s)' % ((': ' + why) if why else ' on another rank')
+                driver_fallback = why or 'the native driver could not be created on another rank'
                 if rank == 0:
                     print('bench.py: falling back to the torch.distributed driver -- ' + driver, file=sys.stderr)
         if dgp is None:
@@ -471,24 +508,6 @@ def main():
             % (world, args.nb, ('RCCL' if (native_transport == 'rccl' if native else backend == 'nccl') else 'gloo, host-staged: rehearsal'),
                'libg3hip g3_dist_* (C++ loop, library-owned communicators)' if native else 'torch.distributed (' + str(driver) + ')')
 
-    # several ranks: a step that never returns (a collective one rank did not enter) must not hold the node until the
-    # launcher's limit -- every rank carries a watchdog over its whole run and leaves with a line that says so
-    watchdog = None
-    if world > 1:
-        import threading
-        limit = float(os.environ.get('G3_BENCH_WATCHDOG_S', '900'))
-
-        def _expired():
-            sys.stderr.write('bench.py: rank %d made no progress for %.0f s (a collective some rank never entered?); '
-                             'G3_DIST_DRIVER=python selects the torch.distributed driver\n' % (rank, limit))
-            if rank == 0:
-                print(json.dumps({'metric': 'GP logp+predict end-to-end', 'value': None, 'n_gpus': world,
-                                  'error': 'watchdog: no progress for %.0f s' % limit}), flush=True)
-            sys.stderr.flush()
-            os._exit(3)
-        watchdog = threading.Timer(limit, _expired)
-        watchdog.daemon = True
-        watchdog.start()
     with _StdoutToStderr():             # (the first collective of a communicator prints RCCL's banner)
         for _ in range(args.warmup):
             step()
@@ -503,8 +522,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_s = []
     for _ in range(args.steps):
-        step()
+        ts0 = time.perf_counter()
+        step()                   # (ends with a host synchronisation: the scalars of the evaluation come back)
+        step_s.append(time.perf_counter() - ts0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -517,9 +539,9 @@ def main():
             for f_ in ('count', 'ms', 'work'):
                 prof[k_][f_] += pb[k_][f_]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed] + step_s, dtype=torch.float64, device=tdev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the slowest rank, for the whole region and step by step
+        elapsed, step_s = float(t[0].item()), [float(v) for v in t[1:]]
     comm_all = None
     if use_dist:
         # per-rank collective counts, bytes over the fabric (sent + received) and host seconds spent waiting
@@ -559,16 +581,21 @@ def main():
     failed = None
     if rank == 0:
         sec = elapsed / args.steps
+        sec_med = float(np.median(step_s)) if step_s else sec     # median of the timed steps
         flops = step_flops(N, M, S)
         out = {
             'metric': 'GP logp+predict end-to-end (Gram+Cholesky+solves), N=%d %s: algorithmic TFLOP/s' % (N, 'fp32' if args.f32 else 'fp64'),
-            'value': flops / sec / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'value': flops / sec_med / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'ms_per_step_median': sec_med * 1e3,
+            'value_mean': flops / sec / 1e12,
+            'value_note': 'value = algorithmic flops / MEDIAN step time (SURVEY.md 8d); ms_per_step = whole timed region / steps '
+                          '(the mean), value_mean the figure that goes with it',
+            'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32' if args.f32 else 'f64', 'data': 'synthetic',
             'config': {'workload': args.kernel.upper() + '-kernel GaussianProcess, N=%d d=%d, M=%d test points: Gram + blocked '
                                    'Cholesky + L^-1 y (logp) + cross-Gram + %d-rhs trsm + posterior mean/variance'
                                    % (N, d, M, M), 'N': N, 'd': d, 'M': M, 'parallelism': parallelism},
-            'e2e_sec': sec, 'logp': float(result['logp']),
+            'e2e_sec': sec_med, 'logp': float(result['logp']),
         }
         if comm_all is not None:
             def per(v):
@@ -578,6 +605,9 @@ def main():
                 else:
                     o['host_wait_s_per_step'] = v['wait_s'] / args.steps
                 return o
+            if driver_fallback:
+                # a downgrade is never silent: it is in the line, and the run fails unless it was allowed explicitly
+                out['driver_fallback'] = driver_fallback
             out['comm'] = {'per_rank': [{k: per(v) for k, v in r.items()} for r in comm_all],
                            'driver': 'native' if native else 'python', 'collectives_forced_at_world_1': bool(solo_pg or (native and world == 1)),
                            'transport': ('rccl (library-owned communicators)' if native_transport == 'rccl' else 'host callbacks over gloo (rehearsal)') if native else backend,
@@ -659,6 +689,8 @@ def main():
                             'grad_natural': [float(v) for v in slots],
                             'note': 'K^-1 (2N^3/3 flops) + alpha + one pass over K^-1 for the kernel-parameter sums; '
                                     'after the timed region, not part of value'}
+        if args.cpu_n < 0:
+            args.cpu_n = cpu_default_n(N)
         if world == 1 and args.cpu_n > 0:
             cb, lp_cpu = cpu_baseline(N, d, M, seed, min(args.cpu_n, N))
             out['cpu_baseline'] = cb
@@ -699,6 +731,9 @@ def main():
         if args.api and world == 1 and not use_dist and S == 0:
             out['api_ms'] = _api_timing(g3, X, y, Xs, d, args.kernel, npdt)
         print(json.dumps(out), flush=True)
+        if out.get('driver_fallback') and os.environ.get('G3_DIST_ALLOW_FALLBACK', '0') != '1':
+            failed = ('bench.py: the native multi-GPU driver was not used (%s); the line above was measured with the '
+                      'torch.distributed driver -- set G3_DIST_ALLOW_FALLBACK=1 to accept that' % out['driver_fallback'])
         if ref is not None and not out['logp_rel_err'] <= tol:
             failed = 'bench.py: logp %.12f differs from the oracle pin %.12f by more than %g relative' % (out['logp'], ref, tol)
     # every rank learns the verdict BEFORE the group is torn down, so a failed pin ends all ranks at once

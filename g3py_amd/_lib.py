@@ -124,6 +124,9 @@ _SIGS = {
     'g3_dist_gp_dlogp': ([_P, C.POINTER(KernelProg), C.POINTER(GradMap), _P, _I64, C.c_double, C.POINTER(C.c_double),
                           C.POINTER(C.c_double)], C.c_int),
     'g3_dist_comm_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
+    'g3_dist_phase_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
+    'g3_dist_set_keep': ([_P, C.c_int], C.c_int),
+    'g3_dist_create_replay': ([_P, _P, C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
     'g3_dist_prof_enable': ([_P, C.c_int], C.c_int),
     'g3_dist_prof_collect': ([_P, C.POINTER(C.c_double)], C.c_int),
     'g3_dist_local_rows': ([_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)], C.c_int),

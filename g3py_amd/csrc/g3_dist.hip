@@ -35,7 +35,7 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------- transports
-enum { G3_COLL_BCAST = 0, G3_COLL_ALLGATHER = 1, G3_COLL_ALLREDUCE = 2, G3_NCOLL = 3 };
+enum { G3_COLL_BCAST = 0, G3_COLL_ALLGATHER = 1, G3_COLL_ALLREDUCE = 2, G3_NCOLL = 3, G3_PH_DIAG = 3, G3_PH_SOLVE = 4, G3_NKIND = 5 };
 
 struct Transport {
   virtual ~Transport() {}
@@ -45,8 +45,11 @@ struct Transport {
   // host values in / out; synchronises s.  op: 0 sum, 1 min, 2 max
   virtual int allreduce(double* host, int n, int op, hipStream_t s) = 0;
   virtual const char* name() const = 0;
+  // what the NEXT collective carries (G3_HINT_*, index of the block / panel): only the replay transport needs to know
+  virtual void hint(int what, int index) { (void)what; (void)index; }
   char err[256] = {0};
 };
+enum { G3_HINT_NONE = 0, G3_HINT_DIAG = 1, G3_HINT_PANEL = 2, G3_HINT_AVEC = 3 };
 
 struct RcclApi {
   void* h = nullptr;
@@ -65,10 +68,13 @@ static RcclApi* rccl_api(char* err, size_t errlen) {
   if (state == 1) return &api;
   if (state == -1) return nullptr;
   // a copy already loaded into the process (e.g. the one PyTorch ships) is reused; G3_RCCL_PATH overrides
-  const char* names[] = {getenv("G3_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  const char* forced = getenv("G3_RCCL_PATH");
+  const bool only = forced && *forced;          // a path given explicitly is the ONLY candidate: a wrong one fails loudly
+  const char* names[] = {forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (int pass = 0; pass < 2 && !api.h; ++pass)
     for (const char* n : names) {
       if (!n || !*n) continue;
+      if (only && n != forced) break;
       api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (api.h) break;
     }
@@ -175,6 +181,10 @@ struct g3_dist {
   char* avec = nullptr;         // 1 x Np: a = L^-1 delta, broadcast for the mean
   char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss
   int* info_dev = nullptr;
+  double phase_calls[2] = {0, 0}, phase_ms[2] = {0, 0};   // as of the last g3_dist_comm_stats
+  bool keep = false;            // g3_dist_set_keep: every block's inverses are kept (the reference of a replay)
+  char* wstore = nullptr;       // Np x 128: block inverses of all diagonal blocks, in block order
+  // phases timed with the collectives' event machinery: 3 = a diagonal block's update + factorisation, 4 = a panel solve
   // gradient mode (g3_dist_set_grad): N / P more right-hand-side rows -- the identity, which the sweep turns into the
   // rank's rows of L^-T -- and the rank's rows of K^-1 = L^-T L^-1
   bool grad = false, have_inv = false;
@@ -184,7 +194,7 @@ struct g3_dist {
   char* agath = nullptr;        // world x cmax_all x nb: gathered alpha pieces
   std::vector<hipEvent_t> ev;   // B_k events + stream joins
   // accounting: per collective kind calls, bytes (sent + received by this rank), device milliseconds
-  double n_calls[G3_NCOLL] = {0, 0, 0}, n_bytes[G3_NCOLL] = {0, 0, 0};
+  double n_calls[G3_NKIND] = {0, 0, 0, 0, 0}, n_bytes[G3_NKIND] = {0, 0, 0, 0, 0};
   std::vector<hipEvent_t> tev;  // timing event pairs
   std::vector<int> tkind;
   size_t tused = 0;
@@ -193,6 +203,28 @@ struct g3_dist {
   int last_info = 0, last_tries = 0, last_fallback = 0;
   char err[512] = {0};
 };
+
+namespace {
+// ---- replay transport: ONE rank of a P-rank evaluation, alone on the GPU.  The reference is a world-1 driver that has
+// just evaluated the same problem with the same block height and kept its block inverses (g3_dist_set_keep): its local
+// matrix is the whole factor.  Every collective becomes a device-to-device copy of exactly the bytes this rank would
+// receive -- the diagonal factor it does not own, the other ranks' blocks of a panel, a = L^-1 delta -- and the scalar
+// all-reduces return the rank's own contribution.  What this times is everything except the fabric.
+struct ReplayTransport : Transport {
+  g3_dist* self = nullptr;
+  const g3_dist* ref = nullptr;
+  int what = G3_HINT_NONE, index = -1;
+  void hint(int w, int i) override { what = w; index = i; }
+  int fail(const char* m) { snprintf(err, sizeof(err), "%s", m); return G3_ERR_HIP; }
+  int bcast(void* buf, size_t bytes, int root, hipStream_t s) override;
+  int allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override;
+  int allreduce(double* host, int n, int op, hipStream_t s) override {
+    (void)host; (void)n; (void)op;                   // the rank's own contribution stays as it is
+    return hipStreamSynchronize(s) == hipSuccess ? G3_OK : G3_ERR_HIP;
+  }
+  const char* name() const override { return "replay"; }
+};
+}  // namespace
 
 #define G3D_HIP(call)                                                                              \
   do {                                                                                             \
@@ -222,6 +254,79 @@ static inline char* Aat(const g3_dist* D, int64_t row, int64_t col) { return D->
 static inline char* Lof(const g3_dist* D, int k) { return D->dbuf[k % 2]; }
 static inline char* Wof(const g3_dist* D, int k) { return D->dbuf[k % 2] + (size_t)D->nb * D->nb * D->es; }
 static inline size_t dbuf_bytes(const g3_dist* D) { return ((size_t)D->nb * D->nb + (size_t)D->nb * 128) * D->es; }
+
+// all blocks of a panel that other ranks would send, in ONE launch (a hipMemcpy2DAsync per 2 MB block costs ~20 us each:
+// 70 ms per evaluation at nb = 512, which would be the replay's own artefact, not the schedule's)
+struct ReplayPanelTab {
+  int nblk;                       // blocks k+1 .. of the panel
+  int slot[G3_RASTER_MAX + 96];   // destination slot in the rank-major gather buffer, -1: this rank's own (not copied)
+};
+__global__ void replay_panel_kernel(char* __restrict__ recv, const char* __restrict__ src0, size_t src_ld_bytes, size_t row_bytes,
+                                    int nb, const ReplayPanelTab tab) {
+  const int b = blockIdx.x;
+  const int slot = tab.slot[b];
+  if (slot < 0) return;
+  const char* src = src0 + (size_t)b * nb * src_ld_bytes;
+  char* dst = recv + (size_t)slot * nb * row_bytes;
+  for (int r = blockIdx.y; r < nb; r += gridDim.y) {
+    const uint4* sp = reinterpret_cast<const uint4*>(src + (size_t)r * src_ld_bytes);
+    uint4* dp = reinterpret_cast<uint4*>(dst + (size_t)r * row_bytes);
+    for (size_t c = threadIdx.x; c < row_bytes / 16; c += blockDim.x) dp[c] = sp[c];
+  }
+}
+
+int ReplayTransport::bcast(void* buf, size_t bytes, int root, hipStream_t s) {
+  const g3_dist* D = self;
+  if (root == D->rank) return G3_OK;
+  const size_t es = D->es;
+  if (what == G3_HINT_DIAG) {
+    if (index < 0 || index >= D->nblk || bytes != dbuf_bytes(D)) return fail("replay: bad diagonal-factor broadcast");
+    // L_jj (nb x nb, leading dimension nb) out of the reference's full factor, then its nb x 128 block inverses
+    const char* src = ref->A + ((size_t)index * D->nb * ref->Np + (size_t)index * D->nb) * es;
+    if (hipMemcpy2DAsync(buf, (size_t)D->nb * es, src, (size_t)ref->Np * es, (size_t)D->nb * es, (size_t)D->nb, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return fail("replay: copy of a diagonal factor failed");
+    if (hipMemcpyAsync((char*)buf + (size_t)D->nb * D->nb * es, ref->wstore + (size_t)index * D->nb * 128 * es, (size_t)D->nb * 128 * es,
+                       hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return fail("replay: copy of the block inverses failed");
+    return G3_OK;
+  }
+  if (what == G3_HINT_AVEC) {
+    // a = L^-1 delta: row 0 of the reference's right-hand-side chunk 0
+    if (hipMemcpyAsync(buf, ref->A + (size_t)ref->rows_mat * ref->Np * es, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return fail("replay: copy of a failed");
+    return G3_OK;
+  }
+  return fail("replay transport: this broadcast is not part of g3_dist_gp_factor_predict");
+}
+
+int ReplayTransport::allgather(const void* send, void* recv, size_t bytes, hipStream_t s) {
+  const g3_dist* D = self;
+  if (what != G3_HINT_PANEL || index < 0 || index >= D->nblk - 1)
+    return fail("replay transport: this all-gather is not part of g3_dist_gp_factor_predict");
+  const int k = index;
+  const size_t es = D->es, blk = (size_t)D->nb * D->nb * es;
+  std::vector<int32_t> idx;
+  const int cnt = g3h_gather_table(D->world, k + 1, D->nblk - 1, &idx);
+  if ((size_t)cnt * blk != bytes) return fail("replay: panel all-gather of an unexpected size");
+  // this rank's own slots, as the collective would place them
+  if (hipMemcpyAsync((char*)recv + (size_t)D->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return fail("replay: local copy failed");
+  // the other ranks' blocks of panel k: block (I, k) of the reference factor, all in one launch
+  const int nbk = D->nblk - 1 - k;
+  for (int b0 = 0; b0 < nbk; b0 += G3_RASTER_MAX + 96) {
+    ReplayPanelTab tab;
+    tab.nblk = nbk - b0 < G3_RASTER_MAX + 96 ? nbk - b0 : G3_RASTER_MAX + 96;
+    for (int b = 0; b < tab.nblk; ++b) {
+      const int I = k + 1 + b0 + b;
+      tab.slot[b] = g3h_owner_of(D->world, I) == D->rank ? -1 : idx[I - k - 1];
+    }
+    const char* src0 = ref->A + ((size_t)(k + 1 + b0) * D->nb * ref->Np + (size_t)k * D->nb) * es;
+    hipLaunchKernelGGL(replay_panel_kernel, dim3((unsigned)tab.nblk, 32), dim3(256), 0, s, (char*)recv, src0, (size_t)ref->Np * es,
+                       (size_t)D->nb * es, (int)D->nb, tab);
+    if (hipGetLastError() != hipSuccess) return fail("replay: panel copy launch failed");
+  }
+  return G3_OK;
+}
 
 static const size_t G3D_MAX_TIMED = 16384;   // event pairs kept between two g3_dist_comm_stats calls; beyond that only counts
 static int coll_begin(g3_dist* D, int kind, hipStream_t s, double bytes) {
@@ -256,15 +361,17 @@ static int coll_end(g3_dist* D, hipStream_t s) {
     }                                                                                       \
   } while (0)
 
-static int do_bcast(g3_dist* D, void* buf, size_t bytes, int root, hipStream_t s) {
+static int do_bcast(g3_dist* D, void* buf, size_t bytes, int root, hipStream_t s, int what = G3_HINT_NONE, int index = -1) {
   int rc = coll_begin(D, G3_COLL_BCAST, s, D->world > 1 ? (double)bytes : 0.0);
   if (rc) return rc;
+  D->tr->hint(what, index);
   G3D_TR(D->tr->bcast(buf, bytes, root, s));
   return coll_end(D, s);
 }
-static int do_allgather(g3_dist* D, const void* sendb, void* recvb, size_t bytes, hipStream_t s) {
+static int do_allgather(g3_dist* D, const void* sendb, void* recvb, size_t bytes, hipStream_t s, int what = G3_HINT_NONE, int index = -1) {
   int rc = coll_begin(D, G3_COLL_ALLGATHER, s, 2.0 * (D->world - 1) * (double)bytes);
   if (rc) return rc;
+  D->tr->hint(what, index);
   G3D_TR(D->tr->allgather(sendb, recvb, bytes, s));
   return coll_end(D, s);
 }
@@ -378,12 +485,38 @@ extern "C" int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb
   return G3_OK;
 }
 
+extern "C" int g3_dist_set_keep(g3_dist* D, int on) {
+  if (!D) return -1;
+  D->keep = on != 0;
+  D->planned = false;          // the store of the block inverses is part of the plan: re-plan
+  return G3_OK;
+}
+
+extern "C" int g3_dist_create_replay(g3_ctx* ctx, g3_dist* reference, int rank, int world, g3_dist** out) {
+  if (!ctx) return -1;
+  if (!reference || reference->world != 1 || !reference->keep || !reference->wstore || !reference->planned) return -2;
+  if (world < 1 || rank < 0 || rank >= world) return -3;
+  if (!out) return -5;
+  *out = nullptr;
+  g3_dist* D = nullptr;
+  int rc = dist_common(ctx, rank, world, &D);
+  if (rc) return rc;
+  ReplayTransport* t = new (std::nothrow) ReplayTransport();
+  if (!t) { g3_dist_destroy(D); return G3_ERR_NOMEM; }
+  t->self = D;
+  t->ref = reference;
+  D->tr = t;
+  *out = D;
+  return G3_OK;
+}
+
 static void free_plan(g3_dist* D) {
   void* bufs[] = {D->A, D->dbuf[0], D->dbuf[1], D->send[0], D->send[1], D->gath[0], D->gath[1], D->gath[2], D->avec, D->dots,
-                  D->Kinv, D->alpha_dev, D->agath};
+                  D->Kinv, D->alpha_dev, D->agath, D->wstore};
   for (void* b : bufs) if (b) (void)hipFree(b);
   D->A = D->dbuf[0] = D->dbuf[1] = D->send[0] = D->send[1] = D->gath[0] = D->gath[1] = D->gath[2] = D->avec = D->dots = nullptr;
   D->Kinv = D->alpha_dev = D->agath = nullptr;
+  D->wstore = nullptr;
   D->have_inv = false;
   for (hipEvent_t e : D->ev) (void)hipEventDestroy(e);
   D->ev.clear();
@@ -454,10 +587,17 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   for (int i = 0; i < 3; ++i) G3D_HIP(hipMalloc((void**)&D->gath[i], (size_t)D->world * D->cmax * nb * nb * D->es));
   G3D_HIP(hipMalloc((void**)&D->avec, (size_t)D->Np * D->es));
   G3D_HIP(hipMalloc((void**)&D->dots, 2 * 128 * D->es));
+  if (D->keep) G3D_HIP(hipMalloc((void**)&D->wstore, (size_t)D->Np * 128 * D->es));
   if (D->grad) {
     G3D_HIP(hipMalloc((void**)&D->Kinv, (size_t)(D->rows_mat ? D->rows_mat : 1) * D->Np * D->es));
     G3D_HIP(hipMalloc((void**)&D->alpha_dev, (size_t)D->Np * D->es));
     G3D_HIP(hipMalloc((void**)&D->agath, (size_t)D->world * D->cmax_all * nb * D->es));
+  }
+  if (ReplayTransport* rt = dynamic_cast<ReplayTransport*>(D->tr)) {
+    if (rt->ref->Np != D->Np || rt->ref->nb != D->nb || rt->ref->dt != D->dt || rt->ref->M != D->M || D->grad) {
+      snprintf(D->err, sizeof(D->err), "replay: the plan must repeat the reference's (N, M, nb, dtype) and gradient mode is not replayed");
+      return -6;
+    }
   }
   D->ev.resize(D->nblk + 5);
   for (auto& e : D->ev) G3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -535,6 +675,9 @@ static int factor_block(g3_dist* D, g3_ctx* cx, int k) {
   G3D_RC(cx, g3_copy2d(cx, Lof(D, k), D->nb, Dk, D->Np, D->nb, D->nb, D->dt));
   G3D_RC(cx, g3_potrf_nowait(cx, Lof(D, k), D->nb, D->nb, D->dt, Wof(D, k), D->info_dev));
   G3D_RC(cx, g3_copy2d(cx, Dk, D->Np, Lof(D, k), D->nb, D->nb, D->nb, D->dt));
+  if (D->keep && D->wstore)
+    G3D_HIP(hipMemcpyAsync(D->wstore + (size_t)k * D->nb * 128 * D->es, Wof(D, k), (size_t)D->nb * 128 * D->es, hipMemcpyDeviceToDevice,
+                           cx->stream));
   return G3_OK;
 }
 
@@ -554,7 +697,13 @@ static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const int64_t nb = D->nb, c0 = (int64_t)k * nb;
   const int64_t r_lo = rows_done(D, k);
   const int64_t m = D->rows_mat + D->rows_rhs - r_lo + inv_active(D, k);
-  if (m > 0) G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), m, D->Np, D->dt, Wof(D, k)));
+  if (m > 0) {
+    int rcp = coll_begin(D, G3_PH_SOLVE, D->ctx->stream, 0.0);
+    if (rcp) return rcp;
+    G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), m, D->Np, D->dt, Wof(D, k)));
+    rcp = coll_end(D, D->ctx->stream);
+    if (rcp) return rcp;
+  }
   // the look-ahead of block k+1 needs these rows, not the gathered panel: it starts while the all-gather is in flight
   G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
   if (D->nblk - 1 - k <= 0) return G3_OK;
@@ -562,7 +711,7 @@ static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const int cnt = perm_of(D, k, &idx);
   const int64_t mine = D->rows_mat - r_lo;
   if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, D->send[k % 2], nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
-  return do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * D->es, D->ctx->stream);
+  return do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * D->es, D->ctx->stream, G3_HINT_PANEL, k);
 }
 
 // diagonal block j on the look-ahead stream: its owner applies the update with panel j-1 from its own panel rows
@@ -579,11 +728,15 @@ static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_solved, 
     if (after) G3D_HIP(hipStreamWaitEvent(D->s_look, after, 0));
     const int64_t lo = D->loff[j];
     char* Pn = Aat(D, lo, (int64_t)(j - 1) * nb);
+    rc = coll_begin(D, G3_PH_DIAG, D->s_look, 0.0);
+    if (rc) return rc;
     G3D_RC(D->ctx_look, g3_gemm_nt(D->ctx_look, Aat(D, lo, (int64_t)j * nb), D->Np, Pn, D->Np, Pn, D->Np, nb, nb, nb, -1.0, 1.0, D->dt, 1));
     rc = factor_block(D, D->ctx_look, j);
     if (rc) return rc;
+    rc = coll_end(D, D->s_look);
+    if (rc) return rc;
   }
-  rc = do_bcast(D, D->dbuf[j % 2], dbuf_bytes(D), owner_of(D, j), D->s_look);
+  rc = do_bcast(D, D->dbuf[j % 2], dbuf_bytes(D), owner_of(D, j), D->s_look, G3_HINT_DIAG, j);
   if (rc) return rc;
   G3D_HIP(hipEventRecord(joined, D->s_look));
   return G3_OK;
@@ -619,10 +772,12 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
   if (rc) return rc;
   G3D_HIP(hipMemsetAsync(D->info_dev, 0, sizeof(int), sA));
   if (owner_of(D, 0) == D->rank) {
-    rc = factor_block(D, D->ctx, 0);
+    rc = coll_begin(D, G3_PH_DIAG, sA, 0.0);
+    if (!rc) rc = factor_block(D, D->ctx, 0);
+    if (!rc) rc = coll_end(D, sA);
     if (rc) return rc;
   }
-  rc = do_bcast(D, D->dbuf[0], dbuf_bytes(D), owner_of(D, 0), sA);
+  rc = do_bcast(D, D->dbuf[0], dbuf_bytes(D), owner_of(D, 0), sA, G3_HINT_DIAG, 0);
   if (rc) return rc;
   rc = solve_and_gather(D, 0, ev_sv);
   if (rc) return rc;
@@ -794,7 +949,7 @@ static int stats(g3_dist* D, double* logdet, double* quad, double* mean, double*
   // a = L^-1 delta is row 0 of right-hand-side chunk 0 (rank 0 holds it); everyone needs it for V a
   const int own0 = 0 % D->world;
   if (D->rank == own0) G3D_HIP(hipMemcpyAsync(D->avec, Aat(D, D->rows_mat, 0), (size_t)Np * D->es, hipMemcpyDeviceToDevice, D->ctx->stream));
-  int rc = do_bcast(D, D->avec, (size_t)Np * D->es, own0, D->ctx->stream);
+  int rc = do_bcast(D, D->avec, (size_t)Np * D->es, own0, D->ctx->stream, G3_HINT_AVEC, 0);
   if (rc) return rc;
   if (D->rank == own0) {     // a^T a in double on the host (Np <= a few 10^5 values)
     std::vector<char> ha((size_t)Np * D->es);
@@ -1159,7 +1314,7 @@ extern "C" int g3_dist_comm_stats(g3_dist* D, double out_host[9]) {
   G3D_HIP(hipStreamSynchronize(D->ctx->stream));
   G3D_HIP(hipStreamSynchronize(D->s_look));
   G3D_HIP(hipStreamSynchronize(D->s_bulk));
-  double ms[G3_NCOLL] = {0, 0, 0};
+  double ms[G3_NKIND] = {0, 0, 0, 0, 0};
   for (size_t i = 0; i + 1 < D->tused; i += 2) {
     float t = 0;
     if (hipEventElapsedTime(&t, D->tev[i], D->tev[i + 1]) == hipSuccess) ms[D->tkind[i / 2]] += t;
@@ -1168,14 +1323,29 @@ extern "C" int g3_dist_comm_stats(g3_dist* D, double out_host[9]) {
     out_host[3 * k] = D->n_calls[k];
     out_host[3 * k + 1] = D->n_bytes[k];
     out_host[3 * k + 2] = ms[k];
-    D->n_calls[k] = D->n_bytes[k] = 0;
   }
+  // the two timed phases of the chain, read by g3_dist_phase_stats (same reset point)
+  for (int k = 0; k < 2; ++k) {
+    D->phase_calls[k] = D->n_calls[G3_PH_DIAG + k];
+    D->phase_ms[k] = ms[G3_PH_DIAG + k];
+  }
+  for (int k = 0; k < G3_NKIND; ++k) D->n_calls[k] = D->n_bytes[k] = 0;
   D->tused = 0;
   return G3_OK;
 }
 
 // HIP-event profiling of the bulk stream's MFMA GEMM launches (the staircase updates: where the flops of a rank
 // are), same tags and output layout as g3_prof_collect
+extern "C" int g3_dist_phase_stats(g3_dist* D, double out_host[4]) {
+  if (!D) return -1;
+  if (!out_host) return -2;
+  out_host[0] = D->phase_calls[0];   // diagonal blocks this rank updated + factored on its look-ahead stream
+  out_host[1] = D->phase_ms[0];      // ... and the device time of that (gemm + factorisation + copies), summed
+  out_host[2] = D->phase_calls[1];   // panel solves of this rank's rows
+  out_host[3] = D->phase_ms[1];
+  return G3_OK;
+}
+
 extern "C" int g3_dist_prof_enable(g3_dist* D, int on) {
   if (!D) return -1;
   int rc = g3_prof_enable(D->ctx_bulk, on);

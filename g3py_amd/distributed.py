@@ -730,7 +730,7 @@ class NativeDistributedGP:
     transport='callbacks' (tests only): the collectives are served by `dist` through host staging, so several ranks
     can share ONE GPU -- RCCL refuses that -- and the library's schedule is checked for world > 1 on a one-GPU box."""
 
-    def __init__(self, dev, dist, rank, world, N, d, M, nb=512, dtype=np.float64, transport='rccl'):
+    def __init__(self, dev, dist, rank, world, N, d, M, nb=512, dtype=np.float64, transport='rccl', reference=None, keep=False):
         import ctypes as C
         from . import _lib
         from .device import compile_spec
@@ -745,30 +745,60 @@ class NativeDistributedGP:
         self.h = C.c_void_p()
         lib = dev.lib
         if transport == 'rccl':
-            ids = [None]
-            if rank == 0:
-                bufs = []
-                for _ in range(2):
-                    b = C.create_string_buffer(_lib.G3_DIST_ID_BYTES)
-                    rc = lib.g3_dist_unique_id(b)
-                    if rc:
-                        raise _lib.G3Error('g3_dist_unique_id failed (%d): is librccl available? (G3_RCCL_PATH)' % rc)
-                    bufs.append(bytes(b.raw))
-                ids = [bufs]
+            # Collective-safe start-up: EVERY rank probes the library (g3_dist_unique_id loads librccl and makes an id; only
+            # rank 0's ids are used), the ranks exchange what they found, and either all go on or all raise the same error --
+            # a rank that cannot load RCCL must never leave its peers inside a broadcast or inside ncclCommInitRank.
+            bufs, why = [], ''
+            for _ in range(2):
+                b = C.create_string_buffer(_lib.G3_DIST_ID_BYTES)
+                rc = lib.g3_dist_unique_id(b)
+                if rc:
+                    why = 'g3_dist_unique_id failed (%d) on rank %d: is librccl available? (G3_RCCL_PATH)' % (rc, rank)
+                    break
+                bufs.append(bytes(b.raw))
+            votes = [why]
+            if world > 1:
+                votes = [None] * world
+                dist.all_gather_object(votes, why)
+            bad = [w for w in votes if w]
+            if bad:
+                raise _lib.G3Error('native multi-GPU driver unavailable on %d of %d ranks: %s' % (len(bad), world, bad[0]))
+            ids = [bufs if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(ids, src=0)
             a, b = ids[0]
             rc = lib.g3_dist_create(dev.ctx, a, b, rank, world, C.byref(self.h))
-            if rc:
-                raise _lib.G3Error('g3_dist_create failed (%d): %s' % (rc, (lib.g3_last_error(dev.ctx) or b'').decode()))
+            msg = ('g3_dist_create failed (%d) on rank %d: %s' % (rc, rank, (lib.g3_last_error(dev.ctx) or b'').decode())) if rc else ''
+            outcome = [msg]
+            if world > 1:
+                outcome = [None] * world
+                dist.all_gather_object(outcome, msg)
+            bad = [w for w in outcome if w]
+            if bad:                                    # every rank leaves together, with its communicators released
+                if not rc and self.h:
+                    lib.g3_dist_destroy(self.h)
+                    self.h = C.c_void_p()
+                raise _lib.G3Error(bad[0])
         elif transport == 'callbacks':
             self._cb = self._make_callbacks()
             rc = lib.g3_dist_create_callbacks(dev.ctx, C.byref(self._cb), rank, world, C.byref(self.h))
             if rc:
                 raise _lib.G3Error('g3_dist_create_callbacks failed (%d)' % rc)
+        elif transport == 'replay':
+            # measurement: this object plays rank `rank` of a `world`-rank evaluation alone on the GPU; `reference` is a
+            # world-1 NativeDistributedGP created with keep=True that has evaluated the same problem (g3hip.h)
+            if reference is None or not reference.h:
+                raise ValueError('the replay transport needs the reference driver')
+            self._reference = reference                    # (must outlive this object)
+            rc = lib.g3_dist_create_replay(dev.ctx, reference.h, rank, world, C.byref(self.h))
+            if rc:
+                raise _lib.G3Error('g3_dist_create_replay failed (%d): the reference must be a planned world-1 driver with '
+                                   'keep=True' % rc)
         else:
             raise ValueError(transport)
         self.transport = transport
+        if keep:
+            self._chk(lib.g3_dist_set_keep(self.h, 1), 'g3_dist_set_keep')
         self._chk(lib.g3_dist_plan(self.h, N, d, M, self.nb, self._dt), 'g3_dist_plan')
 
     def _chk(self, rc, what):
@@ -819,6 +849,7 @@ class NativeDistributedGP:
         def allreduce(user, vals, n, op):
             try:
                 a = np.ctypeslib.as_array(vals, shape=(n,))
+                self.last_allreduce_in = a.copy()      # this rank's own contribution (tests compare it with a replay)
                 t = torch.from_numpy(a.copy())
                 if world > 1:
                     dist.all_reduce(t, op=[dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX][op])
@@ -919,6 +950,13 @@ class NativeDistributedGP:
         self._chk(self.dev.lib.g3_dist_comm_stats(self.h, out), 'g3_dist_comm_stats')
         return {k: {'calls': out[3 * i], 'bytes': out[3 * i + 1], 'device_ms': out[3 * i + 2]}
                 for i, k in enumerate(('bcast', 'allgather', 'allreduce'))}
+
+    def phase_stats(self):
+        """as of the last comm_stats(): diagonal blocks this rank updated + factored and the device milliseconds of
+        that, panel solves of its rows and their device milliseconds"""
+        out = (self._C.c_double * 4)()
+        self._chk(self.dev.lib.g3_dist_phase_stats(self.h, out), 'g3_dist_phase_stats')
+        return {'diag': {'calls': out[0], 'device_ms': out[1]}, 'solve': {'calls': out[2], 'device_ms': out[3]}}
 
     def prof_enable(self, on=2):
         """HIP events around the MFMA GEMM launches of the driver's bulk stream (its staircase updates)"""

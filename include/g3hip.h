@@ -387,6 +387,18 @@ typedef struct {
   int (*allreduce)(void* user, double* vals_host, int n, int op /* 0 sum, 1 min, 2 max */);
 } g3_dist_callbacks;
 int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb, int rank, int world, g3_dist** out);
+/* Replay transport (measurement): ONE rank of a `world`-rank evaluation, alone on one GPU.  `reference` is a world-1
+ * driver (either transport) for which g3_dist_set_keep(reference, 1) was called BEFORE g3_dist_plan and which has since
+ * evaluated the same problem: its local matrix is the whole factor, its block inverses were kept.  In the replayed
+ * rank every collective is a device-to-device copy of exactly the bytes that rank would receive (the diagonal factors it
+ * does not own, the other ranks' blocks of every panel, a = L^-1 delta) and the scalar all-reduces return the rank's own
+ * contribution: g3_dist_gp_factor_predict then times everything of a P-rank evaluation except the fabric, and returns
+ * this rank's share of the log-determinant, of a^T a and of the posterior means / sums of squares.  The plan must repeat
+ * the reference's (N, M, nb, dtype); gradient mode, the posterior covariance and the jitter schedule are not replayed;
+ * the reference must outlive the replay object.  There is nothing of this in the reference package (it has no
+ * multi-device code, stochastic.py:773-783); it exists because a one-GPU box cannot run RCCL with P > 1. */
+int g3_dist_set_keep(g3_dist* D, int on);
+int g3_dist_create_replay(g3_ctx* ctx, g3_dist* reference, int rank, int world, g3_dist** out);
 int g3_dist_destroy(g3_dist* D);
 const char* g3_dist_last_error(g3_dist* D);
 /* Problem shape: N observations in d columns, M test points, nb-row blocks (multiple of 128).  Allocates the
@@ -429,6 +441,10 @@ int g3_dist_gp_dlogp(g3_dist* D, const g3_kernel_prog* prog, const g3_grad_map* 
 /* out_host[3k .. 3k+2] for k = 0 broadcast, 1 all-gather, 2 all-reduce: calls, bytes sent + received by this rank,
  * device milliseconds inside the collective calls (HIP events on the stream each ran on).  Resets the counters. */
 int g3_dist_comm_stats(g3_dist* D, double out_host[9]);
+/* As of the last g3_dist_comm_stats: out_host = [diagonal blocks this rank updated and factored (its turns on the
+ * critical chain, tensors.py:198 per block), device ms of those (update + factorisation + copies); panel solves of its
+ * rows, device ms of those] -- HIP events on the streams they ran on. */
+int g3_dist_phase_stats(g3_dist* D, double out_host[4]);
 /* g3_prof_enable / g3_prof_collect for the driver's bulk stream (its staircase MFMA-GEMM launches), same layout */
 int g3_dist_prof_enable(g3_dist* D, int on);
 int g3_dist_prof_collect(g3_dist* D, double* out_host /* 3 * G3_PROF_NTAGS */);

@@ -829,14 +829,36 @@ def cpu_hot_path(X, y, Xs, var=1.0, rate=1.0, noise=0.1):
     w = 0.5 * r ** 2
     Xw = X * np.sqrt(w)
     sq = (Xw ** 2).sum(1)
-    K = sq[:, None] + sq[None, :] - 2.0 * Xw.dot(Xw.T)
-    np.maximum(K, 0.0, out=K)
-    np.exp(-K, out=K)
-    K *= var
+    K = np.empty((N, N))
+    for r0 in range(0, N, 4096):              # row tiles: the same arithmetic without three N x N temporaries
+        r1 = min(N, r0 + 4096)
+        T = sq[r0:r1, None] + sq[None, :] - 2.0 * Xw[r0:r1].dot(Xw.T)
+        np.maximum(T, 0.0, out=T)
+        np.negative(T, out=T)
+        np.exp(T, out=T)
+        T *= var
+        K[r0:r1] = T
     K[np.diag_indices(N)] += noise
     t1 = time.perf_counter()
-    L, info = sp.linalg.lapack.dpotrf(K, lower=True, overwrite_a=True)
-    assert info == 0
+    if N <= 16384:
+        L, info = sp.linalg.lapack.dpotrf(K, lower=True, overwrite_a=True)
+        assert info == 0
+    else:
+        # One dpotrf over an 8.6 GB matrix segfaults in the OpenBLAS of this image (as in oracle/gen_fullsize.py): the
+        # same factorisation as a right-looking sweep over 8192-wide panels with the same LAPACK / BLAS entry points --
+        # dpotrf on the diagonal blocks, dtrsm for the panel, dgemm for the trailing update (lower block rows only)
+        b = 8192
+        for j in range(0, N, b):
+            e = min(N, j + b)
+            Ljj, info = sp.linalg.lapack.dpotrf(K[j:e, j:e], lower=True)
+            assert info == 0, (j, info)
+            K[j:e, j:e] = np.tril(Ljj)
+            if e < N:
+                K[e:, j:e] = sp.linalg.solve_triangular(Ljj, K[e:, j:e].T, lower=True, check_finite=False).T
+                for i in range(e, N, b):
+                    ie = min(N, i + b)
+                    K[i:ie, e:ie] -= K[i:ie, j:e] @ K[e:ie, j:e].T
+        L = K                                              # lower triangle valid (the solves below reference only that)
     t2 = time.perf_counter()
     a = sp.linalg.solve_triangular(L, y, lower=True, check_finite=False)
     logp = -0.5 * N * np.log(2 * np.pi) - 0.5 * a.dot(a) - np.sum(np.log(np.diag(L)))

@@ -403,3 +403,54 @@ def native_multi_worker(rank, world, port, cases, out_path):
             np.savez(out_path, **res)
     finally:
         dist.destroy_process_group()
+
+
+def handshake_worker(rank, world, port, bad_ranks, out_dir):
+    """start-up handshake of the native driver with librccl unavailable on `bad_ranks`: every rank must raise the SAME
+    collective error and stay in step with its peers (no GPU needed: the probe fails before any HIP call)"""
+    import torch.distributed as dist
+    import types
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if rank in bad_ranks:
+        os.environ['G3_RCCL_PATH'] = '/nonexistent/librccl.so'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from g3py_amd import _lib
+    from g3py_amd.distributed import NativeDistributedGP
+    dev = types.SimpleNamespace(lib=_lib.load(), ctx=None)
+    msg = ''
+    try:
+        NativeDistributedGP(dev, dist, rank, world, 256, 2, 8, nb=128)
+    except _lib.G3Error as e:
+        msg = str(e)
+    # the ranks are still in step: one more collective goes through
+    import torch
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
+        f.write('%s\n%g\n' % (msg, float(t.item())))
+    dist.destroy_process_group()
+
+
+def contrib_worker(rank, world, port, N, d, M, nb, out_dir):
+    """one rank of a world-rank evaluation over the callback transport (gloo, one GPU): writes the rank's OWN
+    contribution to the closing all-reduce -- [log-det part, a^T a part, mean parts (M), sum-of-squares parts (M)]"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        from g3py_amd.distributed import NativeDistributedGP
+        from oracle import g3_oracle as orc
+        X, y, Xs = synth(N, d, M, 77)
+        spec_f = ('SE', 1.0, np.ones(d), None)
+        dev = g3.Device(0)
+        dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, transport='callbacks')
+        lp = dgp.step(orc.with_noise(spec_f, 0.1), spec_f, dev.upload(X), dev.upload(Xs), dev.upload(y))
+        assert dgp.last_allreduce_in.shape == (2 + 2 * M,)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), contrib=dgp.last_allreduce_in, logp=lp, mean=dgp.last['mean'], ss=dgp.last['ss'])
+        dgp.close()
+    finally:
+        dist.destroy_process_group()

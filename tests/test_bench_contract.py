@@ -24,7 +24,12 @@ def _check_line(j, n_gpus=1):
     sys.path.insert(0, ROOT)
     import bench
     flops = bench.step_flops(N, M, j['config'].get('draws', 0))
-    assert abs(j['value'] - flops / (j['ms_per_step'] * 1e-3) / 1e12) <= 1e-9 * j['value']
+    if 'ms_per_step_median' in j:
+        # round 4: value comes from the MEDIAN step, the mean stays beside it
+        assert abs(j['value'] - flops / (j['ms_per_step_median'] * 1e-3) / 1e12) <= 1e-9 * j['value']
+        assert abs(j['value_mean'] - flops / (j['ms_per_step'] * 1e-3) / 1e12) <= 1e-9 * j['value_mean']
+    else:
+        assert abs(j['value'] - flops / (j['ms_per_step'] * 1e-3) / 1e12) <= 1e-9 * j['value']
     r = j['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
     assert abs(r['frac'] - r['achieved'] / r['peak']) <= 1e-12 and 0 < r['frac'] < 1
@@ -41,6 +46,31 @@ def test_committed_headline_line_keeps_the_contract():
     assert j['config']['N'] == 32768 and j['dtype'] == 'f64' and 'cpu_baseline' in j and 'api_ms' in j
     assert j['logp_rel_err'] <= 1e-8                                # against the full-size oracle pin
     assert j['roofline']['traffic'] > j['roofline']['avg_launch_flops'] / 1e6   # bytes, not GB
+
+
+def _r04_lines():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04_bench*.json')))
+
+
+def test_round4_lines_median_value_roofline_everywhere_and_full_size_cpu_baseline():
+    """(a) the headline line's cpu_baseline is a measured pass of the WHOLE N=32768 workload, (b) every
+    committed line of the round carries `roofline`, (c) `value` comes from the median step with the mean beside it."""
+    files = _r04_lines()
+    names = [os.path.basename(f) for f in files]
+    assert 'r04_bench.json' in names and 'r04_bench_c2.json' in names and 'r04_bench_c3.json' in names and 'r04_bench_c5.json' in names
+    for f in files:
+        j = json.load(open(f))
+        if j.get('n_gpus', 1) != 1 or 'comm' in j:
+            continue                                   # (lines of the multi-GPU driver are checked in test_gpu_distributed)
+        _check_line(j)
+        assert 'ms_per_step_median' in j and 'value_mean' in j, f
+        assert 'roofline' in j and 0 < j['roofline']['frac'] < 1, f
+    j = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench.json')))
+    c = j['cpu_baseline']
+    assert j['config']['N'] == 32768 and 'WHOLE workload' in c['sample'] and 'N=32768' in c['sample']
+    assert c.get('extrapolation') is None and c['seconds'] > 1.0 and c['cores'] >= 1
+    assert abs(c['logp'] - j['logp_ref']) <= 1e-8 * abs(j['logp_ref'])      # the CPU pass reproduces the pin, too
 
 
 def test_step_flops_and_synthetic_inputs_are_what_survey_8d_states():
@@ -82,3 +112,20 @@ def test_one_rank_through_rccl_keeps_stdout_to_the_one_line():
     j = json.loads(lines[0])
     assert j['comm']['driver'] == 'native' and j['comm']['per_rank'][0]['allgather']['calls_per_step'] > 0
     assert j['logp_ref'] is None if 'logp_ref' in j else True
+
+
+@pytest.mark.gpu
+def test_driver_downgrade_is_loud():
+    """VERDICT r3 item 3d / ADVICE r3: when the native multi-GPU driver cannot be created the run says so in the line
+    (`driver_fallback`) and FAILS, unless G3_DIST_ALLOW_FALLBACK=1 accepts the torch.distributed driver"""
+    args = [sys.executable, os.path.join(ROOT, 'bench.py'), '--points', '2048', '--queries', '128', '--steps', '1', '--warmup', '1',
+            '--cpu-n', '0', '--no-measure-traffic', '--no-api']
+    env = dict(os.environ, G3_FORCE_DIST='1', G3_RCCL_PATH='/nonexistent/librccl.so')
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert out.returncode != 0 and len(lines) == 1, (out.returncode, out.stderr[-1500:])
+    j = json.loads(lines[0])
+    assert 'driver_fallback' in j and 'librccl' in j['driver_fallback'] and j['comm']['driver'] == 'python'
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, G3_DIST_ALLOW_FALLBACK='1'))
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert 'driver_fallback' in json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])

@@ -136,3 +136,21 @@ def test_stair_chunks_cover_the_staircase_once(limit):
                 got[rr:rr + rws, c0:c0 + cls] -= A[rr:rr + rws] @ b[:cls].T
                 rr += rws
         np.testing.assert_allclose(got, ref, atol=1e-13)
+
+
+@pytest.mark.parametrize('bad', [(0, 1), (1,), (0,)])
+def test_native_driver_handshake_is_collective_when_rccl_is_missing(tmp_path, bad):
+    """a rank that cannot load librccl (G3_RCCL_PATH=/nonexistent) used to raise BEFORE the id broadcast and
+    leave its peers blocked in it.  Now every rank probes, the ranks exchange the outcome, and all raise the same error --
+    whichever rank is the broken one -- and stay in step (one more all-reduce goes through)."""
+    import torch.multiprocessing as mp
+    from dist_helpers import handshake_worker
+    world = 2
+    mp.spawn(handshake_worker, args=(world, _free_port(), tuple(bad), str(tmp_path)), nprocs=world, join=True)
+    msgs = []
+    for r in range(world):
+        lines = open(str(tmp_path / ('rank%d.txt' % r))).read().split('\n')
+        msgs.append(lines[0])
+        assert float(lines[1]) == 3.0                       # 1 + 2: the closing all-reduce saw both ranks
+    assert msgs[0] and msgs[0] == msgs[1]                   # the same error everywhere
+    assert 'native multi-GPU driver unavailable' in msgs[0] and 'of 2 ranks' in msgs[0]

@@ -435,3 +435,54 @@ def test_capacity_n131072_fp64_single_gpu(dev):
     assert -0.45 * N < lp < -0.25 * N          # per-point log density in line with configs 2 and 4 (-0.40, -0.375)
     for b in (K, W, a):
         b.free()
+
+
+@pytest.mark.parametrize('noise', [1e-4, 1e-6])
+def test_conditioning_at_config2_size(dev, noise):
+    """a BASELINE size with a SMALL noise term.  SE, N=8192, d=4, sigma^2 in {1e-4, 1e-6}: cond(K) reaches
+    1e5 ... 1e7 (lambda_max / sigma^2), and every panel solve goes through explicitly inverted 128 x 128 diagonal blocks
+    (error ~ cond(L_128) eps per block, g3_potrf.hip).  logp at the stated 1e-8 relative; mean / variance at a tolerance
+    derived from the conditioning of the factor LAPACK itself produced: 50 eps (max L_ii / min L_ii)^2 x scale -- both
+    factorisations carry a backward error of a few eps ||K||, which the solves amplify by cond(K) ~ that ratio squared
+    (DESIGN.md section 2)."""
+    from oracle import g3_oracle as orc
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    N, d, M = 8192, 4, 256
+    X, y, Xs = _synth(N, d, M, 1002)
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    lp, st, K, a, Xd = _factor(dev, orc.with_noise(spec_f, noise), X, y)
+    lp_ref, mean_ref, var_ref, _ = orc.cpu_hot_path(X, y, Xs, noise=noise)
+    assert st['info'] == 0 and st['tries'] == 0
+    assert abs(lp - lp_ref) <= 1e-8 * abs(lp_ref), (lp, lp_ref)
+    # conditioning of the factor, from the device factor's own diagonal (it is within 1e-8 of LAPACK's by the logdet)
+    Np, Mp = _lib.roundup(N), _lib.roundup(M, 128)
+    diagL = np.array([dev.download(dev.wrap(K[0].offset(i, i), 1, 1, Np, np.float64), 1, 1)[0, 0] for i in range(0, N, 97)])
+    ratio = float(diagL.max() / min(diagL.min(), np.sqrt(noise)))
+    tol = max(1e-8, 50 * np.finfo(np.float64).eps * ratio ** 2)
+    V, mu, ss = dev.alloc(Mp, Np, np.float64), dev.alloc(1, Mp, np.float64), dev.alloc(1, Mp, np.float64)
+    dev.gp_cross(compile_spec(spec_f, d), dev.upload(Xs), M, Xd, N, d, K[0], K[1], a, V, mu, ss)
+    mean = dev.download(mu, 1, M)[0]
+    var = np.maximum(1.0 - dev.download(ss, 1, M)[0], 0.0)
+    assert np.abs(mean - mean_ref).max() <= tol * max(1.0, np.abs(mean_ref).max()), (np.abs(mean - mean_ref).max(), tol)
+    assert np.abs(var - var_ref).max() <= tol, (np.abs(var - var_ref).max(), tol)
+
+
+def test_jitter_branch_at_config2_size(dev):
+    """the same size with NO noise and every input duplicated: K is singular, CholeskyRobust's jitter schedule
+    (tensors.py:203-213) must rescue it exactly as the oracle's does -- same number of retries, logp at 1e-8 relative"""
+    from oracle import g3_oracle as orc
+    N, d = 8192, 4
+    X, y, _ = _synth(N, d, 8, 1002)
+    X[1::2] = X[0::2]
+    y = np.sin(X.sum(1) / np.sqrt(d))
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    lp, st, *_ = _factor(dev, spec_f, X, y)
+    K = orc.tt_to_cov(orc.tt_to_num(orc.kernel_cov(spec_f, X, None)))
+    L, tries, fallback = orc.cholesky_robust(K, return_info=True)
+    del K
+    import scipy.linalg
+    a = scipy.linalg.solve_triangular(L, y, lower=True, check_finite=False)
+    ref = -0.5 * N * np.log(2 * np.pi) - 0.5 * a.dot(a) - np.sum(np.log(np.diag(L)))
+    assert st['tries'] == tries >= 1 and not fallback and st['fallback'] == 0
+    assert abs(lp - ref) <= 1e-8 * abs(ref), (lp, ref)
