@@ -32,6 +32,11 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   // section 4).  The knobs are read ONCE here: G3_CHAIN_WGS workgroups of a server launch, G3_CHAIN_LDS bytes of LDS each
   // asks for, G3_CHAIN_MIN_N / G3_CHAIN_MAX_N the matrices it is used for.
   // (its streams and control block are created at the first chain sweep, g3_potrf.hip)
+  ctx->tune = g3h_tune_from_env();
+  {
+    const char* lg = getenv("G3_GEMM_LOG");
+    ctx->gemm_log = (lg && *lg) ? fopen(lg, "a") : nullptr;
+  }
   ctx->chain_wgs = g3h_env_int("G3_CHAIN", 0) ? g3h_env_int("G3_CHAIN_WGS", 16) : 0;
   ctx->chain_lds = g3h_env_int("G3_CHAIN_LDS", 0);
   ctx->chain_min_n = g3h_env_int("G3_CHAIN_MIN_N", 0);
@@ -88,6 +93,7 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   for (hipEvent_t* ev : {&ctx->chain_ev, &ctx->chain_ev2, &ctx->chain_ev3})
     if (*ev) (void)hipEventDestroy(*ev);
   if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
+  if (ctx->gemm_log) fclose(ctx->gemm_log);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -816,7 +822,22 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
   if (rc) return rc;
   const unsigned nb = (unsigned)((Np + 255) / 256);
   char* rhs = (char*)K + (size_t)Np * ldk * es;
-  if (dt == G3_F64) {
+  const bool small = Np <= 2 * G3_LB;       // one workgroup per member does the whole evaluation (g3i_small_factor_batched)
+  if (small) {
+    if (dt == G3_F64)
+      hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(batch), dim3(1024), 0, ctx->stream, (double*)K, N, ldk, (double*)nullptr, 1, kstride);
+    else
+      hipLaunchKernelGGL((diag_stats_kernel<float>), dim3(batch), dim3(1024), 0, ctx->stream, (float*)K, N, ldk, (double*)nullptr, 1, kstride);
+    g3i_prof_end(ctx, pr);
+    G3_LAUNCH_CHECK();
+    pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)batch * ((double)N * N * N / 3.0 + (double)N * N));
+    rc = g3i_small_factor_batched(ctx, K, ldk, kstride, invd, wstride, delta, ldd, a, Np, dstats, batch, N, Np, dt);
+    g3i_prof_end(ctx, pr);
+    if (!rc && hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = G3_ERR_HIP;
+    if (!rc) rc = g3i_reset_info(ctx);
+    if (rc) return rc;
+  } else if (dt == G3_F64) {
     hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(batch), dim3(1024), 0, ctx->stream, (double*)K, N, ldk,
                        (double*)nullptr, 1, kstride);
     hipLaunchKernelGGL((pad_row_kernel<double>), dim3(nb, batch), dim3(256), 0, ctx->stream, (double*)rhs, ldk,
@@ -827,6 +848,7 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
     hipLaunchKernelGGL((pad_row_kernel<float>), dim3(nb, batch), dim3(256), 0, ctx->stream, (float*)rhs, ldk,
                        (const float*)delta, N, Np, RB, kstride, ldd);
   }
+  if (!small) {
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   // one sweep factors every member; a member whose pivot fails only stops its own launches
@@ -854,6 +876,7 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
     hipLaunchKernelGGL((logp_terms_kernel<float>), dim3(batch), dim3(1024), 0, ctx->stream, (const float*)K, N, ldk,
                        (const float*)a, dstats, kstride, Np);
   G3_LAUNCH_CHECK();
+  }
   double* hst = (double*)malloc(sbytes);
   if (!hst) return G3_ERR_NOMEM;
   if (hipMemcpyAsync(hst, dstats, sbytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

@@ -748,7 +748,7 @@ static int stair_ptr(g3_dist* D, g3_ctx* cx, char* C, const char* A, const char*
   // C[rows_s, 0 : seg_cols[s]) += alpha * A[rows_s, 0 : nb) G[block table]^T (C and A full-width local rows, ld = Np),
   // cut into launches of at most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
   std::vector<G3hStairChunk> ch;
-  g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch, seg_diag);
+  g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch, seg_diag, D->ctx->tune.stair_max);
   for (const auto& c : ch) {
     G3D_RC(cx, g3_gemm_nt_stair(cx, C + ((size_t)c.row0 * D->Np + c.col0) * D->es, D->Np, A + (size_t)c.row0 * D->Np * D->es, D->Np, G,
                                 D->nb, D->nb, c.rows.data(), c.cols.data(), (int)c.rows.size(), alpha, 1.0, D->dt, D->nb, perm + c.blk0,
@@ -1092,7 +1092,7 @@ static int posterior_cov(g3_dist* D, const g3_kernel_prog* prog, const void* Xs_
   }
   if (!mine.empty()) {
     std::vector<G3hStairChunk> ch;
-    g3h_stair_chunks(sr, sc, pad, nch, &ch, &sd);
+    g3h_stair_chunks(sr, sc, pad, nch, &ch, &sd, D->ctx->tune.stair_max);
     for (const auto& cc : ch)
       G3D_TRY(g3_gemm_nt_stair(D->ctx, rows + ((size_t)cc.row0 * Mp + cc.col0) * es, Mp, sendb + (size_t)cc.row0 * Np * es, Np, Vall, Np, Np,
                                cc.rows.data(), cc.cols.data(), (int)cc.rows.size(), -1.0, 1.0, D->dt, pad, perm.data() + cc.blk0, cc.nblk,

@@ -72,13 +72,8 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     brow = (int64_t)tab.b_blk[sblk] * tab.b_nb + (n0 - sblk * tab.b_nb);
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef G3_EXP_SAMEPANEL   // measurement only: every tile streams the same two panels (perfect L2 hit rate)
-  gemm_tile<T, BM, BN, WM, WN, NSTAGE>(C, ldc, A, lda, B, ldb, K, alpha, beta, m0, n0,
-                                       lower_only, doff, failed, smem);
-#else
   gemm_tile<T, BM, BN, WM, WN, NSTAGE>(C, ldc, A + (int64_t)m0 * lda, lda, B + brow * ldb, ldb, K, alpha, beta, m0, n0,
                                        lower_only, doff, failed, smem);
-#endif
 }
 
 // ---- stripe-local triangular solve: X <- X L^-T for a tall panel X (m x n, n <= 1024) in ONE launch.
@@ -110,17 +105,6 @@ trsm_stripe_kernel(T* X, int64_t ldx, const T* L, int64_t ldl, const T* W, const
 }
 
 
-static FILE* gemm_log() {
-  static FILE* f = nullptr;
-  static int tried = 0;
-  if (!tried) {
-    tried = 1;
-    const char* e = getenv("G3_GEMM_LOG");
-    if (e && *e) f = fopen(e, "w");
-  }
-  return f;
-}
-
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                       int64_t ldb, int64_t k, double alpha, double beta, const GemmShape& sh) {
@@ -150,21 +134,14 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
   // The bulk stream has slack wherever the small tile is used.  A/B on one box, N = 4096 ... 32768:
   // -0.3 ... -3.5 % per step (12288: 19.4 -> 18.7 ms), never slower.  G3_SIDE_LDS overrides (0 = off).
   int lds_req = LDS;
-  {
-    static int side_lds = -1;
-    if (side_lds < 0) {
-      const char* e = getenv("G3_SIDE_LDS");
-      side_lds = e ? atoi(e) : 54000;
-    }
-    if (side_lds > LDS && (g3_on_bulk_stream(ctx) || ctx->bulk_role)) lds_req = side_lds;
-  }
+  if (ctx->tune.side_lds > LDS && (g3_on_bulk_stream(ctx) || ctx->bulk_role)) lds_req = ctx->tune.side_lds;
   // algorithmic flops: 2 k per output element that is wanted.  Profiling
   // tag: launches of the 128 x 128 tile with >= 4096 tiles are the bulk panel updates
   // (>= 4096 tiles: the P2b launches, as in rounds 1-2 when nothing smaller used this tile; the column updates that take it
   //  since round 3 -- 1024 .. 4095 tiles -- are tagged MID so that the bulk figure stays comparable)
   const int tag = (BM == 128 && BN == 128) ? (nv >= 4096 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
   const int pr = g3i_prof_begin(ctx, tag, 2.0 * shape_elems(sh) * (double)k);
-  if (FILE* lg = gemm_log())   // G3_GEMM_LOG=<file>: one line per launch, joined with a kernel trace by scripts/launch_table.py
+  if (FILE* lg = ctx->gemm_log)   // G3_GEMM_LOG=<file>: one line per launch, joined with a kernel trace by scripts/launch_table.py
     fprintf(lg, "gemm %d %d %d %lld %lld %lld %d %lld %.9e %d\n", BM, BN, NT / 64, (long long)sh.m, (long long)sh.n, (long long)k, sh.kind,
             nv, 2.0 * shape_elems(sh) * (double)k, g3_on_bulk_stream(ctx) ? 1 : 0);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds_req, ctx->stream, (T*)C, ldc, (const T*)A, lda,
@@ -173,16 +150,6 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
   return G3_OK;
-}
-
-// smallest number of 128 x 128 tiles for which the big tile is chosen (G3_GEMM_BIG_MIN overrides)
-static int64_t big_tile_min() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char* e = getenv("G3_GEMM_BIG_MIN");
-    v = e ? atoll(e) : 4096;
-  }
-  return v;
 }
 
 template <typename T>
@@ -194,29 +161,6 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   bool all128 = sh.m % 128 == 0 && sh.n % 128 == 0;
   if (sh.kind == 2)
     for (int s = 0; s < sh.nseg; ++s) all128 = all128 && sh.seg_rows[s] % 128 == 0 && sh.seg_cols[s] % 128 == 0;
-  static int forced = -1;   // G3_GEMM_CFG: development override of the tile choice
-  if (forced < 0) {
-    const char* e = getenv("G3_GEMM_CFG");
-    forced = e ? atoi(e) : 0;
-  }
-  if (forced == 1 && sh.kind != 2 && sh.m % 256 == 0 && sh.n % 128 == 0)
-    return launch_cfg<T, 256, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 2 && all128)
-    return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 3) return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 5 && all128)    // 8 waves per 128 x 128 tile (64 x 32 each): four waves per SIMD with two tiles per CU
-    return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-#ifdef G3_GEMM_EXPERIMENTS      // measurement build only (scripts/build_variant.sh exp g3_gemm.hip -DG3_GEMM_EXPERIMENTS)
-  if (forced == 6 && all128) return launch_cfg<T, 128, 128, 32, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 7 && sh.kind != 2 && sh.m % 256 == 0 && sh.n % 128 == 0)
-    return launch_cfg<T, 256, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 8 && sh.kind != 2 && sh.m % 128 == 0 && sh.n % 256 == 0)
-    return launch_cfg<T, 128, 256, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  if (forced == 9 && sh.kind != 2 && sh.n % 128 == 0)
-    return launch_cfg<T, 64, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-#endif
-  if (forced == 4 && sh.kind != 2 && sh.n % 128 == 0)
-    return launch_cfg<T, 32, 128, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   // Tile choice (measured on MI355X, scripts/gemm_bench.py):
   //  * in-place panel solves (`wide`, C aliases A, n = 128): thin 32 x 128 tiles always -- one
   //    tile must span the 128 output columns, and 4x more workgroups beat 128 x 128 tiles from
@@ -235,20 +179,13 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   // The 128 x 128 tile runs with EIGHT waves (64 x 32 each, 118 VGPRs) since round 3: two tiles per CU are then
   // four waves per SIMD instead of two, and the matrix pipe finds a ready wave more often -- stand-alone
   // 30720^2 x 1024 lower update 66.3 -> 68.0 TFLOP/s, x 2048: 68.2 -> 69.4, 16384^2 x 512: 60.2 -> 64.4; the
-  // N = 32768 step 208.3 -> 203.3 ms, config 3 33.7 -> 33.4 (profiles/r03_gemm_variants.md).  A retiring
-  // workgroup still leaves room for the fused 256-wide diagonal kernel (2 x 136 <= 512 - 2 x 120 VGPRs per
-  // SIMD).  G3_GEMM_BULK8=0 selects the four-wave tile (64 x 64 per wave) again.
-  static int bulk8 = -1;
-  if (bulk8 < 0) {
-    const char* e = getenv("G3_GEMM_BULK8");
-    bulk8 = e ? atoi(e) : 1;
-  }
-  // the big tile from 4096 tiles on, and from 1024 tiles on when K >= 1024 (round 3, scripts/r3_sweep2.sh: N = 32768
+  // N = 32768 step 208.3 -> 203.3 ms, config 3 33.7 -> 33.4 (profiles/r03_gemm_variants.md; the four-wave tile and
+  // five other shapes that were measured and rejected are in that table, not in the library any more).
+  // The big tile from gemm_big_min tiles on, and from 1024 tiles on when K >= 1024 (round 3, scripts/r3_sweep2.sh: N = 32768
   // 204.0 -> 203.3 ms, config 3 33.54 -> 33.43; at K = 512 -- config 2 -- the small tile stays better: 7.25 vs 7.31 ms)
-  if (all128 && (blocks128 >= big_tile_min() || (blocks128 >= 1024 && k >= 1024 && big_tile_min() == 4096))) {
-    if (bulk8) return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-    return launch_cfg<T, 128, 128, 64, 64, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
-  }
+  const int64_t big_min = ctx->tune.gemm_big_min;
+  if (all128 && (blocks128 >= big_min || (blocks128 >= 1024 && k >= 1024 && big_min == 4096)))
+    return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
 }
 
@@ -297,7 +234,7 @@ static int trsm_stripe_t(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* X, 
   ops.nops = 0;
   trsm_ops_rec(&ops, 0, n);
   const int pr = g3i_prof_begin(ctx, G3_TAG_GEMM_SMALL, (double)m * (double)n * (double)n);
-  if (FILE* lg = gemm_log())
+  if (FILE* lg = ctx->gemm_log)
     fprintf(lg, "trsm %d 128 4 %lld %lld %lld 0 %lld %.9e %d\n", BM, (long long)m, (long long)n, (long long)n, (long long)(m / BM),
             (double)m * (double)n * (double)n, g3_on_bulk_stream(ctx) ? 1 : 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)(m / BM), (unsigned)g3_nbatch(ctx)), dim3(256), LDS, ctx->stream, X, ldx, L, ldl, W,
@@ -316,15 +253,12 @@ int g3i_trsm_stripe(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* X,
   if (ldx % al || ldl % al || (((uintptr_t)X | (uintptr_t)L | (uintptr_t)W) & 15)) return 1;
   // A stripe's workgroup is bound by the share of its CU's matrix pipes it gets beside the bulk workgroups: a
   // short panel (few stripes) is solved in 16-row stripes, twice the workgroups with half the products each.
-  static int64_t thin_max = -1;
-  if (thin_max < 0) { const char* e = getenv("G3_TRSM_THIN_MAX"); thin_max = e ? atoll(e) : 2048; }
+  const int64_t thin_max = ctx->tune.trsm_thin_max;
   const bool thin = m * (int64_t)g3_nbatch(ctx) <= thin_max;
   // a tall panel is bound by the L2 -> LDS traffic of its stripes (every stripe re-reads the triangle): 64-row stripes
   // move 1.7x fewer bytes per flop.  Measured (same box, twice): N = 32768 205.8 -> 204.5 ms, 24576 93.3 -> 92.7; below
   // m ~ 12000 there are too few stripes to fill the chip and 32 rows win (N = 8192: 7.09 -> 7.40 ms with 64).
-  // G3_TRSM_WIDE_MIN: least m for 64-row stripes, 0 = never.
-  static int64_t wide_min = -1;
-  if (wide_min < 0) { const char* e = getenv("G3_TRSM_WIDE_MIN"); wide_min = e ? atoll(e) : 12288; }
+  const int64_t wide_min = ctx->tune.trsm_wide_min;
   if (wide_min > 0 && m >= wide_min && m % 64 == 0 && g3_nbatch(ctx) == 1) {
     if (dt == G3_F64) return trsm_stripe_t<double, 64>(ctx, (const double*)L, n, ldl, (double*)X, m, ldx, (const double*)W);
     return trsm_stripe_t<float, 64>(ctx, (const float*)L, n, ldl, (float*)X, m, ldx, (const float*)W);

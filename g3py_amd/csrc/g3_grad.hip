@@ -47,10 +47,9 @@ int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* in
   const size_t es = g3_esize(dt);
   int64_t NB = ctx->nb_lookahead;
   if (NB <= 0) {
-    const char* e = getenv("G3_NB");
     // the inverse's chain is light (one panel solve per step): wide panels from mid sizes on
     // (measured, dlogp: N=8192 9.4 -> 8.4 ms, 16384 55.7 -> 55.0 ms)
-    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
+    NB = ctx->tune.nb > 0 ? ctx->tune.nb : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
   }
   NB = g3_roundup(NB < G3_LB ? G3_LB : NB, G3_LB);
   const int nblk = (int)((n + NB - 1) / NB);
@@ -819,11 +818,7 @@ int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* ma
     for (int s = 0; s < nslots; ++s) out_host[s] = 0.0;
     return G3_OK;
   }
-  static int generic_only = -1;   // G3_GRAD_GENERIC=1: development switch, always the sum-of-products kernel
-  if (generic_only < 0) {
-    const char* e = getenv("G3_GRAD_GENERIC");
-    generic_only = (e && atoi(e)) ? 1 : 0;
-  }
+  const int generic_only = ctx->tune.grad_interpret;   // G3_GRAD_GENERIC=1 at context creation: always the sum-of-products kernel
   if (!generic_only) {   // var * SE(+ noise) on all columns: register fast path
     bool done = false;
     int r = G3_OK;

@@ -28,36 +28,8 @@ __host__ __device__ __forceinline__ bool leaf_has_trig(int kind) {
 // pieces, degree-13 Taylor polynomial of exp(r) (truncation 4e-18), one v_ldexp_f64; <= 4 ulp, NaN / +-Inf and the
 // subnormal range handled -- and MEASURED it against the library routine (scripts/gram_bench.py, profiles/r03_gram.md):
 // SE d=4 N=32768 1.645 vs 1.599 ms, MAT52+COS d=8 N=16384 0.790 vs 0.766 ms: the device library's exp is already a short
-// branch-free sequence and wins by 2-3 %.  The library routine is used; -DG3_FAST_EXP=1 builds the other one.
-#ifndef G3_FAST_EXP
-#define G3_FAST_EXP 0
-#endif
-__device__ __forceinline__ double g3_exp(double x) {
-#if G3_FAST_EXP
-  double xc = x < -746.0 ? -746.0 : x;        // (comparisons keep a NaN)
-  xc = xc > 746.0 ? 746.0 : xc;
-  const double n = __builtin_rint(xc * 1.44269504088896338700e+00);
-  double r = __builtin_fma(-n, 6.93147180369123816490e-01, xc);
-  r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;          // 1 / 13!
-  p = __builtin_fma(p, r, 2.08767569878681e-09);
-  p = __builtin_fma(p, r, 2.505210838544172e-08);
-  p = __builtin_fma(p, r, 2.755731922398589e-07);
-  p = __builtin_fma(p, r, 2.7557319223985893e-06);
-  p = __builtin_fma(p, r, 2.48015873015873e-05);
-  p = __builtin_fma(p, r, 1.984126984126984e-04);
-  p = __builtin_fma(p, r, 1.3888888888888889e-03);
-  p = __builtin_fma(p, r, 8.333333333333333e-03);
-  p = __builtin_fma(p, r, 4.1666666666666664e-02);
-  p = __builtin_fma(p, r, 1.6666666666666666e-01);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)n);
-#else
-  return exp(x);
-#endif
-}
+// branch-free sequence and wins by 2-3 %.  The library routine is used; the hand-written one was removed in round 4 (its A/B numbers stay in profiles/r03_gram.md).
+__device__ __forceinline__ double g3_exp(double x) { return exp(x); }
 __device__ __forceinline__ float g3_exp(float x) { return exp(x); }
 
 template <typename T>
@@ -481,8 +453,7 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
                   const T* X2, int64_t n2, int64_t ldx2, int d, T* K, int64_t ldk, int64_t n1pad,
                   int64_t n2pad, unsigned flags, int sym) {
   {
-    static int nofast = -1;      // G3_GRAM_NOFAST=1: always interpret (development comparison)
-    if (nofast < 0) { const char* e = getenv("G3_GRAM_NOFAST"); nofast = (e && atoi(e)) ? 1 : 0; }
+    const int nofast = ctx->tune.gram_interpret;      // G3_GRAM_NOFAST=1 at context creation: always interpret (A/B runs)
     int fk, pk;
     SeParams<T, 1> s1; SeParams<T, 2> s2; SeParams<T, 3> s3; SeParams<T, 4> s4; SeParams<T, 8> s8; SeParams<T, 16> s16;
 #define G3_TRY_FAST(DD, SS)                                                                                   \
@@ -500,15 +471,9 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
   if (rc) return rc;
   dim3 grid = gram_grid(n1pad, n2pad, flags);
-  // periodic leaves: per-tile cos / sin tables unless there are too many (LDS) or the caller
-  // asked for the direct formulas (G3_GRAM_DIRECT_TRIG=1)
+  // periodic leaves: per-tile cos / sin tables unless there are too many for the LDS
   int ntrig = prog_trig_pairs(prog);
-  static int direct = -1;
-  if (direct < 0) {
-    const char* e = getenv("G3_GRAM_DIRECT_TRIG");
-    direct = (e && atoi(e)) ? 1 : 0;
-  }
-  if (ntrig > 16 || direct) ntrig = 0;
+  if (ntrig > 16) ntrig = 0;
   const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
   SeParams<T, 1> dummy{};
   hipLaunchKernelGGL((gram_kernel<T, 1, -1, -1>), grid, dim3(256), lds, ctx->stream, dprog, dummy, X1, n1,

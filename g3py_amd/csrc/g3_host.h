@@ -18,15 +18,56 @@ static inline int g3h_env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// Tuning knobs of the library.  They are read from the environment ONCE, when a context is created (g3_ctx_create), and
+// travel with the context: no launch path looks at the environment, so contexts on different threads never race on a
+// lazily initialised static (include/g3hip.h: distinct contexts may run concurrently).  Defaults are what was measured
+// on MI355X; every knob selects another schedule of the SAME arithmetic.
+struct G3hTune {
+  int64_t nb;             // G3_NB          panel width of the look-ahead sweeps (0: by matrix size)
+  int sb;                 // G3_SB          panels per super-panel (1)
+  int nb_tail;            // G3_NB_TAIL     halve the panel width while the remaining size is <= nb_tail x width (10; 0: never)
+  int nb_min;             // G3_NB_MIN      narrowest panel of the taper (128)
+  int nb_head;            // G3_NB_HEAD     leading panels of half / quarter width (-1: one for n <= 16384, else none)
+  int side_lds;           // G3_SIDE_LDS    least LDS a bulk-stream GEMM launch asks for (54000; 0: what it needs)
+  int64_t gemm_big_min;   // G3_GEMM_BIG_MIN  least number of 128 x 128 tiles for the big tile (4096)
+  int64_t trsm_thin_max;  // G3_TRSM_THIN_MAX panel rows up to which the stripe solve uses 16-row stripes (2048)
+  int64_t trsm_wide_min;  // G3_TRSM_WIDE_MIN panel rows from which it uses 64-row stripes (12288; 0: never)
+  int stair_max;          // G3_STAIR_MAX   row segments / B blocks per staircase launch (160; tests lower it)
+  int gram_interpret;     // G3_GRAM_NOFAST   1: always the interpreted Gram kernel (A/B measurements)
+  int grad_interpret;     // G3_GRAD_GENERIC  1: always the interpreted Gram-gradient kernel
+};
+#define G3H_STAIR_MAX 160
+static inline G3hTune g3h_tune_from_env() {
+  G3hTune t;
+  const char* e = getenv("G3_NB");
+  t.nb = e ? atoll(e) : 0;
+  t.sb = g3h_env_int("G3_SB", 1);
+  t.nb_tail = g3h_env_int("G3_NB_TAIL", 10);
+  t.nb_min = g3h_env_int("G3_NB_MIN", 128);
+  t.nb_head = g3h_env_int("G3_NB_HEAD", -1);
+  t.side_lds = g3h_env_int("G3_SIDE_LDS", 54000);
+  e = getenv("G3_GEMM_BIG_MIN");
+  t.gemm_big_min = e ? atoll(e) : 4096;
+  e = getenv("G3_TRSM_THIN_MAX");
+  t.trsm_thin_max = e ? atoll(e) : 2048;
+  e = getenv("G3_TRSM_WIDE_MIN");
+  t.trsm_wide_min = e ? atoll(e) : 12288;
+  const int sm = g3h_env_int("G3_STAIR_MAX", G3H_STAIR_MAX);
+  t.stair_max = sm < 1 ? 1 : (sm > G3H_STAIR_MAX ? G3H_STAIR_MAX : sm);
+  t.gram_interpret = g3h_env_int("G3_GRAM_NOFAST", 0) ? 1 : 0;
+  t.grad_interpret = g3h_env_int("G3_GRAD_GENERIC", 0) ? 1 : 0;
+  return t;
+}
+
 // Panel and super-panel boundaries of the look-ahead sweep over an n x n matrix (n a multiple of 128).
 //   bnd: first column of every panel, then n.  NB-wide panels while the trailing matrix is large, narrower
 //        ones near the end, where the bulk stream runs out of work and the latency of the critical-path chain
 //        (diagonal-block kernels, small GEMMs) is what is left -- narrow panels shorten that chain exactly as
 //        they do for a small stand-alone problem (G3_NB_TAIL=0 keeps NB throughout; G3_NB_MIN the floor)
 //   grp: index of the first panel of every super-panel (G consecutive panels), then the panel count
-static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, std::vector<int64_t>* bnd, std::vector<int>* grp) {
-  const int taper = g3h_env_int("G3_NB_TAIL", 10);   // halve the width while the remaining size is <= taper * width
-  const int wmin = g3h_env_int("G3_NB_MIN", 128);
+static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, const G3hTune& tune, std::vector<int64_t>* bnd, std::vector<int>* grp) {
+  const int taper = tune.nb_tail;   // halve the width while the remaining size is <= taper * width
+  const int wmin = tune.nb_min;
   const int64_t wlo = batch > 1 && wmin < 256 ? 256 : wmin;   // batched sweeps: work per launch matters more
   bnd->clear();
   grp->clear();
@@ -36,7 +77,7 @@ static inline void g3h_panel_bounds(int64_t n, int64_t NB, int G, int batch, std
   // first panel is final, a narrow one gets it started sooner.  Measured (round 3, two A/B rounds on one box): one
   // half-width panel first is worth 1.0 - 1.3 % up to n = 16384 (8192: 7.22 -> 7.14 ms, 16384: 33.0 -> 32.6), nothing at
   // 20480 and costs 0.3 - 0.4 % from 24576 on (its K = NB / 2 bulk update is a slower launch): default 1 up to 16384
-  const int head = g3h_env_int("G3_NB_HEAD", n <= 16384 ? 1 : 0);
+  const int head = tune.nb_head >= 0 ? tune.nb_head : (n <= 16384 ? 1 : 0);
   int64_t r0 = 0;
   int hstep = head;
   while (r0 < n) {
@@ -262,23 +303,18 @@ static inline int g3h_gather_table(int P, int lo, int hi, std::vector<int32_t>* 
 // ---- staircase launches of the multi-GPU sweep.  One launch describes at most G3H_STAIR_MAX row segments and
 // G3H_STAIR_MAX blocks of the B operand (the raster table travels in the kernel arguments, g3_gemm.hip::RasterTab):
 // a longer staircase -- N / nb > 160 row blocks -- is cut into row chunks and column chunks.
-#define G3H_STAIR_MAX 160
 struct G3hStairChunk {
   int64_t row0, col0;              // first row / column of the chunk, relative to the staircase
   std::vector<int64_t> rows, cols; // segment rows / columns inside the chunk
   std::vector<int64_t> diag;       // != 0: the segment's trailing square block inside this chunk is its diagonal block
   int blk0, nblk;                  // blocks of B the chunk multiplies with: [blk0, blk0 + nblk) of the block table
 };
-static inline int g3h_stair_limit() {
-  const int v = g3h_env_int("G3_STAIR_MAX", G3H_STAIR_MAX);   // tests lower it to exercise the chunking
-  return v < 1 ? 1 : (v > G3H_STAIR_MAX ? G3H_STAIR_MAX : v);
-}
 // seg_rows / seg_cols: the staircase (entries multiples of 128; columns multiples of block_rows); nperm: blocks in
 // the B table (columns beyond nperm * block_rows do not exist)
 static inline void g3h_stair_chunks(const std::vector<int64_t>& seg_rows, const std::vector<int64_t>& seg_cols, int64_t block_rows,
-                                    int nperm, std::vector<G3hStairChunk>* out, const std::vector<int64_t>* seg_diag = nullptr) {
+                                    int nperm, std::vector<G3hStairChunk>* out, const std::vector<int64_t>* seg_diag = nullptr,
+                                    int limit = G3H_STAIR_MAX) {
   out->clear();
-  const int limit = g3h_stair_limit();
   const int nseg = (int)seg_rows.size();
   int64_t width = 0;
   for (int s = 0; s < nseg; ++s) width = seg_cols[s] > width ? seg_cols[s] : width;

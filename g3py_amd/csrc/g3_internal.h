@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "g3hip.h"
+#include "g3_host.h"
 
 #define G3_LB 128   // diagonal block factored + inverted by ONE fused kernel; matrices are padded to it
 
@@ -18,6 +19,8 @@ struct g3_ctx {
   hipEvent_t* la_ev;       // look-ahead events (2 per panel)
   int la_nev;
   int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
+  G3hTune tune;            // tuning knobs, read from the environment once at g3_ctx_create
+  FILE* gemm_log;          // G3_GEMM_LOG=<file>: one line per MFMA GEMM / stripe-solve launch (scripts/launch_table.py)
   bool info_clean;         // d_info is known to be zero (left so by the previous evaluation's last kernel)
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
   bool adopted;            // stream belongs to the caller
@@ -157,6 +160,10 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
                  int64_t ldb, g3_dtype dt, const void* invd);
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd);
 int g3i_reset_info(g3_ctx* ctx);
+// batch members of at most 256 padded rows: factor + block inverses + a = L^-1 delta + the four logp scalars, one
+// workgroup per member, one launch (g3_potrf.hip)
+int g3i_small_factor_batched(g3_ctx* ctx, void* K, int64_t ld, int64_t kstride, void* W, int64_t wstride, const void* delta, int64_t ldd,
+                             void* a, int64_t astride, double* dstats, int batch, int64_t n, int64_t np, g3_dtype dt);
 // true when `info` says the chain server gave up: it is switched off for this context (one line on stderr)
 bool g3i_chain_gave_up(g3_ctx* ctx, int info);
 #define G3_INFO_CHAIN 0x40000000   // pivot-flag value: the chain server gave up (never a pivot index)

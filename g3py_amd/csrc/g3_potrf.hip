@@ -13,7 +13,6 @@
 // flat right-looking sweep over panels with one-panel look-ahead on two streams.
 #include "g3_internal.h"
 #include <vector>
-#include <algorithm>
 #include "g3_host.h"
 #include "g3_mfma.h"
 #include "g3_gemm_tile.h"
@@ -58,12 +57,6 @@ __device__ __forceinline__ float fast_rcp(float p) {
 // Two barriers per block step (16 per block) instead of one per column (128), all O(n^3) work on the matrix
 // pipe, and the next diagonal wave is never kept waiting by anything but its own panel tile (see
 // diag128_core).  FACTOR = false: A already holds L, only W is formed.
-#ifndef G3_DIAG16_MFMA
-#define G3_DIAG16_MFMA 1   // fp64: 4 x 4-blocked diagonal tiles on the matrix pipe (0: column sweep)
-#endif
-#ifndef G3_DIAG16_SYM
-#define G3_DIAG16_SYM 1    // fp64 factor path: register-resident symmetric tile routine (0: the LDS round-trip variant)
-#endif
 constexpr int TS = 17;   // LDS tile row stride in elements (16 + 1: conflict-free fragment reads)
 template <typename T>
 struct DiagScratch {};      // fp64: the tile routine works on S.D / S.Wd directly
@@ -464,11 +457,11 @@ __device__ __forceinline__ void diag128_core(typename TileOps<T>::acc_t (&aA)[8]
     if (W == k) {
       G3_TS(64 + 2 * k);
       if (k == 0) TO::store(S.D[par], aA[k], lane);      // (k > 0: handed over in the previous step, below)
-      if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA && FACTOR && G3_DIAG16_SYM)
+      if constexpr (sizeof(T) == 8 && FACTOR)          // fp64 factor + inverse: the register-resident symmetric tile routine
         diag16s((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
-      else if constexpr (sizeof(T) == 8 && G3_DIAG16_MFMA)
+      else if constexpr (sizeof(T) == 8)               // fp64, inverse of an already factored block
         diag16m<FACTOR>((double*)S.D[par], (double*)S.Wd[par], lane, info, row_base + 16 * k);
-      else if constexpr (sizeof(T) == 4 && FACTOR && G3_DIAG16_SYM)
+      else if constexpr (FACTOR)                       // fp32 factor: through the fp64 routine (tensors.py:198,219)
         diag16s_f32((float*)S.D[par], (float*)S.Wd[par], S.x.D, S.x.W, lane, info, row_base + 16 * k);
       else
         diag16<T, FACTOR>(S.D[par], S.Wd[par], lane, info, row_base + 16 * k);
@@ -690,6 +683,128 @@ potrf256_kernel(T* A, int64_t ld, T* W, int* info, int64_t row_base, int64_t a_b
   }
 }
 
+// ---- one WORKGROUP per chain member, N <= 256 (the reference's caller is the Python loop of
+// stochastic.py:515-564 over the rows of a chain, at N = 30 ... 125 in its notebooks).  The batched sweep pushes such a
+// batch through the large-N launch sequence (diagonal kernel, stripe solve of the right-hand-side rows, copies, a
+// reduction kernel: five launches with the batch in grid.y, four passes over HBM); here ONE launch does, per member:
+//   L = chol(K_b) in place (the fused 256-wide factorisation, or the 128-wide one), its block inverses W_b,
+//   a_b = L^-1 delta_b through the inverses (a_0 = W_0 d_0;  a_1 = W_1 (d_1 - L_10 a_0)),
+//   sum log L_ii, a^T a, the counts of non-finite entries -- four doubles per member.
+// The covariance comes from the one batched Gram launch before it (grid.z = batch).
+template <typename T>
+__global__ void __launch_bounds__(512, 4)
+small_factor_kernel(T* K, int64_t ld, int64_t kstride, T* Wall, int64_t wstride, const T* delta, int64_t ldd, T* a_out, int64_t astride,
+                    double* stats, int* info, int n, int np) {
+  const int b = blockIdx.x;
+  info += b;
+  T* A = K + (int64_t)b * kstride;
+  T* W = Wall + (int64_t)b * wstride;
+  __shared__ DiagLds<T> S;
+  __shared__ T vec[2 * G3_LB];        // the right-hand side, then a
+  __shared__ T part[4 * G3_LB];       // partial dot products (4 column quarters x 128 rows)
+  __shared__ double red[4][8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int w = wv < 4 ? wv : 11 - wv;
+  if (np == 2 * G3_LB) {
+    switch (w) {
+      case 0: potrf256_wave<T, 0>(A, ld, W, info, 0, S, lane); break;
+      case 1: potrf256_wave<T, 1>(A, ld, W, info, 0, S, lane); break;
+      case 2: potrf256_wave<T, 2>(A, ld, W, info, 0, S, lane); break;
+      case 3: potrf256_wave<T, 3>(A, ld, W, info, 0, S, lane); break;
+      case 4: potrf256_wave<T, 4>(A, ld, W, info, 0, S, lane); break;
+      case 5: potrf256_wave<T, 5>(A, ld, W, info, 0, S, lane); break;
+      case 6: potrf256_wave<T, 6>(A, ld, W, info, 0, S, lane); break;
+      default: potrf256_wave<T, 7>(A, ld, W, info, 0, S, lane); break;
+    }
+  } else {
+    switch (w) {
+      case 0: diag128_wave<T, true, 0>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      case 1: diag128_wave<T, true, 1>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      case 2: diag128_wave<T, true, 2>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      case 3: diag128_wave<T, true, 3>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      case 4: diag128_wave<T, true, 4>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      case 5: diag128_wave<T, true, 5>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      case 6: diag128_wave<T, true, 6>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+      default: diag128_wave<T, true, 7>(A, ld, W, (int64_t)G3_LB, info, 0, S, lane); break;
+    }
+  }
+  // the factor and the inverses were written by other waves of this workgroup: make them visible to all of it
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < np; i += 512) vec[i] = i < n ? delta[(int64_t)b * ldd + i] : T(0);
+  __syncthreads();
+  // y = M x for a 128 x 128 row-major block M (leading dimension ldm): thread (row r = tid & 127, quarter q = tid >> 7)
+  // takes 32 consecutive columns; the four partial sums of a row are added in a fixed order
+  const int r = tid & (G3_LB - 1), q = tid >> 7;
+  auto matvec = [&](const T* M, int64_t ldm, const T* x) {
+    const T* row = M + (int64_t)r * ldm + 32 * q;
+    T acc = T(0);
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) acc = fma(row[j], x[32 * q + j], acc);
+    part[q * G3_LB + r] = acc;
+    __syncthreads();
+  };
+  matvec(W, G3_LB, vec);                                   // a_0 = W_0 d_0
+  if (tid < G3_LB) vec[tid] = (part[tid] + part[G3_LB + tid]) + (part[2 * G3_LB + tid] + part[3 * G3_LB + tid]);
+  __syncthreads();
+  if (np == 2 * G3_LB) {
+    matvec(A + (int64_t)G3_LB * ld, ld, vec);              // L_10 a_0
+    if (tid < G3_LB)
+      vec[G3_LB + tid] -= (part[tid] + part[G3_LB + tid]) + (part[2 * G3_LB + tid] + part[3 * G3_LB + tid]);
+    __syncthreads();
+    matvec(W + G3_LB * G3_LB, G3_LB, vec + G3_LB);         // a_1 = W_1 (d_1 - L_10 a_0)
+    T a1 = T(0);
+    if (tid < G3_LB) a1 = (part[tid] + part[G3_LB + tid]) + (part[2 * G3_LB + tid] + part[3 * G3_LB + tid]);
+    __syncthreads();
+    if (tid < G3_LB) vec[G3_LB + tid] = a1;
+    __syncthreads();
+  }
+  // a and the four scalars of logp_terms_kernel (g3_api.hip): sum log L_ii, a^T a, #non-finite a, #bad diagonal
+  double ld_sum = 0, ss = 0, nf = 0, bd = 0;
+  for (int i = tid; i < np; i += 512) {
+    const T v = vec[i];
+    a_out[(int64_t)b * astride + i] = v;
+    if (i < n) {
+      const double dg = (double)A[(int64_t)i * ld + i];
+      ld_sum += log(dg);
+      if (!(dg > 0.0) || __builtin_isinf(dg)) bd += 1;
+      const double dv = (double)v;
+      ss += dv * dv;
+      if (dv != dv || __builtin_isinf(dv)) nf += 1;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    ld_sum += __shfl_down(ld_sum, off);
+    ss += __shfl_down(ss, off);
+    nf += __shfl_down(nf, off);
+    bd += __shfl_down(bd, off);
+  }
+  if (lane == 0) { red[0][wv] = ld_sum; red[1][wv] = ss; red[2][wv] = nf; red[3][wv] = bd; }
+  __syncthreads();
+  if (tid < 4) {
+    double t = 0;
+    for (int k = 0; k < 8; ++k) t += red[tid][k];
+    stats[4 * b + tid] = t;
+  }
+}
+
+// the fused small-N evaluation of a batch (np = 128 or 256 padded rows per member); the members' covariances are in K
+int g3i_small_factor_batched(g3_ctx* ctx, void* K, int64_t ld, int64_t kstride, void* W, int64_t wstride, const void* delta, int64_t ldd,
+                             void* a, int64_t astride, double* dstats, int batch, int64_t n, int64_t np, g3_dtype dt) {
+  if (np != G3_LB && np != 2 * G3_LB) return -1;
+  G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * batch, ctx->stream));
+  ctx->info_clean = false;
+  if (dt == G3_F64)
+    hipLaunchKernelGGL((small_factor_kernel<double>), dim3((unsigned)batch), dim3(512), 0, ctx->stream, (double*)K, ld, kstride, (double*)W,
+                       wstride, (const double*)delta, ldd, (double*)a, astride, dstats, ctx->d_info, (int)n, (int)np);
+  else
+    hipLaunchKernelGGL((small_factor_kernel<float>), dim3((unsigned)batch), dim3(512), 0, ctx->stream, (float*)K, ld, kstride, (float*)W,
+                       wstride, (const float*)delta, ldd, (float*)a, astride, dstats, ctx->d_info, (int)n, (int)np);
+  G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
 template <typename T, bool FACTOR>
 __global__ void __launch_bounds__(512)
 diag128m_kernel(T* A, int64_t ld, int64_t a_stride, T* W, int64_t ldw, int64_t w_stride, int* info,
@@ -742,16 +857,10 @@ static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_
 }
 
 // ---- across LB blocks
-static bool stripe_trsm() {     // G3_STRIPE_TRSM=0: the recursive multi-launch solve (development comparison)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("G3_STRIPE_TRSM"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
-
 template <typename T>
 static int trsm_rec(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64_t m, int64_t ldb,
                     const T* W, g3_dtype dt) {
-  if (n > LB && n <= 1024 && stripe_trsm()) {
+  if (n > LB && n <= 1024) {
     // the whole recursion below this point in one launch: a workgroup per 32-row stripe of B
     const int rc = g3i_trsm_stripe(ctx, L, n, ldl, B, m, ldb, W, dt);
     if (rc <= 0) return rc;
@@ -778,16 +887,10 @@ static int potrf_diag256(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base) 
   return G3_OK;
 }
 
-static bool fused256() {       // G3_FUSED256=0: the four-launch recursion (development comparison)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("G3_FUSED256"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
-
 template <typename T>
 static int potrf_rec(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t row_base, g3_dtype dt) {
   if (n == LB) return potrf_diag<T>(ctx, A, ld, W, row_base, dt);
-  if (n == 2 * LB && ctx->fuse256 && fused256()) return potrf_diag256<T>(ctx, A, ld, W, row_base);
+  if (n == 2 * LB && ctx->fuse256) return potrf_diag256<T>(ctx, A, ld, W, row_base);
   const int64_t n1 = split_point(n, LB), n2 = n - n1;
   int rc = potrf_rec<T>(ctx, A, n1, ld, W, row_base, dt);
   if (rc) return rc;
@@ -1190,7 +1293,7 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
   const int64_t R = n + E;   // rows: the square part plus E appended right-hand-side rows
   std::vector<int64_t> bnd;
   std::vector<int> gb;
-  g3h_panel_bounds(n, NB, G, ctx->batch, &bnd, &gb);
+  g3h_panel_bounds(n, NB, G, ctx->batch, ctx->tune, &bnd, &gb);
   const int nblk = (int)bnd.size() - 1, ngrp = (int)gb.size() - 1;
   const int nev = 4 * ngrp + 1;
   if (ctx->la_nev < nev) {
@@ -1287,7 +1390,7 @@ static int potrf_lookahead_chain(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W,
   const int64_t R = n + E;
   std::vector<int64_t> bnd;
   std::vector<int> gb;
-  g3h_panel_bounds(n, NB, 1, ctx->batch, &bnd, &gb);
+  g3h_panel_bounds(n, NB, 1, ctx->batch, ctx->tune, &bnd, &gb);
   const int nblk = (int)bnd.size() - 1;
   const int nev = 2 * nblk + 1;
   if (ctx->la_nev < nev) {
@@ -1441,7 +1544,7 @@ static bool g3i_chain_usable(g3_ctx* ctx, int64_t n, int64_t NB, int G) {
   if (n < ctx->chain_min_n || n > ctx->chain_max_n) return false;
   std::vector<int64_t> bnd;
   std::vector<int> gb;
-  g3h_panel_bounds(n, NB, 1, ctx->batch, &bnd, &gb);
+  g3h_panel_bounds(n, NB, 1, ctx->batch, ctx->tune, &bnd, &gb);
   if ((int)bnd.size() - 1 > CH_MAXP) return false;
   if (!ctx->chain_ctl) {
     // first use: the four streams back to back.  The server's two have a CU mask (all CUs), which gives them a hardware
@@ -1473,15 +1576,14 @@ static bool g3i_chain_usable(g3_ctx* ctx, int64_t n, int64_t NB, int G) {
 
 static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n, int* G) {
   int64_t NB = ctx->nb_lookahead;
-  const char* eg = getenv("G3_SB");          // panels per super-panel (development override)
-  *G = eg ? atoi(eg) : 1;
+  *G = ctx->tune.sb;                 // panels per super-panel
   if (NB <= 0) {
-    const char* e = getenv("G3_NB");
     // measured on MI355X (fp64): narrow panels shorten the latency-bound chain of diagonal-block
     // kernels that dominates small problems, wide panels give the bulk updates more K
-    NB = e ? atoll(e) : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
+    const bool forced = ctx->tune.nb > 0;
+    NB = forced ? ctx->tune.nb : (n <= 4096 ? 128 : (n <= 6144 ? 256 : (n <= 12288 ? 512 : 1024)));
     // a batched sweep is bound by work per launch, not by the chain: wider panels again
-    if (!e && ctx->batch > 1 && NB < 256) NB = 256;
+    if (!forced && ctx->batch > 1 && NB < 256) NB = 256;
   }
   if (*G < 1) *G = 1;
   if (*G > 8) *G = 8;
@@ -1583,10 +1685,8 @@ static int trsm_lookahead(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B,
 int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,
                  int64_t ldb, g3_dtype dt, const void* invd) {
   if (n == 0 || m == 0) return G3_OK;
-  static int la = -1;     // G3_TRSM_LOOKAHEAD=0: the recursion for every shape (development comparison)
-  if (la < 0) { const char* e = getenv("G3_TRSM_LOOKAHEAD"); la = e ? atoi(e) : 1; }
   // few rows against a long factor, outside batch mode and not from inside a two-stream sweep (side stream free)
-  if (la && n >= 4096 && m <= 4096 && ctx->batch <= 1 && !g3_on_bulk_stream(ctx)) {
+  if (n >= 4096 && m <= 4096 && ctx->batch <= 1 && !g3_on_bulk_stream(ctx)) {
     if (dt == G3_F64) return trsm_lookahead<double>(ctx, (const double*)L, n, ldl, (double*)B, m, ldb, (const double*)invd, dt);
     return trsm_lookahead<float>(ctx, (const float*)L, n, ldl, (float*)B, m, ldb, (const float*)invd, dt);
   }
@@ -1849,233 +1949,6 @@ extern "C" int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void
                          tries_host, fallback_host, jitter_host);
 }
 
-#ifdef G3_PROBE
-// ---------------------------------------------------------------------------------------
-// Measurement build only (scripts/build_variant.sh probe g3_potrf.hip -DG3_PROBE): does a workgroup that holds a whole
-// CU (by its LDS request) run the fused 256-wide diagonal kernel at its stand-alone speed while a bulk update streams
-// through the other CUs, and what does a flag round trip between a stream and a resident kernel cost?
-template <typename T>
-__global__ void __launch_bounds__(512) probe_potrf_loop(T* Aall, const T* A0, int64_t ld, T* Wall, int* info, int reps,
-                                                        unsigned long long* ts) {
-  extern __shared__ __attribute__((aligned(16))) char smem_probe[];
-  DiagLds<T>& S = *reinterpret_cast<DiagLds<T>*>(smem_probe);
-  T* A = Aall + (int64_t)blockIdx.x * 256 * ld;
-  T* W = Wall + (int64_t)blockIdx.x * 2 * G3_LB * G3_LB;
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = wv < 4 ? wv : 11 - wv;
-  for (int rep = 0; rep < reps; ++rep) {
-    for (int e = threadIdx.x; e < 256 * 256; e += 512) A[(int64_t)(e >> 8) * ld + (e & 255)] = A0[(int64_t)(e >> 8) * ld + (e & 255)];
-    __threadfence_block();
-    __syncthreads();
-    const unsigned long long t0 = wall_clock64();
-    switch (w) {
-      case 0: potrf256_wave<T, 0>(A, ld, W, info, 0, S, lane); break;
-      case 1: potrf256_wave<T, 1>(A, ld, W, info, 0, S, lane); break;
-      case 2: potrf256_wave<T, 2>(A, ld, W, info, 0, S, lane); break;
-      case 3: potrf256_wave<T, 3>(A, ld, W, info, 0, S, lane); break;
-      case 4: potrf256_wave<T, 4>(A, ld, W, info, 0, S, lane); break;
-      case 5: potrf256_wave<T, 5>(A, ld, W, info, 0, S, lane); break;
-      case 6: potrf256_wave<T, 6>(A, ld, W, info, 0, S, lane); break;
-      default: potrf256_wave<T, 7>(A, ld, W, info, 0, S, lane); break;
-    }
-    __syncthreads();
-    const unsigned long long t1 = wall_clock64();
-    if (threadIdx.x == 0) {
-      ts[((int64_t)blockIdx.x * reps + rep) * 2] = t0;
-      ts[((int64_t)blockIdx.x * reps + rep) * 2 + 1] = t1;
-    }
-  }
-}
-
-__global__ void probe_post(unsigned* flag, unsigned v) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void probe_wait(const unsigned* flag, unsigned v, unsigned* err) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 200000000ull) { atomicExch(err, 1u); break; }   // 2 s
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-// resident echo: out <- i as soon as in >= i, for i = 1 .. n
-__global__ void probe_echo(const unsigned* in, unsigned* out, unsigned n, unsigned* err) {
-  extern __shared__ __attribute__((aligned(16))) char smem_probe[];
-  if (threadIdx.x != 0) return;
-  for (unsigned i = 1; i <= n; ++i) {
-    const unsigned long long t0 = wall_clock64();
-    bool ok = true;
-    while (__hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) {
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > 200000000ull) { atomicExch(err, 2u); ok = false; break; }
-    }
-    if (!ok) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(out, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// modes 2-5: what do resident workgroups cost the bulk updates?  E workgroups of 512 threads run for `reps` x 10 us:
-//   2: lane 0 polls one word (relaxed agent loads, s_sleep 1) -- the waiting state of the chain server
-//   3: as 2, plus an agent-scope ACQUIRE fence every 10 us      4: as 2, plus an agent-scope RELEASE fence every 10 us
-//   5: only s_sleep (no memory traffic at all)
-__global__ void __launch_bounds__(512) probe_resident(const unsigned* word, int mode, int reps, unsigned* sink) {
-  extern __shared__ __attribute__((aligned(16))) char smem_probe[];
-  if (threadIdx.x == 0) {
-    unsigned acc = 0;
-    for (int r = 0; r < reps; ++r) {
-      const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < 1000ull) {
-        if (mode != 5) acc += __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (mode == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (mode == 4) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    }
-    sink[blockIdx.x] = acc;
-  }
-  __syncthreads();
-}
-
-// mode 0: potrf256 loop on E workgroups asking for lds_bytes of LDS (160 KB: a CU each), `load` bulk updates
-//         (16384^2 x 1024 lower, fp64) queued on the side stream first; out[0..3] = median / min / max / mean us per
-//         factorisation, out[4] = ms the load took
-// mode 1: n = reps flag round trips stream -> resident kernel -> stream; out[0] = us per round trip
-extern "C" int g3x_probe(g3_ctx* ctx, int mode, int E, int lds_bytes, int reps, int load, double* out) {
-  g3_dev_guard _dg(ctx);
-  const int64_t NL = 16384, KL = 1024;
-  double *C = nullptr, *P = nullptr;
-  hipEvent_t e0, e1, l0, l1;
-  G3_HIP(hipEventCreate(&e0)); G3_HIP(hipEventCreate(&e1)); G3_HIP(hipEventCreate(&l0)); G3_HIP(hipEventCreate(&l1));
-  if (load > 0) {
-    G3_HIP(hipMalloc(&C, NL * NL * 8));
-    G3_HIP(hipMalloc(&P, NL * KL * 8));
-    G3_HIP(hipMemset(C, 0, NL * NL * 8));
-    G3_HIP(hipMemset(P, 0, NL * KL * 8));
-  }
-  hipStream_t sS;
-  G3_HIP(hipStreamCreateWithFlags(&sS, hipStreamNonBlocking));
-  unsigned* flags;
-  G3_HIP(hipMalloc(&flags, 4096));
-  G3_HIP(hipMemset(flags, 0, 4096));
-  G3_HIP(hipMemset(ctx->d_info, 0, sizeof(int)));
-  G3_HIP(hipDeviceSynchronize());
-  auto start_load = [&]() -> int {
-    hipStream_t sA = ctx->stream;
-    ctx->stream = ctx->side_stream;
-    G3_HIP(hipEventRecord(l0, ctx->side_stream));
-    int rc = 0;
-    for (int i = 0; i < load && !rc; ++i) rc = g3i_gemm_nt(ctx, C, NL, P, KL, P, KL, NL, NL, KL, -1.0, 1.0, G3_F64, 1);
-    G3_HIP(hipEventRecord(l1, ctx->side_stream));
-    ctx->stream = sA;
-    return rc;
-  };
-  int rc = 0;
-  if (mode == 0) {
-    const int64_t ld = 256;
-    std::vector<double> h(256 * 256);
-    for (int i = 0; i < 256; ++i)
-      for (int j = 0; j < 256; ++j) h[i * 256 + j] = (i == j ? 2.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
-    double *A0, *A, *W;
-    unsigned long long* ts;
-    G3_HIP(hipMalloc(&A0, 256 * 256 * 8));
-    G3_HIP(hipMalloc(&A, (size_t)E * 256 * 256 * 8));
-    G3_HIP(hipMalloc(&W, (size_t)E * 2 * 128 * 128 * 8));
-    G3_HIP(hipMalloc(&ts, (size_t)E * reps * 16));
-    G3_HIP(hipMemcpy(A0, h.data(), 256 * 256 * 8, hipMemcpyHostToDevice));
-    auto kern = probe_potrf_loop<double>;
-    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (lds_bytes < (int)sizeof(DiagLds<double>)) lds_bytes = (int)sizeof(DiagLds<double>);
-    // the resident workgroups first (they need empty CUs), then the load
-    hipLaunchKernelGGL(kern, dim3(E), dim3(512), lds_bytes, sS, A, A0, ld, W, ctx->d_info, reps, ts);
-    G3_LAUNCH_CHECK();
-    rc = start_load();
-    G3_HIP(hipDeviceSynchronize());
-    std::vector<unsigned long long> t((size_t)E * reps * 2);
-    G3_HIP(hipMemcpy(t.data(), ts, t.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<double> us;
-    for (int b = 0; b < E; ++b)
-      for (int r = 2; r < reps; ++r) us.push_back((double)(t[((size_t)b * reps + r) * 2 + 1] - t[((size_t)b * reps + r) * 2]) * 0.01);
-    std::sort(us.begin(), us.end());
-    double mean = 0;
-    for (double u : us) mean += u;
-    out[0] = us[us.size() / 2]; out[1] = us.front(); out[2] = us.back(); out[3] = mean / us.size();
-    float ms = 0;
-    if (load > 0) G3_HIP(hipEventElapsedTime(&ms, l0, l1));
-    out[4] = ms;
-    out[5] = (double)(t[((size_t)0 * reps + reps - 1) * 2 + 1] - t[0]) * 0.01;   // span of workgroup 0's loop, us
-    int info = 0;
-    G3_HIP(hipMemcpy(&info, ctx->d_info, 4, hipMemcpyDeviceToHost));
-    out[6] = info;
-    (void)hipFree(A0); (void)hipFree(A); (void)hipFree(W); (void)hipFree(ts);
-  } else if (mode == 6) {
-    // E resident one-workgroup kernels (s_sleep only) on E streams of their own, lds_bytes = priority (0 least, 1 normal,
-    // 2 greatest); the load on the side stream, and `reps` tiny kernels trickling on the context's stream meanwhile
-    auto kern = probe_resident;
-    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    std::vector<hipStream_t> st(E);
-    for (int i = 0; i < E; ++i) {
-      G3_HIP(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, lds_bytes >= 2 ? hi : (lds_bytes == 1 ? 0 : lo)));
-      hipLaunchKernelGGL(kern, dim3(1), dim3(512), 40960, st[i], flags, 5, 3500, flags + 256 + i);
-    }
-    G3_LAUNCH_CHECK();
-    rc = start_load();
-    G3_HIP(hipEventRecord(e0, ctx->stream));
-    for (int i = 1; i <= reps; ++i) hipLaunchKernelGGL(probe_post, dim3(1), dim3(64), 0, ctx->stream, flags, (unsigned)i);
-    G3_HIP(hipEventRecord(e1, ctx->stream));
-    G3_HIP(hipDeviceSynchronize());
-    float lms = 0, tms = 0;
-    if (load > 0) G3_HIP(hipEventElapsedTime(&lms, l0, l1));
-    G3_HIP(hipEventElapsedTime(&tms, e0, e1));
-    out[4] = lms;
-    out[0] = tms * 1000.0 / (reps > 0 ? reps : 1);
-    for (int i = 0; i < E; ++i) (void)hipStreamDestroy(st[i]);
-  } else if (mode >= 2) {
-    auto kern = probe_resident;
-    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    if (E > 0) hipLaunchKernelGGL(kern, dim3(E), dim3(512), lds_bytes, sS, flags, mode, reps, flags + 256);
-    G3_LAUNCH_CHECK();
-    rc = start_load();
-    G3_HIP(hipDeviceSynchronize());
-    float lms = 0;
-    if (load > 0) G3_HIP(hipEventElapsedTime(&lms, l0, l1));
-    out[4] = lms;
-  } else {
-    auto kern = probe_echo;
-    G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    unsigned* fin = flags, *fout = flags + 64, *err = flags + 128;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds_bytes, sS, fin, fout, (unsigned)reps, err);
-    G3_LAUNCH_CHECK();
-    rc = start_load();
-    G3_HIP(hipEventRecord(e0, ctx->stream));
-    for (int i = 1; i <= reps; ++i) {
-      hipLaunchKernelGGL(probe_post, dim3(1), dim3(64), 0, ctx->stream, fin, (unsigned)i);
-      hipLaunchKernelGGL(probe_wait, dim3(1), dim3(64), 0, ctx->stream, fout, (unsigned)i, err);
-    }
-    G3_HIP(hipEventRecord(e1, ctx->stream));
-    G3_HIP(hipDeviceSynchronize());
-    float ms = 0;
-    G3_HIP(hipEventElapsedTime(&ms, e0, e1));
-    out[0] = ms * 1000.0 / reps;
-    unsigned herr = 0;
-    G3_HIP(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
-    out[1] = herr;
-    float lms = 0;
-    if (load > 0) G3_HIP(hipEventElapsedTime(&lms, l0, l1));
-    out[4] = lms;
-  }
-  (void)hipStreamDestroy(sS);
-  (void)hipFree(flags);
-  if (C) (void)hipFree(C);
-  if (P) (void)hipFree(P);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(l0); (void)hipEventDestroy(l1);
-  return rc;
-}
+#ifdef G3_PROBE   // measurement build only: the round-4 feasibility probes (scripts/probe_resident.inc)
+#include "../../scripts/probe_resident.inc"
 #endif

@@ -287,17 +287,21 @@ class Device:
         return dict(logdet=out[0], quad=out[1], nonfinite=out[2], tries=int(out[3]),
                     fallback=bool(out[4]), info=int(out[5]))
 
-    def gp_factor_batched(self, progs, X, N, d, delta, K, kstride, W, a):
-        """len(progs) evaluations in one sweep; K holds the members `kstride` elements apart"""
+    def gp_factor_batched(self, progs, X, N, d, delta, K, kstride, W, a, raw=False):
+        """len(progs) evaluations in one sweep; K holds the members `kstride` elements apart.  `progs`: a list of
+        KernelProg or an existing ctypes array of them (long chains: packing 4096 programs costs more than evaluating
+        them); raw=True returns the (B, 6) array [logdet, quad, nonfinite, tries, fallback, info] instead of dicts"""
         B = len(progs)
-        arr = (_lib.KernelProg * B)(*progs)
-        out = (C.c_double * (6 * B))()
+        arr = progs if isinstance(progs, C.Array) else (_lib.KernelProg * B)(*progs)
+        out = np.empty((B, 6))
         rc = self.lib.g3_gp_factor_batched(self.ctx, arr, B, X.ptr, N, X.ld, d, delta.ptr, delta.ld,
-                                           _lib.dtype_code(K.dtype), K.ptr, K.ld, kstride, W.ptr, a.ptr, out)
+                                           _lib.dtype_code(K.dtype), K.ptr, K.ld, kstride, W.ptr, a.ptr,
+                                           out.ctypes.data_as(C.POINTER(C.c_double)))
         _check(self, rc, 'g3_gp_factor_batched')
-        o = np.array(out[:]).reshape(B, 6)
+        if raw:
+            return out
         return [dict(logdet=r[0], quad=r[1], nonfinite=r[2], tries=int(r[3]), fallback=bool(r[4]), info=int(r[5]))
-                for r in o]
+                for r in out]
 
     def gp_cross(self, prog, Xs, M, X, N, d, L, W, a, V, mu, ss):
         rc = self.lib.g3_gp_cross(self.ctx, C.byref(prog), Xs.ptr, M, Xs.ld, X.ptr, N, X.ld, d, L.ptr, L.ld,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build a measurement variant of the library next to the product build (never loaded unless G3_LIB_PATH names it):
-#   scripts/build_variant.sh order0 g3_gemm.hip -DG3_GEMM_ORDER=0     -> g3py_amd/lib/libg3hip_order0.so
-#   scripts/build_variant.sh ownexp g3_gram.hip -DG3_FAST_EXP=1
+#   scripts/build_variant.sh ctrace g3_potrf.hip -DG3_CHAIN_TRACE     -> g3py_amd/lib/libg3hip_ctrace.so
+#   scripts/build_variant.sh probe g3_potrf.hip -DG3_PROBE
 # usage: build_variant.sh <name> <source file to recompile> <extra hipcc flags...>
 set -e
 name=$1; src=$2; shift 2

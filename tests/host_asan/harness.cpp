@@ -144,9 +144,9 @@ static void test_rasters() {
     check_raster<64, 64>(sh);
     // and through the chunker of the multi-GPU driver: the chunks tile the staircase exactly once
     std::vector<G3hStairChunk> ch;
-    g3h_stair_chunks(rows, cols, nb, nperm, &ch, sh.seg_diag ? &diag : nullptr);
+    const int limit = g3h_tune_from_env().stair_max;        // (the test lowers G3_STAIR_MAX)
+    g3h_stair_chunks(rows, cols, nb, nperm, &ch, sh.seg_diag ? &diag : nullptr, limit);
     std::map<std::pair<int64_t, int64_t>, int> cover;   // (segment-row block, column block) -> times covered
-    const int limit = g3h_stair_limit();
     for (auto& c : ch) {
       CHECK((int)c.rows.size() <= limit && c.nblk <= limit && c.nblk >= 1);
       CHECK(c.blk0 >= 0 && c.blk0 + c.nblk <= nperm);
@@ -255,7 +255,7 @@ static void test_panel_bounds() {
           const int64_t np = g3h_roundup(n, 128);
           std::vector<int64_t> b;
           std::vector<int> g;
-          g3h_panel_bounds(np, NB, G, batch, &b, &g);
+          g3h_panel_bounds(np, NB, G, batch, g3h_tune_from_env(), &b, &g);
           CHECK(b.size() >= 2 && b.front() == 0 && b.back() == np);
           for (size_t i = 0; i + 1 < b.size(); ++i) {
             CHECK(b[i] < b[i + 1] || (i + 2 == b.size() && b[i] <= b[i + 1]));

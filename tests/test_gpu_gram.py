@@ -262,8 +262,8 @@ def test_gram_fast_path_stationary_plus_periodic(dev, d, stat, noise):
 
 
 def test_fast_exp_accuracy_and_range(dev):
-    """the exp of the compile-time fast paths (the device library's; an own range-reduction + polynomial variant can be
-    built with -DG3_FAST_EXP=1 and must pass the same test) against NumPy's over the whole range an SE / Matern
+    """the exp of the compile-time fast paths (the device library's; the own range-reduction + polynomial variant of round 3
+    was measured slower and removed in round 4, profiles/r03_gram.md) against NumPy's over the whole range an SE / Matern
     exponent can take: <= 4 ulp down to the subnormal range, exact zeros below it, NaN / Inf inputs scrubbed exactly
     as tt_to_num prescribes (tensors.py:90-92)"""
     import g3py_amd._lib as lib

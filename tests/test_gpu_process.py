@@ -691,3 +691,33 @@ def test_experiment_harness_scores_and_timings():
     assert len(rep) == 2 and abs(rep[0] - rep[1]) <= 1e-12
     with pytest.raises(NotImplementedError):
         ex.model_selection(find_MAP=True)
+
+
+@pytest.mark.parametrize('N,dtype', [(64, np.float64), (100, np.float64), (128, np.float64), (200, np.float64), (256, np.float64),
+                                     (128, np.float32), (256, np.float32)])
+def test_small_chain_one_workgroup_per_member(N, dtype):
+    """N <= 256 members of a chain are evaluated by ONE workgroup each in one launch
+    (g3_potrf.hip::small_factor_kernel: factor, block inverses, a = L^-1 delta, log-determinant and quadratic form).
+    Every member equals the one-at-a-time evaluation at 1e-12 (fp32: 1e-5) and the oracle at 1e-8 (fp32: 1e-4); the
+    factor, the inverses and a left behind are what the batched gradient needs (checked through dlogp_chain)."""
+    import g3py_amd as g3
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(N)
+    d = 3
+    X = rng.uniform(0, N ** (1 / d), (N, d))
+    y = np.sin(X.sum(1) / 2) + 0.1 * rng.standard_normal(N)
+    gp = g3.GaussianProcess(space=X, location=g3.Bias(), kernel=g3.MAT52(X), dtype=dtype)
+    gp.observed(X, y)
+    base = _params(gp, MAT52_var=1.2, MAT52_rate=[0.8, 1.0, 1.3], Noise_var=0.1, Bias_Bias=0.1)
+    a0 = gp.active.dict_to_array(base)
+    chain = a0 + 0.15 * rng.standard_normal((70, len(a0)))
+    chain[0] = a0
+    want = np.array([gp.logp(r, array=True) for r in chain], dtype=np.float64)
+    got = np.asarray(gp.logp_chain(chain), dtype=np.float64)
+    f32 = np.dtype(dtype) == np.float32
+    np.testing.assert_allclose(got, want, rtol=1e-5 if f32 else 1e-12)
+    ref = orc.GP(('MAT52', 1.2, np.array([0.8, 1.0, 1.3]), None), 0.1, ('Bias', 0.1)).logp(X, y)
+    assert abs(got[0] - ref) <= (1e-4 if f32 else 1e-8) * abs(ref)
+    if not f32:
+        g1 = np.array([gp.dlogp(r, array=True) for r in chain[:5]])
+        np.testing.assert_allclose(gp.dlogp_chain(chain[:5]), g1, rtol=1e-8, atol=1e-9)

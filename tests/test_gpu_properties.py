@@ -85,3 +85,56 @@ def test_logp_is_invariant_to_the_panel_width(nb):
     env = dict(os.environ, G3_NB='512', G3_NB_TAIL='0')
     base = float.fromhex(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().split()[-1])
     assert abs(got - base) <= 1e-11 * abs(base)
+
+
+def test_two_contexts_on_two_threads_run_concurrently():
+    """include/g3hip.h: "one ctx is single-threaded, distinct contexts may run concurrently".  Round 3 read its tuning
+    knobs through function-local statics inside the launch paths; since round 4 they are read once per context
+    (g3_host.h::G3hTune).  Two threads, a context each, evaluate different problems at the same time, many times:
+    every evaluation must equal the same evaluation made alone."""
+    import threading
+    import g3py_amd as g3
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+
+    def problem(seed, N, d):
+        rng = np.random.default_rng(seed)
+        X = rng.uniform(0, N ** (1 / d), (N, d))
+        y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(N)
+        return X, y
+
+    def evaluate(dev, X, y, reps):
+        N, d = X.shape
+        Np = _lib.roundup(N)
+        spec = ('sum', ('SE', 1.0, np.ones(d), None), ('NOISE', 0.1))
+        Xd, yd = dev.upload(X), dev.upload(y)
+        K, a, W = dev.alloc(Np + 128, Np, np.float64), dev.alloc(1, Np, np.float64), dev.alloc_inverses(Np, np.float64)
+        out = []
+        for _ in range(reps):
+            st = dev.gp_factor(compile_spec(spec, d), Xd, N, d, yd, K, W, a)
+            out.append((st['info'], st['logdet'], st['quad']))
+        return out
+
+    cases = [(11, 1700, 3), (12, 2900, 2)]
+    alone = []
+    for seed, N, d in cases:
+        dev = g3.Device(0)
+        alone.append(evaluate(dev, *problem(seed, N, d), 1)[0])
+        dev.close()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            dev = g3.Device(0)
+            results[i] = evaluate(dev, *problem(*cases[i]), 12)
+            dev.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errors, errors
+    for i in range(2):
+        assert all(r == alone[i] for r in results[i]), (i, alone[i], results[i][:3])

@@ -152,9 +152,11 @@ def test_full_size_configs_match_oracle_pins(dev, name):
         b.free()
 
 
-def test_potrf_blocking_invariance(dev, monkeypatch):
-    """the look-ahead panel width must not change the factor beyond rounding"""
+def test_potrf_blocking_invariance(monkeypatch):
+    """the look-ahead panel width must not change the factor beyond rounding (the knobs are read when a context is
+    created: a fresh one per width)"""
     import scipy.linalg
+    import g3py_amd as g3
     rng = np.random.default_rng(9)
     n = 4096
     B = rng.standard_normal((n, 512))
@@ -162,9 +164,11 @@ def test_potrf_blocking_invariance(dev, monkeypatch):
     res = []
     for nb in ('512', '1024', '4096'):
         monkeypatch.setenv('G3_NB', nb)
+        dev = g3.Device(0)
         Kd = dev.upload(K)
         assert dev.potrf(Kd, n) == 0
         res.append(np.tril(dev.download(Kd)))
+        dev.close()
     ref = scipy.linalg.cholesky(K, lower=True)
     for L in res:
         assert np.abs(L - ref).max() < 1e-11
@@ -354,11 +358,12 @@ def test_config5_matches_oracle_pin(dev, golden_dir, name, dtype, rtol, atol):
 
 
 @pytest.mark.parametrize('env', [{'G3_SB': '2'}, {'G3_SB': '3', 'G3_NB': '256'}, {'G3_SB': '4', 'G3_NB': '128', 'G3_NB_TAIL': '0'},
-                                 {'G3_GEMM_BULK8': '0', 'G3_GEMM_BIG_MIN': '64'}, {'G3_GEMM_BIG_MIN': '64'}])
+                                 {'G3_GEMM_BIG_MIN': '64'}, {'G3_CHAIN': '1'}, {'G3_CHAIN': '1', 'G3_CHAIN_WGS': '5'}])
 def test_alternative_sweep_schedules_give_the_same_factor(tmp_path, env):
     """the knobs README.md documents select other schedules of the SAME arithmetic: super-panels (G3_SB: bulk updates
-    with K = G3_SB x panel width), the four-wave bulk tile, the 128 x 128 tile from 64 tiles on.  Each must reproduce
-    the default sweep's statistics (the environment is read once per process: run in a child)"""
+    with K = G3_SB x panel width), the 128 x 128 tile from 64 tiles on, the chain of the sweep on resident workgroups
+    (G3_CHAIN=1, round 4).  Each must reproduce the default sweep's statistics (the environment is read when a context is
+    created: run in a child)"""
     import json
     import os
     import subprocess
@@ -389,7 +394,7 @@ print('RESULT ' + json.dumps(out))
 
     def run(extra):
         e = dict(os.environ)
-        for k in ('G3_SB', 'G3_NB', 'G3_NB_TAIL', 'G3_GEMM_BULK8', 'G3_GEMM_BIG_MIN'):
+        for k in ('G3_SB', 'G3_NB', 'G3_NB_TAIL', 'G3_GEMM_BIG_MIN', 'G3_CHAIN', 'G3_CHAIN_WGS'):
             e.pop(k, None)
         e.update(extra)
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=e)
