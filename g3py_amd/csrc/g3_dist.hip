@@ -182,6 +182,7 @@ struct g3_dist {
   char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss
   int* info_dev = nullptr;
   double phase_calls[2] = {0, 0}, phase_ms[2] = {0, 0};   // as of the last g3_dist_comm_stats
+  bool serial_coll = false;     // G3_DIST_SERIAL_COLL=1 (read at creation): the two communicators are never in flight together
   bool keep = false;            // g3_dist_set_keep: every block's inverses are kept (the reference of a replay)
   char* wstore = nullptr;       // Np x 128: block inverses of all diagonal blocks, in block order
   // phases timed with the collectives' event machinery: 3 = a diagonal block's update + factorisation, 4 = a panel solve
@@ -423,6 +424,7 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
     delete D;
     return G3_ERR_HIP;
   }
+  D->serial_coll = g3h_env_int("G3_DIST_SERIAL_COLL", 0) != 0;
   g3_ctx_set_stream(D->ctx_look, D->s_look);
   g3_ctx_set_stream(D->ctx_bulk, D->s_bulk);
   D->ctx_bulk->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
@@ -599,7 +601,7 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
       return -6;
     }
   }
-  D->ev.resize(D->nblk + 5);
+  D->ev.resize(D->nblk + 6);
   for (auto& e : D->ev) G3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   G3D_HIP(hipStreamSynchronize(D->ctx->stream));
   D->planned = true;
@@ -711,7 +713,10 @@ static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const int cnt = perm_of(D, k, &idx);
   const int64_t mine = D->rows_mat - r_lo;
   if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, D->send[k % 2], nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
-  return do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * D->es, D->ctx->stream, G3_HINT_PANEL, k);
+  int rc = do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * D->es, D->ctx->stream, G3_HINT_PANEL, k);
+  if (rc) return rc;
+  if (D->serial_coll) G3D_HIP(hipEventRecord(D->ev[D->nblk + 5], D->ctx->stream));    // "panel k is gathered"
+  return G3_OK;
 }
 
 // diagonal block j on the look-ahead stream: its owner applies the update with panel j-1 from its own panel rows
@@ -736,6 +741,12 @@ static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_solved, 
     rc = coll_end(D, D->s_look);
     if (rc) return rc;
   }
+  // Default: the broadcast of block j (its own communicator, this stream) is in flight together with the all-gather of
+  // panel j-1 (the other communicator, chain stream) -- what hides the exchange behind the factorisation.  Two RCCL
+  // communicators used concurrently from one device have never run with more than one rank here (a one-GPU box);
+  // G3_DIST_SERIAL_COLL=1 is the conservative schedule: the broadcast waits until the gather of panel j-1 has been
+  // issued AND completed on this rank, so every rank issues the two communicators strictly one after the other.
+  if (D->serial_coll && j >= 1 && D->nblk - j > 0) G3D_HIP(hipStreamWaitEvent(D->s_look, D->ev[D->nblk + 5], 0));
   rc = do_bcast(D, D->dbuf[j % 2], dbuf_bytes(D), owner_of(D, j), D->s_look, G3_HINT_DIAG, j);
   if (rc) return rc;
   G3D_HIP(hipEventRecord(joined, D->s_look));

@@ -406,11 +406,16 @@ class DistributedGP:
                 if nv > 0:
                     o.diag_add(self._diag(I), nv, add)
 
-    def _count(self, kind, t, peers):
-        """bytes this rank moves over the fabric for one collective on tensor t (sent + received)"""
+    def _count(self, kind, t, peers, tag=None):
+        """bytes this rank moves over the fabric for one collective on tensor t (sent + received); with
+        self.coll_trace a list, the collective is also logged as (kind, payload bytes, root / op) -- the test that keeps
+        this driver and the native one (g3_dist.hip) from drifting compares the two logs"""
         c = self.comm[kind]
         c['calls'] += 1
         c['bytes'] += int(t.numel() * t.element_size() * peers)
+        tr = getattr(self, 'coll_trace', None)
+        if tr is not None:
+            tr.append((kind, int(t.numel() * t.element_size()), tag))
 
     def _allreduce(self, t, op='sum'):
         dist = self.dist
@@ -423,13 +428,13 @@ class DistributedGP:
         dist.all_reduce(dev_t, op=opmap[op], group=self.g_main)
         out = dev_t.cpu()
         self.comm['allreduce']['wait_s'] += time.perf_counter() - t0
-        self._count('allreduce', dev_t, 2 * (self.world - 1) / max(self.world, 1))
+        self._count('allreduce', dev_t, 2 * (self.world - 1) / max(self.world, 1), op)
         return out
 
     def _bcast(self, t, src, async_op):
         if not self.use_coll:
             return None
-        self._count('bcast', t, 1 if self.world > 1 else 0)
+        self._count('bcast', t, 1 if self.world > 1 else 0, int(src))
         return self.dist.broadcast(t, src=src, group=self.g_bcast, async_op=async_op)
 
     def _allgather(self, out, inp):
@@ -819,8 +824,12 @@ class NativeDistributedGP:
         def h2d(ptr, a):
             assert lib.g3_memcpy_h2d(dev.ctx, ptr, a.ctypes.data, a.nbytes) == 0
 
+        self.coll_trace = None      # a list: every collective the LIBRARY asks for is logged as (kind, bytes, root / op)
+
         def bcast(user, buf, nbytes, root):
             try:
+                if self.coll_trace is not None:
+                    self.coll_trace.append(('bcast', int(nbytes), int(root)))
                 t = torch.from_numpy(d2h(buf, nbytes))
                 if world > 1:
                     dist.broadcast(t, src=root)
@@ -833,6 +842,8 @@ class NativeDistributedGP:
 
         def allgather(user, sendp, recvp, nbytes):
             try:
+                if self.coll_trace is not None:
+                    self.coll_trace.append(('allgather', int(nbytes), None))
                 t = torch.from_numpy(d2h(sendp, nbytes))
                 out = [torch.empty_like(t) for _ in range(world)]
                 if world > 1:
@@ -849,6 +860,8 @@ class NativeDistributedGP:
         def allreduce(user, vals, n, op):
             try:
                 a = np.ctypeslib.as_array(vals, shape=(n,))
+                if self.coll_trace is not None:
+                    self.coll_trace.append(('allreduce', int(n) * 8, ('sum', 'min', 'max')[op]))
                 self.last_allreduce_in = a.copy()      # this rank's own contribution (tests compare it with a replay)
                 t = torch.from_numpy(a.copy())
                 if world > 1:

@@ -454,3 +454,40 @@ def contrib_worker(rank, world, port, N, d, M, nb, out_dir):
         dgp.close()
     finally:
         dist.destroy_process_group()
+
+
+def twin_worker(rank, world, port, N, d, M, nb, out_dir):
+    """both drivers on the same plan: the collectives each issues, in order and per kind"""
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import g3py_amd as g3
+        from g3py_amd.distributed import DistributedGP, NativeDistributedGP
+        from oracle import g3_oracle as orc
+        X, y, Xs = synth(N, d, M, 77)
+        spec_f = ('SE', 1.0, np.ones(d), None)
+        spec_n = orc.with_noise(spec_f, 0.1)
+        dev = g3.Device(0)
+        nat = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, transport='callbacks')
+        nat.coll_trace = []
+        lp_n = nat.step(spec_n, spec_f, dev.upload(X), dev.upload(Xs), dev.upload(y))
+        nat_trace = list(nat.coll_trace)
+        nat.close()
+        tdev = torch.device('cuda', 0)
+        torch.cuda.set_device(0)
+        st = torch.cuda.Stream()                 # the Python driver mixes torch ops and library calls: one stream for both
+        torch.cuda.set_stream(st)
+        dev.set_stream(st.cuda_stream)
+        py = DistributedGP(dev, dist, rank, world, N, d, M, nb=nb, torch_device=tdev)
+        py.coll_trace = []
+        o = py.ops
+        lp_p = py.step(spec_n, spec_f, o.from_host(X), o.from_host(Xs), o.from_host(y))
+        import json
+        with open(os.path.join(out_dir, 'rank%d.json' % rank), 'w') as f:
+            json.dump({'native': nat_trace, 'python': py.coll_trace, 'logp': [lp_n, lp_p]}, f)
+    finally:
+        dist.destroy_process_group()

@@ -501,3 +501,42 @@ def test_replayed_rank_equals_the_rank_of_a_real_run(tmp_path, world, N, nb, M):
     with pytest.raises(Exception):
         NativeDistributedGP(dev, None, 0, 2, N + 128, d, M, nb=nb, transport='replay', reference=ref)
     ref.close()
+
+
+@pytest.mark.parametrize('world,N,nb,M', [(2, 900, 128, 40), (3, 1300, 256, 140)])
+def test_python_twin_issues_the_collectives_of_the_native_driver(tmp_path, world, N, nb, M):
+    """the Python DistributedGP is the readable twin of the C++ schedule in g3_dist.hip -- the two must
+    not drift.  On the same plan both drivers are asked for one evaluation and every collective they issue is logged
+    (kind, payload bytes, root / reduction): per kind the two sequences are identical, rank by rank, and so is logp."""
+    import json
+    import torch.multiprocessing as mp
+    from dist_helpers import twin_worker
+    mp.spawn(twin_worker, args=(world, _free_port(), N, 3, M, nb, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        j = json.load(open(str(tmp_path / ('rank%d.json' % r))))
+        assert abs(j['logp'][0] - j['logp'][1]) <= 1e-12 * abs(j['logp'][0])
+        for kind in ('bcast', 'allgather', 'allreduce'):
+            a = [tuple(e[1:]) for e in j['native'] if e[0] == kind]
+            b = [tuple(e[1:]) for e in j['python'] if e[0] == kind]
+            assert a == b, (r, kind, a[:6], b[:6], len(a), len(b))
+        assert len([e for e in j['native'] if e[0] == 'allgather']) == -(-N // nb) - 1
+
+
+@pytest.mark.parametrize('world,transport', [(3, 'callbacks'), (1, 'rccl')])
+def test_native_driver_serial_collectives_knob(tmp_path, monkeypatch, world, transport):
+    """G3_DIST_SERIAL_COLL=1 makes the diagonal-factor broadcast wait for the previous panel's all-gather, so
+    the two communicators are never in flight together (the conservative schedule for the first multi-GPU runs): same
+    numbers as the overlapped default"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    monkeypatch.setenv('G3_DIST_SERIAL_COLL', '1')
+    N, d, M, nb = 1100, 3, 70, 128
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, transport, spec_f, 0.1, out), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    gp = orc.GP(spec_f, 0.1)
+    ref = gp.logp(X, y)
+    assert abs(float(r['logp']) - ref) <= 1e-10 * abs(ref)
+    np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-9)
