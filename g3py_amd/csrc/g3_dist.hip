@@ -56,6 +56,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;      // optional
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -93,6 +94,7 @@ static RcclApi* rccl_api(char* err, size_t errlen) {
   G3_SYM(GetUniqueId) G3_SYM(CommInitRank) G3_SYM(CommDestroy) G3_SYM(Broadcast) G3_SYM(AllGather) G3_SYM(AllReduce)
   G3_SYM(GetErrorString)
 #undef G3_SYM
+  api.CommAbort = (decltype(api.CommAbort))dlsym(api.h, "ncclCommAbort");
   state = 1;
   return &api;
 }
@@ -104,9 +106,14 @@ struct RcclTransport : Transport {
   double* scratch = nullptr;          // device scratch of the scalar all-reduces
   double* hscratch = nullptr;         // pinned
   static const int SCR = 16384;
+  bool failed = false;                // an evaluation returned an error on this rank: peers may be inside a collective
   ~RcclTransport() override {
-    if (api && comm_gather) api->CommDestroy(comm_gather);
-    if (api && comm_bcast) api->CommDestroy(comm_bcast);
+    // after a local error the communicators are ABORTED, not destroyed: ncclCommDestroy waits for outstanding
+    // collectives, which the peers of a rank that left the sweep will never complete.  (A failed rank must end the job:
+    // the other ranks are by then blocked on the GPU in a collective this rank did not enter.)
+    auto drop = [&](ncclComm_t c) { if (failed && api->CommAbort) api->CommAbort(c); else api->CommDestroy(c); };
+    if (api && comm_gather) drop(comm_gather);
+    if (api && comm_bcast) drop(comm_bcast);
     if (scratch) (void)hipFree(scratch);
     if (hscratch) (void)hipHostFree(hscratch);
   }
@@ -244,6 +251,12 @@ struct ReplayTransport : Transport {
       return _rc < 0 ? _rc : G3_ERR_HIP;                                                           \
     }                                                                                              \
   } while (0)
+
+// a sweep that ended in an error on this rank: its RCCL communicators are aborted (not destroyed) at teardown
+static int mark_failed(g3_dist* D, int rc) {
+  if (RcclTransport* t = dynamic_cast<RcclTransport*>(D->tr)) t->failed = true;
+  return rc;
+}
 
 static int owner_of(const g3_dist* D, int I) { return g3h_owner_of(D->world, I); }   // boustrophedon dealing (g3_host.h)
 
@@ -1018,11 +1031,11 @@ extern "C" int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog,
   if (g3i_validate_prog(prog, D->d) || g3i_validate_prog(prog_cross, D->d)) return -2;
   g3_dev_guard _dg(D->ctx);
   int rc = factor_robust(D, prog, prog_cross, X_dev, ldx, Xs_dev, ldxs, delta_dev);
-  if (rc) return rc;
+  if (rc) return mark_failed(D, rc);
   std::vector<double> mm(D->M > 0 ? D->M : 1), sv(D->M > 0 ? D->M : 1);
   double logdet = 0, quad = 0;
   rc = stats(D, &logdet, &quad, mm.data(), sv.data());
-  if (rc) return rc;
+  if (rc) return mark_failed(D, rc);
   out_host[0] = logdet;
   out_host[1] = quad;
   out_host[2] = (double)D->last_info;

@@ -416,6 +416,7 @@ static int launch_gram_fast(g3_ctx* ctx, int kind, int pk, const SeParams<T, D>&
                             const T* X2, int64_t n2, int64_t ldx2, T* K, int64_t ldk, int64_t n1pad,
                             int64_t n2pad, unsigned flags, int sym) {
   dim3 grid = gram_grid(n1pad, n2pad, flags);
+  ctx->gram_paths[0] += 1;
   const size_t lds = (GT + GTN) * ((D | 1) + (pk >= 0 ? 2 * D + 1 : 0)) * sizeof(T);
 #define G3_GRAM_FAST_LAUNCH(KIND, PKIND)                                                                            \
   hipLaunchKernelGGL((gram_kernel<T, D, KIND, PKIND>), grid, dim3(256), lds, ctx->stream, (const g3_kernel_prog*)nullptr, \
@@ -471,7 +472,12 @@ static int gram_t(g3_ctx* ctx, const g3_kernel_prog* prog, const T* X1, int64_t 
   int rc = g3i_upload_prog(ctx, prog, 0, &dprog);
   if (rc) return rc;
   dim3 grid = gram_grid(n1pad, n2pad, flags);
-  // periodic leaves: per-tile cos / sin tables unless there are too many for the LDS
+  // a kernel generated for this expression's structure (compiled at first use, g3_gram_jit.hip) ...
+  if (g3i_gram_jit(ctx, prog, dprog, 1, X1, n1, ldx1, X2, n2, ldx2, d, sizeof(T) == 8 ? G3_F64 : G3_F32, K, ldk, n1pad, n2pad, flags, sym,
+                   (int64_t)0, ctx_diag_off(ctx), grid) == 0)
+    return G3_OK;
+  // ... or the interpreter.  Periodic leaves: per-tile cos / sin tables unless there are too many for the LDS
+  ctx->gram_paths[2] += 1;
   int ntrig = prog_trig_pairs(prog);
   if (ntrig > 16) ntrig = 0;
   const size_t lds = (GT + GTN) * ((d | 1) + (ntrig ? 2 * ntrig + 1 : 0)) * sizeof(T);
@@ -489,6 +495,9 @@ int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_
                      int64_t kstride, int64_t npad, unsigned flags) {
   dim3 grid = gram_grid(npad, npad, flags);
   grid.z = (unsigned)batch;
+  if (g3i_gram_jit(ctx, first_host, dprogs, batch, X, n, ldx, X, n, ldx, d, dt, K, ldk, npad, npad, flags, 1, kstride, (int64_t)0, grid) == 0)
+    return G3_OK;
+  ctx->gram_paths[2] += 1;
   int ntrig = prog_trig_pairs(first_host);
   if (ntrig > 16) ntrig = 0;
   if (dt == G3_F64) {
@@ -596,5 +605,12 @@ extern "C" int g3_gram_diag(g3_ctx* ctx, const g3_kernel_prog* prog, const void*
     hipLaunchKernelGGL((gram_diag_kernel<float>), dim3(nb), dim3(64), 64 * (d | 1) * sizeof(float),
                        ctx->stream, dprog, (const float*)X, n, ldx, d, (float*)diag);
   G3_LAUNCH_CHECK();
+  return G3_OK;
+}
+
+extern "C" int g3_gram_path_stats(g3_ctx* ctx, double out_host[3]) {
+  if (!ctx) return -1;
+  if (!out_host) return -2;
+  for (int i = 0; i < 3; ++i) out_host[i] = (double)ctx->gram_paths[i];
   return G3_OK;
 }

@@ -35,6 +35,7 @@ struct G3hTune {
   int stair_max;          // G3_STAIR_MAX   row segments / B blocks per staircase launch (160; tests lower it)
   int gram_interpret;     // G3_GRAM_NOFAST   1: always the interpreted Gram kernel (A/B measurements)
   int grad_interpret;     // G3_GRAD_GENERIC  1: always the interpreted Gram-gradient kernel
+  int gram_jit;           // G3_GRAM_JIT      0: never generate a Gram kernel for an expression (g3_gram_jit.hip); default 1
 };
 #define G3H_STAIR_MAX 160
 static inline G3hTune g3h_tune_from_env() {
@@ -56,6 +57,7 @@ static inline G3hTune g3h_tune_from_env() {
   t.stair_max = sm < 1 ? 1 : (sm > G3H_STAIR_MAX ? G3H_STAIR_MAX : sm);
   t.gram_interpret = g3h_env_int("G3_GRAM_NOFAST", 0) ? 1 : 0;
   t.grad_interpret = g3h_env_int("G3_GRAD_GENERIC", 0) ? 1 : 0;
+  t.gram_jit = g3h_env_int("G3_GRAM_JIT", 1) ? 1 : 0;
   return t;
 }
 

@@ -20,6 +20,7 @@ struct g3_ctx {
   int la_nev;
   int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
   G3hTune tune;            // tuning knobs, read from the environment once at g3_ctx_create
+  unsigned long long gram_paths[3];   // Gram launches so far: compile-time table, generated at first use, interpreted
   FILE* gemm_log;          // G3_GEMM_LOG=<file>: one line per MFMA GEMM / stripe-solve launch (scripts/launch_table.py)
   bool info_clean;         // d_info is known to be zero (left so by the previous evaluation's last kernel)
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
@@ -180,5 +181,9 @@ int g3i_gram_batched(g3_ctx* ctx, const g3_kernel_prog* dprogs, const g3_kernel_
                      const void* X, int64_t n, int64_t ldx, int d, g3_dtype dt, void* K, int64_t ldk,
                      int64_t kstride, int64_t npad, unsigned flags);
 int g3i_validate_prog(const g3_kernel_prog* p, int d);
+// the Gram kernel generated for prog's structure (g3_gram_jit.hip); 0 = launched, 1 = none (the caller interprets)
+int g3i_gram_jit(g3_ctx* ctx, const g3_kernel_prog* prog_host, const g3_kernel_prog* prog_dev, int batch, const void* X1, int64_t n1,
+                 int64_t ldx1, const void* X2, int64_t n2, int64_t ldx2, int d, g3_dtype dt, void* K, int64_t ldk, int64_t n1pad,
+                 int64_t n2pad, unsigned flags, int sym, int64_t kstride, int64_t diag_off, dim3 grid);
 int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* invd, g3_dtype dt, void* Y,
               int64_t ldy, void* C, int64_t ldc);

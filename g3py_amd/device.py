@@ -191,6 +191,12 @@ class Device:
             _check(self, self.lib.g3_memcpy_d2h(self.ctx, full.ctypes.data, d.ptr, full.nbytes), 'g3_memcpy_d2h')
         return np.ascontiguousarray(full[:rows, :cols])
 
+    def gram_path_stats(self):
+        """Gram launches of this context so far by kernel: compile-time table / generated at first use / interpreted"""
+        out = (C.c_double * 3)()
+        _check(self, self.lib.g3_gram_path_stats(self.ctx, out), 'g3_gram_path_stats')
+        return {'table': int(out[0]), 'generated': int(out[1]), 'interpreted': int(out[2])}
+
     # ---- kernels (thin, argument-checked wrappers)
     def gram(self, prog, X1, X2, d, out, n1pad, n2pad, flags):
         dt = _lib.dtype_code(out.dtype)

@@ -222,6 +222,7 @@ class EllipticalProcess(StochasticProcess):
             if cc is None or cc['kid'][1] != kd or cc['S'].shape != S.shape or not np.array_equal(cc['S'], S):
                 dl = c['delta'] if c['which'] == 'logp' else c['delta_post']
                 st, cc = self._dist_step(c, values, dl, S, cross_kernel=kernel)   # another space / cross kernel: one more evaluation
+                cc['kernel_ref'] = kernel          # keeps the object alive: its id() cannot be handed to another kernel
                 c['stats'], c['cross'] = dict(st, delta_finite=c['stats']['delta_finite']), cc
             return cc['out']
         if cc is not None and cc['kid'] == kid and cc['S'].shape == S.shape and np.array_equal(cc['S'], S):
@@ -233,7 +234,7 @@ class EllipticalProcess(StochasticProcess):
         kern = kernel if kernel is not None else (self.f_kernel_noise if noise else self.f_kernel)
         dev.gp_cross(self._prog(kern, values, c['d']), Sd, M, c['Xd'], c['N'], c['d'], c['Kd'], c['Wd'], c['ad'], V, mu, ss)
         out = (V, dev.download(mu, 1, M)[0], dev.download(ss, 1, M)[0], M, Mp)
-        c['cross'] = dict(kid=kid, S=S.copy(), out=out)
+        c['cross'] = dict(kid=kid, S=S.copy(), out=out, kernel_ref=kernel)   # (the reference pins id(kernel))
         return out
 
     def _prior_gram(self, values, space, noise, pad=False):

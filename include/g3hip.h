@@ -138,6 +138,14 @@ int g3_gram_diag(g3_ctx* ctx, const g3_kernel_prog* prog_host, const void* X_dev
 /* tt_to_cov's diagonal lift (tensors.py:95-98), given a matrix already scrubbed by
  * G3_GRAM_SCRUB: m = min diag; if m <= 0 add (1e-6f - m) to the diagonal. */
 int g3_cov_lift(g3_ctx* ctx, void* K_dev, int64_t n, int64_t ld, g3_dtype dt);
+/* Which Gram kernel the launches of this context used so far: out_host = [compile-time table (one stationary kernel
+ * (+ noise) (+ or x one periodic term)), generated for the expression at first use (hipRTC, g3_gram_jit.hip: any
+ * KernelSum / KernelProd / KernelScale / KernelShift tree, kernels.py:192-244), interpreted].  G3_GRAM_JIT=0 or a
+ * missing libhiprtc leaves the interpreter; all three evaluate the same formulas. */
+int g3_gram_path_stats(g3_ctx* ctx, double out_host[3]);
+/* Build-host check (no GPU, no context): does the kernel generated for this expression compile for gfx950?  0 and the
+ * size of the code object, or hipRTC's status and its log (-1: libhiprtc not available). */
+int g3_gram_jit_check(const g3_kernel_prog* prog_host, int d, g3_dtype dt, int64_t* code_bytes, char* log, int64_t log_bytes);
 /* tt_to_num over a dense n1 x n2 matrix (tensors.py:90-92) */
 int g3_scrub(g3_ctx* ctx, void* A_dev, int64_t n1, int64_t n2, int64_t ld, g3_dtype dt);
 

@@ -396,3 +396,29 @@ def test_gram_grad_fast_path_every_periodic_shape(dev, per, form, d, stat):
             want = 0.5 * np.sum(Gfull * dK)
             scale = 0.5 * np.sum(np.abs(Gfull * dK)) + 1e-30
             assert abs(out[slot] - want) < tol * scale, (stat, per, form, d, lf, pname, k, out[slot], want)
+
+
+def test_no_zoo_expression_is_interpreted_and_generated_equals_interpreted(golden_dir, monkeypatch):
+    """every expression of the zoo runs a compile-time kernel -- the table of g3_gram.hip or one
+    generated for the expression at first use (g3_gram_jit.hip) -- and the generated kernel gives what the interpreter
+    gives (same formulas, same order: 1e-13)"""
+    import g3py_amd as g3
+    g = np.load(os.path.join(golden_dir, 'oracle_kernels.npz'))
+    dev1 = g3.Device(0)
+    monkeypatch.setenv('G3_GRAM_JIT', '0')
+    monkeypatch.setenv('G3_GRAM_NOFAST', '1')
+    dev0 = g3.Device(0)                      # this context interprets everything
+    for d in (1, 3, 8):
+        X, Xs = g['d%d_X' % d], g['d%d_Xs' % d]
+        for name, spec in _zoo(d).items():
+            a, b = _gram(dev1, spec, X), _gram(dev0, spec, X)
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-14 * max(1.0, np.abs(b).max()), err_msg='%s d=%d' % (name, d))
+            a32 = _gram(dev1, spec, X, dtype=np.float32)
+            np.testing.assert_allclose(a32, b, rtol=3e-4, atol=3e-5 * max(1.0, np.abs(b).max()), err_msg='%s d=%d fp32' % (name, d))
+            a, b = _gram(dev1, spec, Xs, X), _gram(dev0, spec, Xs, X)
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-14 * max(1.0, np.abs(b).max()), err_msg='%s d=%d cross' % (name, d))
+    s1, s0 = dev1.gram_path_stats(), dev0.gram_path_stats()
+    assert s1['interpreted'] == 0 and s1['generated'] > 0 and s1['table'] > 0, s1
+    assert s0['generated'] == 0 and s0['table'] == 0 and s0['interpreted'] > 0, s0
+    dev0.close()
+    dev1.close()
