@@ -98,6 +98,8 @@ _SIGS = {
                               _I64, C.c_int, _P, _I64, _P, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_factor_batched': ([_P, C.POINTER(KernelProg), C.c_int, _P, _I64, _I64, C.c_int, _P, _I64, C.c_int, _P, _I64,
                               _I64, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_factor_batched_fields': ([_P, C.POINTER(KernelProg), C.c_int, _P, _P, C.c_int, _P, _I64, _I64, C.c_int, _P,
+                                     _I64, C.c_int, _P, _I64, _I64, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_cross': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P, _I64, _P, _P,
                      C.c_int, _P, _I64, _P, _P], C.c_int),
     'g3_gp_sample': ([_P, _P, _I64, _I64, _P, _P, _I64, C.c_int, _P], C.c_int),

@@ -776,12 +776,46 @@ static int ensure_bbuf(g3_ctx* ctx, size_t bytes) {
   return G3_OK;
 }
 
-extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const void* X, int64_t N,
-                                    int64_t ldx, int d, const void* delta, int64_t ldd, g3_dtype dt, void* K,
-                                    int64_t ldk, int64_t kstride, void* invd, void* a, double* out) {
-  if (!ctx) return -1;
-  g3_dev_guard _dg(ctx);
-  if (!progs) return -2;
+// Where the members' programs come from: `batch` complete host programs, or ONE template plus, per member, the doubles
+// that differ (hyper-parameter values) and the byte offsets in g3_kernel_prog they go to -- a chain of 4096 members is
+// then 4096 x nfield doubles to pack and to copy instead of 4096 x 6 KB.
+struct MemberProgs {
+  const g3_kernel_prog* progs = nullptr;
+  const g3_kernel_prog* tmpl = nullptr;
+  const double* fields = nullptr;
+  const int32_t* offs = nullptr;
+  int nfield = 0;
+  void member(int b, g3_kernel_prog* out) const {
+    if (progs) { *out = progs[b]; return; }
+    *out = *tmpl;
+    for (int i = 0; i < nfield; ++i) memcpy((char*)out + offs[i], &fields[(size_t)b * nfield + i], sizeof(double));
+  }
+};
+
+// a byte offset that names one of the double members of g3_kernel_prog (shift, leaf var / alpha / rate / freq, product coef)
+static int field_offset_ok(int32_t off) {
+  if (off < 0 || off % 8 || (size_t)off + 8 > sizeof(g3_kernel_prog)) return 0;
+  if ((size_t)off == offsetof(g3_kernel_prog, shift)) return 1;
+  const size_t l0 = offsetof(g3_kernel_prog, leaf), p0 = offsetof(g3_kernel_prog, prod);
+  if ((size_t)off >= l0 && (size_t)off < l0 + sizeof(g3_leaf) * G3_MAXLEAF)
+    return ((size_t)off - l0) % sizeof(g3_leaf) >= offsetof(g3_leaf, var);
+  if ((size_t)off >= p0) return ((size_t)off - p0) % sizeof(g3_prod) == offsetof(g3_prod, coef);
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) expand_progs_kernel(g3_kernel_prog* dst, const g3_kernel_prog* tmpl,
+                                                          const double* fields, const int32_t* offs, int nfield) {
+  const uint32_t* s = (const uint32_t*)tmpl;
+  uint32_t* o = (uint32_t*)(dst + blockIdx.x);
+  for (unsigned i = threadIdx.x; i < sizeof(g3_kernel_prog) / 4; i += 256) o[i] = s[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < nfield; i += 256)
+    *(double*)((char*)o + offs[i]) = fields[(size_t)blockIdx.x * nfield + i];
+}
+
+static int gp_factor_batched_impl(g3_ctx* ctx, const MemberProgs& mp, int batch, const void* X, int64_t N,
+                                  int64_t ldx, int d, const void* delta, int64_t ldd, g3_dtype dt, void* K,
+                                  int64_t ldk, int64_t kstride, void* invd, void* a, double* out) {
   if (batch < 1 || batch > G3_MAX_BATCH) return -3;
   if (!X) return -4;
   if (N <= 0) return -5;
@@ -798,10 +832,17 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
   if (!invd) return -14;
   if (!a) return -15;
   if (!out) return -16;
-  for (int b = 0; b < batch; ++b) {
-    if (g3i_validate_prog(&progs[b], d)) return -2;
-    if (!same_structure(&progs[0], &progs[b])) return -2;
+  g3_kernel_prog first;
+  mp.member(0, &first);
+  if (mp.progs) {
+    for (int b = 0; b < batch; ++b) {
+      if (g3i_validate_prog(&mp.progs[b], d)) return -2;
+      if (!same_structure(&mp.progs[0], &mp.progs[b])) return -2;
+    }
+  } else {
+    if (g3i_validate_prog(mp.tmpl, d) || g3i_validate_prog(&first, d)) return -2;
   }
+  const g3_kernel_prog* progs = &first;   // the structure every member shares
   int rc = G3_OK;
   if (batch == 1)
     return gp_factor_impl(ctx, progs, X, N, ldx, d, delta, dt, K, ldk, invd, a, out, nullptr, nullptr, 0, 0, nullptr,
@@ -809,11 +850,26 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
   // device copies of the programs, then the per-member statistics
   const size_t pbytes = (size_t)batch * sizeof(g3_kernel_prog);
   const size_t sbytes = (size_t)batch * 4 * sizeof(double);
-  rc = ensure_bbuf(ctx, pbytes + sbytes);
+  const size_t fbytes = mp.progs ? 0 : (size_t)batch * mp.nfield * sizeof(double);
+  const size_t obytes = mp.progs ? 0 : (((size_t)mp.nfield * sizeof(int32_t) + 15) & ~(size_t)15);
+  rc = ensure_bbuf(ctx, pbytes + sbytes + (mp.progs ? 0 : sizeof(g3_kernel_prog)) + fbytes + obytes);
   if (rc) return rc;
   g3_kernel_prog* dprogs = (g3_kernel_prog*)ctx->bbuf;
   double* dstats = (double*)((char*)ctx->bbuf + pbytes);
-  G3_HIP(hipMemcpyAsync(dprogs, progs, pbytes, hipMemcpyHostToDevice, ctx->stream));
+  if (mp.progs) {
+    G3_HIP(hipMemcpyAsync(dprogs, mp.progs, pbytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    g3_kernel_prog* dtmpl = (g3_kernel_prog*)((char*)dstats + sbytes);
+    double* dfields = (double*)(dtmpl + 1);
+    int32_t* doffs = (int32_t*)((char*)dfields + fbytes);
+    G3_HIP(hipMemcpyAsync(dtmpl, mp.tmpl, sizeof(g3_kernel_prog), hipMemcpyHostToDevice, ctx->stream));
+    if (mp.nfield) {
+      G3_HIP(hipMemcpyAsync(dfields, mp.fields, fbytes, hipMemcpyHostToDevice, ctx->stream));
+      G3_HIP(hipMemcpyAsync(doffs, mp.offs, (size_t)mp.nfield * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(expand_progs_kernel, dim3(batch), dim3(256), 0, ctx->stream, dprogs, dtmpl, dfields, doffs, mp.nfield);
+    G3_LAUNCH_CHECK();
+  }
   const int64_t wstride = Np * G3_LB;
   // K_b = tt_to_cov(cov(X)) (elliptical.py:70-71), right-hand-side block = [delta_b; 0]
   int pr = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)batch * ((double)N * d + 0.5 * (double)N * (N + 1)) * es);
@@ -895,7 +951,9 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
       o[3] = 0; o[4] = 0; o[5] = 0;
     } else {
       // CholeskyRobust's jitter schedule (tensors.py:203-222) for this member alone
-      rc = gp_factor_impl(ctx, &progs[b], X, N, ldx, d, (const char*)delta + (size_t)b * ldd * es, dt,
+      g3_kernel_prog mine;
+      mp.member(b, &mine);
+      rc = gp_factor_impl(ctx, &mine, X, N, ldx, d, (const char*)delta + (size_t)b * ldd * es, dt,
                           (char*)K + (size_t)b * kstride * es, ldk, (char*)invd + (size_t)b * wstride * es,
                           (char*)a + (size_t)b * Np * es, o, nullptr, nullptr, 0, 0, nullptr, nullptr);
     }
@@ -903,6 +961,38 @@ extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, in
   free(hst);
   free(infos);
   return rc;
+}
+
+extern "C" int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const void* X, int64_t N,
+                                    int64_t ldx, int d, const void* delta, int64_t ldd, g3_dtype dt, void* K,
+                                    int64_t ldk, int64_t kstride, void* invd, void* a, double* out) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!progs) return -2;
+  MemberProgs mp;
+  mp.progs = progs;
+  return gp_factor_batched_impl(ctx, mp, batch, X, N, ldx, d, delta, ldd, dt, K, ldk, kstride, invd, a, out);
+}
+
+extern "C" int g3_gp_factor_batched_fields(g3_ctx* ctx, const g3_kernel_prog* tmpl, int batch, const double* fields,
+                                           const int32_t* offsets, int nfield, const void* X, int64_t N, int64_t ldx,
+                                           int d, const void* delta, int64_t ldd, g3_dtype dt, void* K, int64_t ldk,
+                                           int64_t kstride, void* invd, void* a, double* out) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!tmpl) return -2;
+  if (nfield < 0 || nfield > G3_MAX_FIELDS) return -6;
+  if (nfield && (!fields || !offsets)) return -4;
+  for (int i = 0; i < nfield; ++i)
+    if (!field_offset_ok(offsets[i])) return -5;
+  MemberProgs mp;
+  mp.tmpl = tmpl;
+  mp.fields = fields;
+  mp.offs = offsets;
+  mp.nfield = nfield;
+  // the shared checks number their arguments as g3_gp_factor_batched does: X and later sit three places further here
+  int rc = gp_factor_batched_impl(ctx, mp, batch, X, N, ldx, d, delta, ldd, dt, K, ldk, kstride, invd, a, out);
+  return (rc <= -4 && rc >= -16) ? rc - 3 : rc;
 }
 
 extern "C" int g3_gp_factor(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X, int64_t N,

@@ -309,6 +309,23 @@ class Device:
         return [dict(logdet=r[0], quad=r[1], nonfinite=r[2], tries=int(r[3]), fallback=bool(r[4]), info=int(r[5]))
                 for r in out]
 
+    def gp_factor_batched_fields(self, tmpl, offsets, fields, X, N, d, delta, K, kstride, W, a):
+        """gp_factor_batched with the members given as one template program plus a (B, nfield) float64 matrix of the
+        values that differ and the byte offsets in g3_kernel_prog they belong at (see compile_spec_rows); the library
+        expands the programs on the device.  Returns the raw (B, 6) statistics."""
+        fields = np.ascontiguousarray(fields, dtype=np.float64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        B, nf = fields.shape
+        if len(offsets) != nf:
+            raise G3Error('gp_factor_batched_fields: %d offsets for %d fields' % (len(offsets), nf))
+        out = np.empty((B, 6))
+        rc = self.lib.g3_gp_factor_batched_fields(self.ctx, C.byref(tmpl), B, fields.ctypes.data, offsets.ctypes.data, nf,
+                                                  X.ptr, N, X.ld, d, delta.ptr, delta.ld, _lib.dtype_code(K.dtype),
+                                                  K.ptr, K.ld, kstride, W.ptr, a.ptr,
+                                                  out.ctypes.data_as(C.POINTER(C.c_double)))
+        _check(self, rc, 'g3_gp_factor_batched_fields')
+        return out
+
     def gp_cross(self, prog, Xs, M, X, N, d, L, W, a, V, mu, ss):
         rc = self.lib.g3_gp_cross(self.ctx, C.byref(prog), Xs.ptr, M, Xs.ld, X.ptr, N, X.ld, d, L.ptr, L.ld,
                                   W.ptr, a.ptr if a is not None else None, _lib.dtype_code(L.dtype), V.ptr, V.ld,
@@ -458,3 +475,42 @@ def compile_spec(spec, d):
         for k, f in enumerate(fac):
             prog.prod[p].fac[k] = int(f)
     return prog
+
+
+class Rows(np.ndarray):
+    """a hyper value with a leading axis over chain rows (marks batched values apart from constants in a spec)"""
+
+
+def compile_spec_rows(spec_rows, spec0, d, B):
+    """(template, offsets, fields) for gp_factor_batched_fields: `spec_rows` is a spec tree whose free hyper values are
+    Rows arrays (B, ...), `spec0` the same tree for row 0.  Scale / shift constants are not hypers, so products and
+    the shift are the template's; every Rows leaf value becomes field columns."""
+    tmpl = compile_spec(spec0, d)
+    leaves = spec_leaves(spec_rows)
+    leaf0 = KernelProg.leaf.offset
+    lsz = C.sizeof(_lib.Leaf)
+    offs, cols = [], []
+
+    def put(i, member, v, n):
+        if not isinstance(v, Rows):
+            return
+        v = np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(B, -1), (B, n))
+        base = leaf0 + i * lsz + getattr(_lib.Leaf, member).offset
+        for k in range(n):
+            offs.append(base + 8 * k)
+            cols.append(v[:, k])
+    for i, lf in enumerate(leaves):
+        kind, nd = lf[0], int(tmpl.leaf[i].ndims)
+        put(i, 'var', lf[1], 1)
+        if kind in ('SE', 'OU', 'MAT32', 'MAT52'):
+            put(i, 'rate', lf[2], nd)
+        elif kind == 'RQ':
+            put(i, 'rate', lf[2], nd)
+            put(i, 'alpha', lf[3], 1)
+        elif kind in ('COS', 'SINC'):
+            put(i, 'freq', lf[2], nd)
+        elif kind in ('SIN', 'SM'):
+            put(i, 'freq', lf[2], nd)
+            put(i, 'rate', lf[3], nd)
+    fields = np.stack(cols, axis=1) if cols else np.zeros((B, 0))
+    return tmpl, np.asarray(offs, dtype=np.int32), np.ascontiguousarray(fields)

@@ -3,6 +3,7 @@ import numpy as np
 from scipy import stats
 
 from .. import _lib
+from ..device import compile_spec_rows
 from .elliptical import EllipticalProcess, SENTINEL
 
 
@@ -122,7 +123,7 @@ class GaussianProcess(EllipticalProcess):
     def _chain_rule(self, values, inputs, outputs, nat, prog, gmap, slots, alpha, d):
         """host part of d loglike: route the device's per-leaf parameter sums (`slots`) to the model's
         variables and add the O(N) location / warping terms on alpha = s K^-1 delta"""
-        from ..device import spec_leaves
+        from ..device import compile_spec_rows, spec_leaves
         # kernel hypers: leaf parameter slots -> the HyperVars that fed them
         by_name = {v.name: v for v in self.model.vars}
         refs = spec_leaves(self.f_kernel_noise.spec(_Refs(), d))
@@ -259,30 +260,28 @@ class GaussianProcess(EllipticalProcess):
         a = dev.alloc(batch, Np, self.dtype)
         npi = t(-0.5) * t(N) * np.log(t(2.0 * np.pi))
         for lo in range(0, n_rows, batch):
-            rows = range(lo, min(lo + batch, n_rows))
-            progs, deltas, consts, live = [], [], [], []
-            for i in rows:
-                params = self.active.array_to_dict(chain[i])
-                values, logjac = self._values(params)
-                with np.errstate(all='ignore'):
-                    delta = np.asarray(self.f_mapping.inv(y, values), dtype=self.dtype) - self.f_location(X, values)
-                    det_m = self.f_mapping.logdet_dinv(y, values)
-                if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):     # gaussian.py:234-235
-                    out[i] = t(logjac + t(SENTINEL))
-                    continue
-                progs.append(self._prog(self.f_kernel_noise, values, d))
-                deltas.append(delta)
-                consts.append((logjac, det_m))
-                live.append(i)
-            if not live:
-                continue
-            dd = dev.upload(np.stack(deltas).astype(self.dtype))
-            stats = dev.gp_factor_batched(progs, Xd, N, d, dd, K, kstride, W, a)
-            for i, st, (logjac, det_m) in zip(live, stats, consts):
-                if not np.isfinite(st['logdet']) or st['nonfinite'] > 0:                  # gaussian.py:237
-                    out[i] = t(logjac + t(SENTINEL))
-                else:
-                    out[i] = t(logjac + t(npi + t(-0.5) * t(st['quad']) - t(st['logdet']) + det_m))
+            hi = min(lo + batch, n_rows)
+            B = hi - lo
+            # the whole block at once on the host: values, programs (one template + the hyper values that differ per
+            # row), warped observations and the mean -- O(B) NumPy passes, no per-row Python
+            values_b, logjac = self._values_rows(chain[lo:hi])
+            values0 = self._values_row(values_b, 0)
+            tmpl, offs, fields = compile_spec_rows(self.f_kernel_noise.spec(values_b, d),
+                                                   self.f_kernel_noise.spec(values0, d), d, B)
+            with np.errstate(all='ignore'):
+                delta = (np.asarray(self.f_mapping.inv_rows(y, values_b, B), dtype=self.dtype)
+                         - np.asarray(self.f_location.rows(X, values_b, B), dtype=self.dtype))
+                det_m = np.asarray(self.f_mapping.logdet_dinv_rows(y, values_b, B), dtype=self.dtype)
+            bad = ~(np.isfinite(delta).all(axis=1) & np.isfinite(det_m))                  # gaussian.py:234-235
+            if bad.any():
+                delta = np.where(bad[:, None], t(0), delta)        # evaluated like the others, result replaced below
+            dd = dev.upload(np.ascontiguousarray(delta, dtype=self.dtype))
+            st = dev.gp_factor_batched_fields(tmpl, offs, fields, Xd, N, d, dd, K, kstride, W, a)
+            with np.errstate(all='ignore'):
+                lp = logjac.astype(self.dtype) + (npi + t(-0.5) * st[:, 1].astype(self.dtype)
+                                                  - st[:, 0].astype(self.dtype) + det_m)
+            bad |= ~np.isfinite(st[:, 0]) | (st[:, 2] > 0)                                # gaussian.py:237
+            out[lo:hi] = np.where(bad, logjac.astype(self.dtype) + t(SENTINEL), lp)
         return out
 
     def th_logpredictive(self, space, inputs, outputs, vector, params, prior=False, noise=False):

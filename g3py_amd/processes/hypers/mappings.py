@@ -16,6 +16,16 @@ class Mapping(Hypers):
     def logdet_dinv(self, y, values=None):
         raise NotImplementedError
 
+    def inv_rows(self, y, values_rows, B):
+        """inv(y) for B rows of hyper values at once -> (B, N).  Base: row by row."""
+        return np.stack([np.asarray(self.inv(y, {k: np.asarray(v)[j] for k, v in values_rows.items()}), dtype=y.dtype)
+                         for j in range(B)])
+
+    def logdet_dinv_rows(self, y, values_rows, B):
+        with np.errstate(all='ignore'):
+            return np.array([self.logdet_dinv(y, {k: np.asarray(v)[j] for k, v in values_rows.items()})
+                             for j in range(B)], dtype=y.dtype)
+
     def grad(self, y, values=None):
         """[(hyper, d inv(y) / d hyper (length N), d logdet_dinv(y) / d hyper)] in natural space:
         the pieces th_dlogp needs from the warping (mappings.py:88-215, 309-333 differentiated)"""
@@ -31,6 +41,12 @@ class Identity(Mapping):
 
     def logdet_dinv(self, y, values=None):
         return 0.0
+
+    def inv_rows(self, y, values_rows, B):
+        return np.broadcast_to(y, (B, y.shape[0]))
+
+    def logdet_dinv_rows(self, y, values_rows, B):
+        return np.zeros(B, dtype=y.dtype)
 
 
 class LinearMapping(Mapping):
@@ -52,6 +68,18 @@ class LinearMapping(Mapping):
 
     def logdet_dinv(self, y, values=None):
         shift, scale = self._p(values, y.dtype.type)
+        return -y.dtype.type(y.shape[0]) * np.log(scale)
+
+    def _p_rows(self, values_rows, B, t):
+        return tuple(np.broadcast_to(np.asarray(value_of(h, values_rows), dtype=np.float64).reshape(-1), (B,)).astype(t)
+                     for h in (self.shift, self.scale))
+
+    def inv_rows(self, y, values_rows, B):
+        shift, scale = self._p_rows(values_rows, B, y.dtype.type)
+        return y[None, :] / scale[:, None] + shift[:, None]
+
+    def logdet_dinv_rows(self, y, values_rows, B):
+        shift, scale = self._p_rows(values_rows, B, y.dtype.type)
         return -y.dtype.type(y.shape[0]) * np.log(scale)
 
     def grad(self, y, values=None):

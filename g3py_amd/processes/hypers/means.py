@@ -14,6 +14,10 @@ class Mean(Hypers):
         x = np.asarray(x)
         return self.eval(x[:, self.dims] if self.dims is not None else x, values or {})
 
+    def rows(self, x, values_rows, B):
+        """m(x) for B rows of hyper values at once (values_rows[name][j] = row j) -> (B, N).  Base: row by row."""
+        return np.stack([self(x, {k: np.asarray(v)[j] for k, v in values_rows.items()}) for j in range(B)])
+
     def jac(self, x, values):
         """[(hyper, d m(x) / d hyper as an N x size array)] for the free hypers -- what Theano's
         reverse mode propagates through means.py:117-159 for th_dlogp"""
@@ -30,6 +34,10 @@ class Zero(Mean):
     def eval(self, x, values):
         return np.zeros(x.shape[0], dtype=x.dtype)
 
+    def rows(self, x, values_rows, B):
+        x = np.asarray(x)
+        return np.zeros((B, x.shape[0]), dtype=x.dtype)
+
 
 class Bias(Mean):
     SLOTS = (Slot('bias', False, '_Bias'),)
@@ -39,6 +47,11 @@ class Bias(Mean):
 
     def eval(self, x, values):
         return x.dtype.type(value_of(self.bias, values)) * np.ones(x.shape[0], dtype=x.dtype)
+
+    def rows(self, x, values_rows, B):
+        x = np.asarray(x)
+        b = np.broadcast_to(np.asarray(value_of(self.bias, values_rows), dtype=np.float64).reshape(-1), (B,))
+        return b.astype(x.dtype)[:, None] * np.ones((1, x.shape[0]), dtype=x.dtype)
 
     def jac(self, x, values):
         return [(self.bias, np.ones((x.shape[0], 1), dtype=x.dtype))]

@@ -295,6 +295,35 @@ class StochasticProcess:
         self._values_memo = (params, values, logjac)
         return values, logjac
 
+    def _values_rows(self, chain):
+        """_values for every row of a flat-parameter chain at once: {hyper name: Rows (B, *shape)} and the (B,) extra
+        logp terms.  Same arithmetic as _values, reductions taken per row."""
+        from ..device import Rows
+        chain = np.asarray(chain, dtype=np.float64)
+        B = len(chain)
+        values, logjac, o = {}, np.zeros(B), 0
+        for v in self.model.vars:
+            p = chain[:, o:o + v.size].reshape((B,) + tuple(v.shape))
+            o += v.size
+            if v.positive:
+                with np.errstate(over='ignore'):
+                    p = np.exp(p)
+                logjac = logjac + np.where(p > 1e-6, 0.0, -np.inf).reshape(B, -1).sum(axis=1)
+            values[v.name] = np.ascontiguousarray(p).view(Rows)
+        for _, reg, c, sel in self.model.potentials:
+            tot = np.zeros(B)
+            for h in sel:
+                hv = np.asarray(values[h.name]).reshape(B, -1)
+                tot = tot + (np.abs(hv).sum(axis=1) if reg == 'L1' else (hv ** 2).sum(axis=1))
+            if reg in ('L1', 'L2'):
+                logjac = logjac + c * -tot
+        return values, logjac
+
+    @staticmethod
+    def _values_row(values_rows, j):
+        """row j of _values_rows as the plain dict _values returns"""
+        return {k: np.asarray(v)[j] for k, v in values_rows.items()}
+
     # ---- to be provided by subclasses
     def default_hypers(self):
         return {}

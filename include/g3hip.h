@@ -280,6 +280,21 @@ int g3_gp_factor_batched(g3_ctx* ctx, const g3_kernel_prog* progs_host, int batc
                          int64_t ldx, int d, const void* delta_dev, int64_t ldd, g3_dtype dt, void* K_dev,
                          int64_t ldk, int64_t kstride, void* invd_dev, void* a_dev, double* out_host);
 
+/* The same sweep with the members' programs given as ONE template plus what differs: member b is
+ * the template with the double at byte offset offsets_host[i] of g3_kernel_prog replaced by
+ * fields_host[b * nfield + i] (i < nfield <= G3_MAX_FIELDS).  Offsets must name double members
+ * (shift, leaf var / alpha / rate[k] / freq[k], product coef).  The members are expanded on the
+ * device, so a chain row costs nfield doubles of packing and PCIe instead of a 6 KB program --
+ * what lets logp_chain / fixed_logp (stochastic.py:515-532) keep up with the one-workgroup-per-
+ * member evaluation at N <= 256.  Members that fail the first factorisation are rebuilt on the
+ * host and re-run through the jitter schedule exactly as above.  Returns as g3_gp_factor_batched
+ * (argument numbers follow this signature). */
+#define G3_MAX_FIELDS (1 + G3_MAXLEAF * (2 + 2 * G3_MAXD) + G3_MAXPROD)
+int g3_gp_factor_batched_fields(g3_ctx* ctx, const g3_kernel_prog* tmpl_host, int batch, const double* fields_host,
+                                const int32_t* offsets_host, int nfield, const void* X_dev, int64_t N, int64_t ldx,
+                                int d, const void* delta_dev, int64_t ldd, g3_dtype dt, void* K_dev, int64_t ldk,
+                                int64_t kstride, void* invd_dev, void* a_dev, double* out_host);
+
 /* ---- gradient of logp w.r.t. the kernel hyper-parameters ----
  * Reference: StochasticProcess.th_dlogp = gradient(th_logp) (g3py/processes/stochastic.py:308-309;
  * g3py/libs/tensors.py:11-22), i.e. Theano's reverse mode through logp_cho (gaussian.py:208-224)

@@ -53,4 +53,4 @@ p0 = gp.active.dict_to_array(gp.params)
 chain = p0[None, :] + 0.05 * rng.standard_normal((B, len(p0)))
 gp.logp_chain(chain[:64])
 t0 = time.perf_counter(); lp = gp.logp_chain(chain); t = time.perf_counter() - t0
-print('GaussianProcess.logp_chain, N=128, %d rows: %.1f ms = %.0f k eval/s (host: parameter dictionaries, programs, mapping per row)' % (B, t * 1e3, B / t / 1e3))
+print('GaussianProcess.logp_chain, N=128, %d rows: %.1f ms = %.0f k eval/s (block host path, see scripts/r4_chain_host.py)' % (B, t * 1e3, B / t / 1e3))

@@ -721,3 +721,57 @@ def test_small_chain_one_workgroup_per_member(N, dtype):
     if not f32:
         g1 = np.array([gp.dlogp(r, array=True) for r in chain[:5]])
         np.testing.assert_allclose(gp.dlogp_chain(chain[:5]), g1, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N', [96, 700])
+def test_chain_fields_abi_equals_programs_abi(N):
+    """g3_gp_factor_batched_fields (one template + the doubles that differ, expanded on the device) returns what
+    g3_gp_factor_batched returns for the same members packed as whole programs -- bit for bit, both below and above
+    the one-workgroup-per-member size, including a member that needs the jitter schedule; bad offsets are refused."""
+    import g3py_amd as g3
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec, compile_spec_rows
+    rng = np.random.default_rng(N)
+    d, B = 2, 9
+    X = np.repeat(rng.uniform(0, 6, (N // 2, d)), 2, axis=0)          # every input twice: singular without noise
+    y = np.sin(X.sum(1))
+    gp = g3.GaussianProcess(space=X, location=g3.Zero(), kernel=g3.SE(X) * g3.COS(X) + 0.5 * g3.RQ(X))
+    gp.observed(X, y)
+    a0 = gp.active.dict_to_array(gp.params_default)
+    chain = a0 + 0.2 * rng.standard_normal((B, len(a0)))
+    sizes = [(v.key, v.size) for v in gp.model.vars]
+    at = sum(n for k, n in sizes[:[k for k, _ in sizes].index('GP_Noise_var_log_')])
+    chain[4, at] = -800.0                  # exp underflows: no noise, the first factorisation fails
+    values_b, _ = gp._values_rows(chain)
+    tmpl, offs, fields = compile_spec_rows(gp.f_kernel_noise.spec(values_b, d),
+                                           gp.f_kernel_noise.spec(gp._values_row(values_b, 0), d), d, B)
+    progs = [compile_spec(gp.f_kernel_noise.spec(gp._values_row(values_b, j), d), d) for j in range(B)]
+    dev = gp.device
+    Np = _lib.roundup(N)
+    kstride = (Np + _lib.G3_RHS_PAD) * Np
+    Xd = dev.upload(X)
+    dd = dev.upload(np.tile(y, (B, 1)))
+    res = []
+    for call in ('progs', 'fields'):
+        K = dev.alloc(B * (Np + _lib.G3_RHS_PAD), Np, np.float64)
+        W = dev.alloc(B * Np, _lib.G3_PAD, np.float64)
+        a = dev.alloc(B, Np, np.float64)
+        if call == 'progs':
+            st = dev.gp_factor_batched(progs, Xd, N, d, dd, K, kstride, W, a, raw=True)
+        else:
+            st = dev.gp_factor_batched_fields(tmpl, offs, fields, Xd, N, d, dd, K, kstride, W, a)
+        res.append((st.copy(), dev.download(a, B, N).copy()))
+        for b in (K, W, a):
+            b.free()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][0][4, 3] >= 1 and np.all(np.delete(res[0][0][:, 3], 4) == 0), res[0][0]   # only member 4 retried
+    K = dev.alloc(B * (Np + _lib.G3_RHS_PAD), Np, np.float64)
+    W = dev.alloc(B * Np, _lib.G3_PAD, np.float64)
+    a = dev.alloc(B, Np, np.float64)
+    for bad in (4, 0, _lib.KernelProg.leaf.offset + 8, 10 ** 6):        # not 8-aligned / nleaf / a leaf's dims / outside
+        o2 = offs.copy()
+        o2[0] = bad
+        with pytest.raises(g3.G3Error, match='status -5'):
+            dev.gp_factor_batched_fields(tmpl, o2, fields, Xd, N, d, dd, K, kstride, W, a)

@@ -221,3 +221,50 @@ def test_generated_gram_kernel_compiles_for_every_zoo_expression():
                 assert rc == 0 and cb.value > 1000, (d, name, dt, rc, log.value.decode()[:2000])
                 n += 1
     assert n >= 45
+
+
+def test_chain_rows_packing_equals_row_by_row():
+    """logp_chain's block path: one template program + per-row fields (compile_spec_rows, _values_rows, the `rows`
+    forms of the mean and the warp) against the one-row-at-a-time host path, byte for byte where that is defined."""
+    import ctypes as C
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec_rows
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 5, (25, 3))
+    y = np.sin(X.sum(1)) + 3.0
+    k1 = g3.SE(X)
+    k1.set_potential('var', 'L2', c=0.5)
+    cases = [
+        g3.GP(space=X, location=g3.Bias(), kernel=2.5 * k1 * g3.SIN(X) + g3.RQ(X[:, :2], name='RQ2') + 0.25),
+        g3.WGP(space=X, location=g3.Linear(), kernel=g3.MAT52(X) + g3.COS(X) * g3.OU(X), mapping=g3.BoxCoxLinear()),
+        g3.WGP(space=X, location=g3.Zero(), kernel=g3.SM(X) + g3.WN(X), mapping=g3.LinearMapping()),
+    ]
+    for gp in cases:
+        gp.observed(X, y)
+        B, d = 7, X.shape[1]
+        base = gp.active.dict_to_array(gp.params_default)
+        chain = base[None, :] + 0.3 * rng.standard_normal((B, gp.active.ndim))
+        chain[2, :] = -40.0                       # exp() underflows below 1e-6: -inf in the Jacobian term
+        values_b, logjac = gp._values_rows(chain)
+        tmpl, offs, fields = compile_spec_rows(gp.f_kernel_noise.spec(values_b, d),
+                                               gp.f_kernel_noise.spec(gp._values_row(values_b, 0), d), d, B)
+        assert fields.shape == (B, len(offs)) and len(set(offs.tolist())) == len(offs)
+        yv = np.asarray(y, dtype=gp.dtype)
+        with np.errstate(all='ignore'):
+            inv_b = gp.f_mapping.inv_rows(yv, values_b, B)
+            det_b = gp.f_mapping.logdet_dinv_rows(yv, values_b, B)
+            loc_b = gp.f_location.rows(X, values_b, B)
+        for j in range(B):
+            gp._values_memo = None
+            values, lj = gp._values(gp.active.array_to_dict(chain[j]))
+            assert (lj == logjac[j]) or np.isclose(lj, logjac[j], rtol=1e-15), (lj, logjac[j])
+            want = compile_spec(gp.f_kernel_noise.spec(values, d), d)
+            got = _lib.KernelProg.from_buffer_copy(bytes(tmpl))
+            raw = (C.c_char * C.sizeof(got)).from_buffer(got)
+            for o, v in zip(offs, fields[j]):
+                raw[o:o + 8] = np.float64(v).tobytes()
+            assert bytes(got) == bytes(want), j
+            with np.errstate(all='ignore'):
+                np.testing.assert_array_equal(inv_b[j], np.asarray(gp.f_mapping.inv(yv, values), dtype=gp.dtype))
+                np.testing.assert_array_equal(loc_b[j], gp.f_location(X, values))
+                assert np.array_equal(det_b[j], gp.dtype.type(gp.f_mapping.logdet_dinv(yv, values)), equal_nan=True)
