@@ -186,7 +186,8 @@ struct g3_dist {
   char* send[2] = {nullptr, nullptr};
   char* gath[3] = {nullptr, nullptr, nullptr};
   char* avec = nullptr;         // 1 x Np: a = L^-1 delta, broadcast for the mean
-  char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss
+  char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss, one pair per right-hand-side chunk of this rank
+  double* blkstats = nullptr;   // 4 doubles per owned block: per-block reductions stay on the device until ONE copy fetches them
   int* info_dev = nullptr;
   double phase_calls[2] = {0, 0}, phase_ms[2] = {0, 0};   // as of the last g3_dist_comm_stats
   bool serial_coll = false;     // G3_DIST_SERIAL_COLL=1 (read at creation): the two communicators are never in flight together
@@ -323,7 +324,8 @@ int ReplayTransport::allgather(const void* send, void* recv, size_t bytes, hipSt
   const int cnt = g3h_gather_table(D->world, k + 1, D->nblk - 1, &idx);
   if ((size_t)cnt * blk != bytes) return fail("replay: panel all-gather of an unexpected size");
   // this rank's own slots, as the collective would place them
-  if (hipMemcpyAsync((char*)recv + (size_t)D->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+  if ((const char*)send != (char*)recv + (size_t)D->rank * bytes &&
+      hipMemcpyAsync((char*)recv + (size_t)D->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
     return fail("replay: local copy failed");
   // the other ranks' blocks of panel k: block (I, k) of the reference factor, all in one launch
   const int nbk = D->nblk - 1 - k;
@@ -527,7 +529,8 @@ extern "C" int g3_dist_create_replay(g3_ctx* ctx, g3_dist* reference, int rank, 
 
 static void free_plan(g3_dist* D) {
   void* bufs[] = {D->A, D->dbuf[0], D->dbuf[1], D->send[0], D->send[1], D->gath[0], D->gath[1], D->gath[2], D->avec, D->dots,
-                  D->Kinv, D->alpha_dev, D->agath, D->wstore};
+                  D->Kinv, D->alpha_dev, D->agath, D->wstore, D->blkstats};
+  D->blkstats = nullptr;
   for (void* b : bufs) if (b) (void)hipFree(b);
   D->A = D->dbuf[0] = D->dbuf[1] = D->send[0] = D->send[1] = D->gath[0] = D->gath[1] = D->gath[2] = D->avec = D->dots = nullptr;
   D->Kinv = D->alpha_dev = D->agath = nullptr;
@@ -599,9 +602,14 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
     G3D_HIP(hipMemsetAsync(D->send[i], 0, (size_t)D->cmax * nb * nb * D->es, D->ctx->stream));
   }
   // three gather buffers: the bulk update with panel k may still be reading its buffer while panel k + 2 arrives
-  for (int i = 0; i < 3; ++i) G3D_HIP(hipMalloc((void**)&D->gath[i], (size_t)D->world * D->cmax * nb * nb * D->es));
+  for (int i = 0; i < 3; ++i) {
+    G3D_HIP(hipMalloc((void**)&D->gath[i], (size_t)D->world * D->cmax * nb * nb * D->es));
+    // ranks write their rows straight into their slot: the padding of a slot is never written, keep it finite
+    G3D_HIP(hipMemsetAsync(D->gath[i], 0, (size_t)D->world * D->cmax * nb * nb * D->es, D->ctx->stream));
+  }
   G3D_HIP(hipMalloc((void**)&D->avec, (size_t)D->Np * D->es));
-  G3D_HIP(hipMalloc((void**)&D->dots, 2 * 128 * D->es));
+  G3D_HIP(hipMalloc((void**)&D->dots, (D->my_chunks.size() + 1) * 2 * 128 * D->es));
+  G3D_HIP(hipMalloc((void**)&D->blkstats, (D->my_blocks.size() + 1) * 4 * sizeof(double)));
   if (D->keep) G3D_HIP(hipMalloc((void**)&D->wstore, (size_t)D->Np * 128 * D->es));
   if (D->grad) {
     G3D_HIP(hipMalloc((void**)&D->Kinv, (size_t)(D->rows_mat ? D->rows_mat : 1) * D->Np * D->es));
@@ -650,14 +658,24 @@ static int build(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* p
                  const void* Xs, int64_t ldxs, const void* delta, double jitter) {
   const int64_t nb = D->nb;
   double lmin = INFINITY;
-  for (int I : D->my_blocks) {
-    G3D_RC(D->ctx, g3_gram_rows(D->ctx, prog, X, D->N, ldx, D->d, (int64_t)I * nb, nb, D->dt, Aat(D, D->loff[I], 0), D->Np,
-                                G3_GRAM_SCRUB | G3_GRAM_PAD_EYE));
-    const int64_t nv = D->N - (int64_t)I * nb < nb ? D->N - (int64_t)I * nb : nb;
-    if (nv > 0) {
-      double st[3];
-      G3D_RC(D->ctx, g3_diag_stats(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, D->Np, D->dt, st));
-      if (st[0] < lmin || st[0] != st[0]) lmin = st[0];
+  {
+    // the diagonal minimum of each owned block stays on the device; one copy fetches them all
+    int cnt = 0;
+    for (int I : D->my_blocks) {
+      G3D_RC(D->ctx, g3_gram_rows(D->ctx, prog, X, D->N, ldx, D->d, (int64_t)I * nb, nb, D->dt, Aat(D, D->loff[I], 0), D->Np,
+                                  G3_GRAM_SCRUB | G3_GRAM_PAD_EYE));
+      const int64_t nv = D->N - (int64_t)I * nb < nb ? D->N - (int64_t)I * nb : nb;
+      if (nv > 0) {
+        G3D_RC(D->ctx, g3i_diag_stats_dev(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, D->Np, D->dt, D->blkstats + 4 * cnt));
+        ++cnt;
+      }
+    }
+    if (cnt > 0) {
+      std::vector<double> hs((size_t)4 * cnt);
+      G3D_HIP(hipMemcpyAsync(hs.data(), D->blkstats, hs.size() * sizeof(double), hipMemcpyDeviceToHost, D->ctx->stream));
+      G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+      for (int i = 0; i < cnt; ++i)
+        if (hs[4 * i] < lmin || hs[4 * i] != hs[4 * i]) lmin = hs[4 * i];
     }
   }
   for (size_t t = 0; t < D->my_chunks.size(); ++t) {
@@ -725,8 +743,12 @@ static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   std::vector<int32_t> idx;
   const int cnt = perm_of(D, k, &idx);
   const int64_t mine = D->rows_mat - r_lo;
-  if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, D->send[k % 2], nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
-  int rc = do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * D->es, D->ctx->stream, G3_HINT_PANEL, k);
+  // my rows go straight into my slot of the gather buffer and the all-gather runs in place (send = recv + rank * bytes):
+  // no staging copy, and RCCL skips the local block -- at one rank the collective moves nothing at all
+  const size_t gbytes = (size_t)cnt * nb * nb * D->es;
+  char* slot = D->gath[k % 3] + (size_t)D->rank * gbytes;
+  if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, slot, nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
+  int rc = do_allgather(D, slot, D->gath[k % 3], gbytes, D->ctx->stream, G3_HINT_PANEL, k);
   if (rc) return rc;
   if (D->serial_coll) G3D_HIP(hipEventRecord(D->ev[D->nblk + 5], D->ctx->stream));    // "panel k is gathered"
   return G3_OK;
@@ -766,24 +788,27 @@ static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_solved, 
   return G3_OK;
 }
 
-static int stair_ptr(g3_dist* D, g3_ctx* cx, char* C, const char* A, const char* G, const std::vector<int64_t>& seg_rows,
+static int stair_ptr(g3_dist* D, g3_ctx* cx, char* C, const char* A, int64_t lda, const char* G, const std::vector<int64_t>& seg_rows,
                      const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm, const std::vector<int64_t>* seg_diag,
                      double alpha) {
-  // C[rows_s, 0 : seg_cols[s]) += alpha * A[rows_s, 0 : nb) G[block table]^T (C and A full-width local rows, ld = Np),
-  // cut into launches of at most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
+  // C[rows_s, 0 : seg_cols[s]) += alpha * A[rows_s, 0 : nb) G[block table]^T (C full-width local rows, ld = Np; A with leading
+  // dimension lda), cut into launches of at most G3H_STAIR_MAX row segments / blocks of G (g3_host.h)
   std::vector<G3hStairChunk> ch;
   g3h_stair_chunks(seg_rows, seg_cols, D->nb, nperm, &ch, seg_diag, D->ctx->tune.stair_max);
   for (const auto& c : ch) {
-    G3D_RC(cx, g3_gemm_nt_stair(cx, C + ((size_t)c.row0 * D->Np + c.col0) * D->es, D->Np, A + (size_t)c.row0 * D->Np * D->es, D->Np, G,
+    G3D_RC(cx, g3_gemm_nt_stair(cx, C + ((size_t)c.row0 * D->Np + c.col0) * D->es, D->Np, A + (size_t)c.row0 * lda * D->es, lda, G,
                                 D->nb, D->nb, c.rows.data(), c.cols.data(), (int)c.rows.size(), alpha, 1.0, D->dt, D->nb, perm + c.blk0,
                                 c.nblk, seg_diag ? c.diag.data() : nullptr));
   }
   return G3_OK;
 }
+// C[rows_s, col0 : col0 + seg_cols[s]) -= A[rows_s, kcol : kcol + nb) G[block table]^T inside the local matrix.
+// (Measured and not kept, round 4: taking A from this rank's slot of the gathered panel -- both operands from one compact
+//  buffer, as the one-GPU sweep takes both from the panel column -- gains 0.8 ms of 210 at N = 32768, but the right-hand-side
+//  rows are not part of the exchange and need their own launch then, which costs 3.5 ms.)
 static int stair(g3_dist* D, g3_ctx* cx, int64_t row0, int64_t col0, int64_t kcol, const char* G, const std::vector<int64_t>& seg_rows,
                  const std::vector<int64_t>& seg_cols, const int32_t* perm, int nperm, const std::vector<int64_t>* seg_diag = nullptr) {
-  // C[rows_s, col0 : col0 + seg_cols[s]) -= A[rows_s, kcol : kcol + nb) G[block table]^T inside the local matrix
-  return stair_ptr(D, cx, Aat(D, row0, col0), Aat(D, row0, kcol), G, seg_rows, seg_cols, perm, nperm, seg_diag, -1.0);
+  return stair_ptr(D, cx, Aat(D, row0, col0), Aat(D, row0, kcol), D->Np, G, seg_rows, seg_cols, perm, nperm, seg_diag, -1.0);
 }
 
 static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X, int64_t ldx, const void* Xs,
@@ -961,15 +986,18 @@ static int factor_robust(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel
 static int stats(g3_dist* D, double* logdet, double* quad, double* mean, double* ss) {
   const int64_t nb = D->nb, M = D->M, Np = D->Np;
   std::vector<double> acc(2 + 2 * M, 0.0);
+  int nstat = 0;
   for (int I : D->my_blocks) {
     const int64_t nv0 = D->N - (int64_t)I * nb;
     const int64_t nv = nv0 < 0 ? 0 : (nv0 < nb ? nv0 : nb);
     if (nv > 0) {
-      double o[4];
-      G3D_RC(D->ctx, g3_logp_terms(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, Np, nullptr, D->dt, o));
-      acc[0] += o[0];
+      G3D_RC(D->ctx, g3i_logp_terms_dev(D->ctx, Aat(D, D->loff[I], (int64_t)I * nb), nv, Np, nullptr, D->dt, D->blkstats + 4 * nstat));
+      ++nstat;
     }
   }
+  std::vector<double> hstat((size_t)4 * nstat + 1);
+  if (nstat > 0)      // fetched by the synchronisation below (rank 0: with a; the others: with the first chunk or the all-reduce)
+    G3D_HIP(hipMemcpyAsync(hstat.data(), D->blkstats, (size_t)4 * nstat * sizeof(double), hipMemcpyDeviceToHost, D->ctx->stream));
   // a = L^-1 delta is row 0 of right-hand-side chunk 0 (rank 0 holds it); everyone needs it for V a
   const int own0 = 0 % D->world;
   if (D->rank == own0) G3D_HIP(hipMemcpyAsync(D->avec, Aat(D, D->rows_mat, 0), (size_t)Np * D->es, hipMemcpyDeviceToDevice, D->ctx->stream));
@@ -986,23 +1014,35 @@ static int stats(g3_dist* D, double* logdet, double* quad, double* mean, double*
     }
     acc[1] = q;
   }
-  std::vector<char> hb(2 * 128 * D->es);
+  // V a and the row sums of squares of every chunk of mine, then ONE copy and ONE synchronisation for all of them
+  const size_t pair = 2 * 128 * D->es;
+  std::vector<char> hb((D->my_chunks.size() + 1) * pair);
   for (size_t t = 0; t < D->my_chunks.size(); ++t) {
     const int c = D->my_chunks[t];
     if (c == 0) continue;
     const int64_t s0 = (int64_t)(c - 1) * 128;
     const int64_t m = M - s0 < 128 ? M - s0 : 128;
     if (m <= 0) continue;
-    G3D_RC(D->ctx, g3_rows_dot_ss(D->ctx, Aat(D, D->rows_mat + (int64_t)t * 128, 0), m, Np, Np, D->avec, D->dt, D->dots, D->dots + 128 * D->es));
-    G3D_HIP(hipMemcpyAsync(hb.data(), D->dots, 2 * 128 * D->es, hipMemcpyDeviceToHost, D->ctx->stream));
-    G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+    char* dd = D->dots + t * pair;
+    G3D_RC(D->ctx, g3_rows_dot_ss(D->ctx, Aat(D, D->rows_mat + (int64_t)t * 128, 0), m, Np, Np, D->avec, D->dt, dd, dd + 128 * D->es));
+  }
+  if (!D->my_chunks.empty())
+    G3D_HIP(hipMemcpyAsync(hb.data(), D->dots, D->my_chunks.size() * pair, hipMemcpyDeviceToHost, D->ctx->stream));
+  G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+  for (int i = 0; i < nstat; ++i) acc[0] += hstat[4 * i];
+  for (size_t t = 0; t < D->my_chunks.size(); ++t) {
+    const int c = D->my_chunks[t];
+    if (c == 0) continue;
+    const int64_t s0 = (int64_t)(c - 1) * 128;
+    const int64_t m = M - s0 < 128 ? M - s0 : 128;
+    const char* h = hb.data() + t * pair;
     for (int64_t i = 0; i < m; ++i) {
       if (D->dt == G3_F64) {
-        acc[2 + s0 + i] += ((const double*)hb.data())[i];
-        acc[2 + M + s0 + i] += ((const double*)hb.data())[128 + i];
+        acc[2 + s0 + i] += ((const double*)h)[i];
+        acc[2 + M + s0 + i] += ((const double*)h)[128 + i];
       } else {
-        acc[2 + s0 + i] += (double)((const float*)hb.data())[i];
-        acc[2 + M + s0 + i] += (double)((const float*)hb.data())[128 + i];
+        acc[2 + s0 + i] += (double)((const float*)h)[i];
+        acc[2 + M + s0 + i] += (double)((const float*)h)[128 + i];
       }
     }
   }
@@ -1293,15 +1333,16 @@ extern "C" int g3_dist_gp_dlogp(g3_dist* D, const g3_kernel_prog* prog, const g3
     const int cnt = perm_upto(D, k, &perm);
     const int64_t act = rows_done(D, k);
     if (k >= 3) G3D_HIP(hipStreamWaitEvent(sA, D->ev[k - 3], 0));     // the product that read gath[k % 3] is done
-    if (act > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, D->send[k % 2], nb, Xinv + (size_t)k * nb * es, Np, act, nb, D->dt));
-    rc = do_allgather(D, D->send[k % 2], D->gath[k % 3], (size_t)cnt * nb * nb * es, sA);
+    char* slot = D->gath[k % 3] + (size_t)D->rank * cnt * nb * nb * es;      // in place, as in solve_and_gather
+    if (act > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, slot, nb, Xinv + (size_t)k * nb * es, Np, act, nb, D->dt));
+    rc = do_allgather(D, slot, D->gath[k % 3], (size_t)cnt * nb * nb * es, sA);
     if (rc) return rc;
     rc = stream_after(D, sB, sA, ev_tmp);
     if (rc) return rc;
     seg_rows.clear(); seg_cols.clear(); seg_diag.clear();
     for (int I : D->my_blocks) if (I <= k) { seg_rows.push_back(nb); seg_cols.push_back((int64_t)(I + 1) * nb); seg_diag.push_back(1); }
     if (!seg_rows.empty()) {
-      rc = stair_ptr(D, D->ctx_bulk, D->Kinv, Xinv + (size_t)k * nb * es, D->gath[k % 3], seg_rows, seg_cols, perm.data(), k + 1,
+      rc = stair_ptr(D, D->ctx_bulk, D->Kinv, Xinv + (size_t)k * nb * es, Np, D->gath[k % 3], seg_rows, seg_cols, perm.data(), k + 1,
                      &seg_diag, 1.0);
       if (rc) return rc;
     }

@@ -32,6 +32,8 @@ struct G3hTune {
   int64_t gemm_big_min;   // G3_GEMM_BIG_MIN  least number of 128 x 128 tiles for the big tile (4096)
   int64_t trsm_thin_max;  // G3_TRSM_THIN_MAX panel rows up to which the stripe solve uses 16-row stripes (2048)
   int64_t trsm_wide_min;  // G3_TRSM_WIDE_MIN panel rows from which it uses 64-row stripes (12288; 0: never)
+  int64_t trsm_split_min; // G3_TRSM_SPLIT_MIN panel rows from which the solve is split at the launch level (0: never)
+  int64_t trsm_split_n;   // G3_TRSM_SPLIT_N   widest block one stripe launch solves once the split applies (512)
   int stair_max;          // G3_STAIR_MAX   row segments / B blocks per staircase launch (160; tests lower it)
   int gram_interpret;     // G3_GRAM_NOFAST   1: always the interpreted Gram kernel (A/B measurements)
   int grad_interpret;     // G3_GRAD_GENERIC  1: always the interpreted Gram-gradient kernel
@@ -53,6 +55,10 @@ static inline G3hTune g3h_tune_from_env() {
   t.trsm_thin_max = e ? atoll(e) : 2048;
   e = getenv("G3_TRSM_WIDE_MIN");
   t.trsm_wide_min = e ? atoll(e) : 12288;
+  e = getenv("G3_TRSM_SPLIT_MIN");
+  t.trsm_split_min = e ? atoll(e) : 0;
+  e = getenv("G3_TRSM_SPLIT_N");
+  t.trsm_split_n = e ? atoll(e) : 512;
   const int sm = g3h_env_int("G3_STAIR_MAX", G3H_STAIR_MAX);
   t.stair_max = sm < 1 ? 1 : (sm > G3H_STAIR_MAX ? G3H_STAIR_MAX : sm);
   t.gram_interpret = g3h_env_int("G3_GRAM_NOFAST", 0) ? 1 : 0;

@@ -22,7 +22,10 @@ struct g3_ctx {
   G3hTune tune;            // tuning knobs, read from the environment once at g3_ctx_create
   unsigned long long gram_paths[3];   // Gram launches so far: compile-time table, generated at first use, interpreted
   FILE* gemm_log;          // G3_GEMM_LOG=<file>: one line per MFMA GEMM / stripe-solve launch (scripts/launch_table.py)
-  bool info_clean;         // d_info is known to be zero (left so by the previous evaluation's last kernel)
+  bool info_clean;         // d_info is known to be zero: left so by a synchronised evaluation (info_stream == nullptr and
+                           // info_sync), or cleared on info_stream with no factorisation queued since (g3i_reset_info)
+  bool info_sync;
+  hipStream_t info_stream;
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
   bool adopted;            // stream belongs to the caller
   bool bulk_role;          // this context's stream carries bulk updates beside another context's chain (multi-GPU driver)
@@ -161,6 +164,10 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
                  int64_t ldb, g3_dtype dt, const void* invd);
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd);
 int g3i_reset_info(g3_ctx* ctx);
+bool g3i_info_known_zero(const g3_ctx* ctx);
+// g3_diag_stats / g3_logp_terms / g3_rows_dot_ss results left in device memory (no host synchronisation): 3 / 4 doubles
+int g3i_diag_stats_dev(g3_ctx* ctx, const void* A, int64_t n, int64_t ld, g3_dtype dt, double* out_dev);
+int g3i_logp_terms_dev(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const void* a, g3_dtype dt, double* out_dev);
 // batch members of at most 256 padded rows: factor + block inverses + a = L^-1 delta + the four logp scalars, one
 // workgroup per member, one launch (g3_potrf.hip)
 int g3i_small_factor_batched(g3_ctx* ctx, void* K, int64_t ld, int64_t kstride, void* W, int64_t wstride, const void* delta, int64_t ldd,

@@ -860,7 +860,11 @@ static int potrf_diag(g3_ctx* ctx, T* A, int64_t ld, T* W, int64_t row_base, g3_
 template <typename T>
 static int trsm_rec(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B, int64_t m, int64_t ldb,
                     const T* W, g3_dtype dt) {
-  if (n > LB && n <= 1024) {
+  // a tall panel takes the top of the recursion as launches (its X_hi -= X_lo L_hi,lo^T products are then tiles of the bulk
+  // GEMM, not 64 x 128 products of a stripe's workgroup) and only blocks up to trsm_split_n as stripe launches
+  const bool split = ctx->tune.trsm_split_min > 0 && m >= ctx->tune.trsm_split_min && n > ctx->tune.trsm_split_n &&
+                     g3_nbatch(ctx) == 1;
+  if (n > LB && n <= 1024 && !split) {
     // the whole recursion below this point in one launch: a workgroup per 32-row stripe of B
     const int rc = g3i_trsm_stripe(ctx, L, n, ldl, B, m, ldb, W, dt);
     if (rc <= 0) return rc;
@@ -903,8 +907,22 @@ static int potrf_rec(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t row
   return potrf_rec<T>(ctx, A22, n2, ld, W + (n1 / LB) * LB * LB, row_base + n1, dt);
 }
 
+// the pivot flag is known to be zero for work queued on the context's current stream
+bool g3i_info_known_zero(const g3_ctx* ctx) {
+  return ctx->info_clean && g3_nbatch(ctx) == 1 && (ctx->info_sync || ctx->info_stream == ctx->stream);
+}
+
+// GEMM and solve kernels only READ the pivot flag (a failed pivot turns what follows into no-ops).  Once it has been cleared
+// on this stream and no factorisation has been queued since, clearing it again is a 5 us stream operation for nothing --
+// the multi-GPU driver makes ~450 such calls per evaluation.  Everything that can SET the flag marks it unknown first.
 int g3i_reset_info(g3_ctx* ctx) {
+  if (g3i_info_known_zero(ctx)) return G3_OK;
   G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
+  if (g3_nbatch(ctx) == 1) {
+    ctx->info_clean = true;
+    ctx->info_sync = false;
+    ctx->info_stream = ctx->stream;
+  }
   return G3_OK;
 }
 
@@ -1594,7 +1612,7 @@ static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n, int* G) {
 // right-hand sides B: on return those rows hold B L^-T (the forward substitution rides along
 // with the panel solves and trailing updates of the factorisation -- no separate trsm pass).
 int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd, int64_t E) {
-  if (!(ctx->info_clean && g3_nbatch(ctx) == 1))
+  if (!g3i_info_known_zero(ctx))
     G3_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * g3_nbatch(ctx), ctx->stream));
   ctx->info_clean = false;
   if (n == 0) return G3_OK;
@@ -1697,6 +1715,7 @@ int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, in
 
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd) {
   if (n == 0) return G3_OK;
+  ctx->info_clean = false;       // the inversion kernel takes the flag read-write
 
   const unsigned nb = (unsigned)(n / LB);
   if (dt == G3_F64)

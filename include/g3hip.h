@@ -402,7 +402,8 @@ int g3_dist_unique_id(void* id_out /* G3_DIST_ID_BYTES */);
 int g3_dist_create(g3_ctx* ctx, const void* id_gather, const void* id_bcast, int rank, int world, g3_dist** out);
 /* Test transport: the three collectives are supplied by the caller as blocking host callbacks on DEVICE buffers
  * (return 0 on success).  Lets several ranks share ONE GPU (RCCL refuses that) so the schedule can be checked for
- * world > 1 on a one-GPU box; never used by the product path. */
+ * world > 1 on a one-GPU box; never used by the product path.  The panel all-gathers are issued IN PLACE, as RCCL
+ * defines it: send_dev == recv_dev + rank * bytes_per_rank; a callback must read its block before it writes recv_dev. */
 typedef struct {
   void* user;
   int (*bcast)(void* user, void* buf_dev, size_t bytes, int root);

@@ -138,3 +138,23 @@ def test_two_contexts_on_two_threads_run_concurrently():
     assert not errors, errors
     for i in range(2):
         assert all(r == alone[i] for r in results[i]), (i, alone[i], results[i][:3])
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_copy2d_moves_exactly_the_rectangle(dev, dtype):
+    """g3_copy2d (the multi-GPU driver's panel / diagonal-block copies): the 16-byte kernel path and the runtime's
+    rectangular copy for everything unaligned move the same rectangle and nothing else"""
+    from g3py_amd import _lib
+    rng = np.random.default_rng(5)
+    es = np.dtype(dtype).itemsize
+    for rows, cols, ldd, lds, off in [(1024, 1024, 1024, 4096, 0), (300, 512, 640, 768, 128), (7, 130, 200, 256, 0),
+                                      (33, 64, 96, 100, 3), (20000, 256, 256, 512, 256)]:
+        src = rng.standard_normal((rows, lds)).astype(dtype)
+        dst0 = rng.standard_normal((rows, ldd)).astype(dtype)
+        S, Dd = dev.upload(src), dev.upload(dst0)
+        rc = dev.lib.g3_copy2d(dev.ctx, Dd.ptr, ldd, S.ptr + off * es, lds, rows, cols, _lib.dtype_code(np.dtype(dtype)))
+        assert rc == 0
+        got = dev.download(Dd, rows, ldd)
+        want = dst0.copy()
+        want[:, :cols] = src[:, off:off + cols]
+        np.testing.assert_array_equal(got, want)
