@@ -730,15 +730,27 @@ static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const int64_t nb = D->nb, c0 = (int64_t)k * nb;
   const int64_t r_lo = rows_done(D, k);
   const int64_t m = D->rows_mat + D->rows_rhs - r_lo + inv_active(D, k);
+  // The look-ahead of block k+1 needs ITS rows of the panel, not the gathered panel and not my other rows: the owner of
+  // block k+1 solves those nb rows first and releases the look-ahead (update + factorisation + broadcast of block k+1, the
+  // serial cycle every rank waits on) before it solves the rest -- the one-GPU sweep orders its panel solve the same way.
+  // Row-wise independent solves: same arithmetic per row whichever launch carries it.
+  const bool own_next = k + 1 < D->nblk && owner_of(D, k + 1) == D->rank;
+  const int64_t head = (own_next && m > nb) ? nb : 0;
+  bool released = false;
   if (m > 0) {
     int rcp = coll_begin(D, G3_PH_SOLVE, D->ctx->stream, 0.0);
     if (rcp) return rcp;
-    G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), m, D->Np, D->dt, Wof(D, k)));
+    if (head > 0) {
+      G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), head, D->Np, D->dt, Wof(D, k)));
+      G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
+      released = true;
+    }
+    G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo + head, c0), m - head, D->Np, D->dt, Wof(D, k)));
     rcp = coll_end(D, D->ctx->stream);
     if (rcp) return rcp;
   }
-  // the look-ahead of block k+1 needs these rows, not the gathered panel: it starts while the all-gather is in flight
-  G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
+  // (ranks that do not own block k+1: the event only orders the broadcast buffer's reuse behind this solve)
+  if (!released) G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
   if (D->nblk - 1 - k <= 0) return G3_OK;
   std::vector<int32_t> idx;
   const int cnt = perm_of(D, k, &idx);

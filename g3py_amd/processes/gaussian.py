@@ -123,7 +123,7 @@ class GaussianProcess(EllipticalProcess):
     def _chain_rule(self, values, inputs, outputs, nat, prog, gmap, slots, alpha, d):
         """host part of d loglike: route the device's per-leaf parameter sums (`slots`) to the model's
         variables and add the O(N) location / warping terms on alpha = s K^-1 delta"""
-        from ..device import compile_spec_rows, spec_leaves
+        from ..device import spec_leaves
         # kernel hypers: leaf parameter slots -> the HyperVars that fed them
         by_name = {v.name: v for v in self.model.vars}
         refs = spec_leaves(self.f_kernel_noise.spec(_Refs(), d))
