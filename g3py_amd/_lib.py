@@ -113,6 +113,8 @@ _SIGS = {
                      C.c_int, _P, _I64, _P, _I64, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_gp_dlogp_batched': ([_P, C.POINTER(KernelProg), C.c_int, C.POINTER(GradMap), _P, _I64, _I64, C.c_int, _P, _I64,
                              _I64, _P, _P, C.c_int, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
+    'g3_gp_dlogp_batched_fields': ([_P, C.POINTER(KernelProg), C.c_int, _P, _P, C.c_int, C.POINTER(GradMap), _P, _I64, _I64,
+                                    C.c_int, _P, _I64, _I64, _P, _P, C.c_int, _P, _P, _P, C.POINTER(C.c_double)], C.c_int),
     'g3_dist_unique_id': ([_P], C.c_int),
     'g3_dist_create': ([_P, _P, _P, C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
     'g3_dist_create_callbacks': ([_P, C.POINTER(DistCallbacks), C.c_int, C.c_int, C.POINTER(_P)], C.c_int),

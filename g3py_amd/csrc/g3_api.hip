@@ -423,8 +423,13 @@ logp_finish_kernel(const T* L, int64_t n, int64_t npad, int64_t ld, const T* __r
 template <typename T>
 __global__ void __launch_bounds__(256)
 rows_dot_ss_kernel(const T* __restrict__ V, int64_t n, int64_t ld, const T* __restrict__ a,
-                   T* __restrict__ dot, T* __restrict__ ss) {
+                   T* __restrict__ dot, T* __restrict__ ss, int64_t vstride, int64_t astride, int64_t ostride) {
   __shared__ double sd[4], sq[4];
+  // grid.y = batch member: V, a and the outputs vstride / astride / ostride elements apart (0, 0, 0 for one problem)
+  V += (int64_t)blockIdx.y * vstride;
+  if (a) a += (int64_t)blockIdx.y * astride;
+  if (dot) dot += (int64_t)blockIdx.y * ostride;
+  if (ss) ss += (int64_t)blockIdx.y * ostride;
   const T* v = V + (int64_t)blockIdx.x * ld;
   double d = 0, q = 0;
   for (int64_t j = threadIdx.x; j < n; j += 256) {
@@ -578,16 +583,22 @@ extern "C" int g3_logp_terms(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, 
 }
 
 static int rows_dot_ss_launch(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld, const void* a,
-                              g3_dtype dt, void* dot, void* ss) {
+                              g3_dtype dt, void* dot, void* ss, int batch = 1, int64_t vstride = 0, int64_t astride = 0,
+                              int64_t ostride = 0) {
   if (m == 0) return G3_OK;
   if (dt == G3_F64)
-    hipLaunchKernelGGL((rows_dot_ss_kernel<double>), dim3((unsigned)m), dim3(256), 0, ctx->stream,
-                       (const double*)V, n, ld, (const double*)a, (double*)dot, (double*)ss);
+    hipLaunchKernelGGL((rows_dot_ss_kernel<double>), dim3((unsigned)m, (unsigned)batch), dim3(256), 0, ctx->stream,
+                       (const double*)V, n, ld, (const double*)a, (double*)dot, (double*)ss, vstride, astride, ostride);
   else
-    hipLaunchKernelGGL((rows_dot_ss_kernel<float>), dim3((unsigned)m), dim3(256), 0, ctx->stream,
-                       (const float*)V, n, ld, (const float*)a, (float*)dot, (float*)ss);
+    hipLaunchKernelGGL((rows_dot_ss_kernel<float>), dim3((unsigned)m, (unsigned)batch), dim3(256), 0, ctx->stream,
+                       (const float*)V, n, ld, (const float*)a, (float*)dot, (float*)ss, vstride, astride, ostride);
   G3_LAUNCH_CHECK();
   return G3_OK;
+}
+
+int g3i_rows_dot_ss_batched(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld, const void* a, g3_dtype dt, void* dot,
+                            void* ss, int batch, int64_t vstride, int64_t astride, int64_t ostride) {
+  return rows_dot_ss_launch(ctx, V, m, n, ld, a, dt, dot, ss, batch, vstride, astride, ostride);
 }
 
 extern "C" int g3_rows_dot_ss(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld,
@@ -924,7 +935,7 @@ static int gp_factor_batched_impl(g3_ctx* ctx, const MemberProgs& mp, int batch,
     g3i_prof_end(ctx, pr);
     if (!rc && hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = G3_ERR_HIP;
-    if (!rc) rc = g3i_reset_info(ctx);
+    if (!rc && hipMemsetAsync(ctx->d_info, 0, sizeof(int) * batch, ctx->stream) != hipSuccess) rc = G3_ERR_HIP;   // every member's flag
     if (rc) return rc;
   } else if (dt == G3_F64) {
     hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(batch), dim3(1024), 0, ctx->stream, (double*)K, N, ldk,

@@ -181,6 +181,11 @@ int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_d
 int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N, int64_t ldx,
                   int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
                   int64_t row0 = 0, int64_t nrows = -1);
+int g3i_gram_grad_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const g3_grad_map* map, const void* X, int64_t N,
+                          int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, int64_t gstride, const void* alpha,
+                          int64_t astride, double* out_host, int64_t row0 = 0, int64_t nrows = -1);
+int g3i_rows_dot_ss_batched(g3_ctx* ctx, const void* V, int64_t m, int64_t n, int64_t ld, const void* a, g3_dtype dt, void* dot,
+                            void* ss, int batch, int64_t vstride, int64_t astride, int64_t ostride);
 int g3i_ensure_invd(g3_ctx* ctx, int64_t n, g3_dtype dt);
 int g3i_ensure_work(g3_ctx* ctx, size_t bytes);
 int g3i_upload_prog(g3_ctx* ctx, const g3_kernel_prog* prog, int slot, const g3_kernel_prog** dptr);

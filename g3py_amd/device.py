@@ -342,6 +342,21 @@ class Device:
         _check(self, rc, 'g3_gp_dlogp_batched')
         return np.array(out[:]).reshape(B, max(gmap.nslots, 1))[:, :gmap.nslots]
 
+    def gp_dlogp_batched_fields(self, tmpl, offsets, fields, gmap, X, N, d, K, kstride, W, a, Y, Kinv, alpha):
+        """gp_dlogp_batched for members given as template + fields (after gp_factor_batched_fields on the same buffers);
+        returns (B, nslots)"""
+        fields = np.ascontiguousarray(fields, dtype=np.float64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        B, nf = fields.shape
+        ns = max(gmap.nslots, 1)
+        out = np.empty((B, ns))
+        rc = self.lib.g3_gp_dlogp_batched_fields(self.ctx, C.byref(tmpl), B, fields.ctypes.data, offsets.ctypes.data, nf,
+                                                 C.byref(gmap), X.ptr, N, X.ld, d, K.ptr, K.ld, kstride, W.ptr, a.ptr,
+                                                 _lib.dtype_code(K.dtype), Y.ptr, Kinv.ptr, alpha.ptr,
+                                                 out.ctypes.data_as(C.POINTER(C.c_double)))
+        _check(self, rc, 'g3_gp_dlogp_batched_fields')
+        return out[:, :gmap.nslots]
+
     def gp_sample(self, L, M, loc, Z):
         """loc[:, None] + L Z for host normals Z (M x S); L is the padded device factor"""
         Z = np.ascontiguousarray(Z, dtype=L.dtype)

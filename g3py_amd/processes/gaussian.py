@@ -174,11 +174,37 @@ class GaussianProcess(EllipticalProcess):
                 nat[h.name] = nat[h.name] + (-c * np.sign(hv) if reg == 'L1' else -2.0 * c * hv)
         return nat
 
+    def _chain_workspace(self, batch, Np, grad):
+        """device buffers of logp_chain / dlogp_chain, kept between calls (samplers and optimisers evaluate chain after
+        chain on one data set; a GB-sized hipMalloc + hipFree per call costs more than the evaluation: 250 - 390 ms spikes
+        against 7 ms).  One workspace serves both: it only grows (more members, or the two extra matrices of the gradient)
+        and is replaced when the padded size or the dtype changes."""
+        ws = getattr(self, '_chain_ws', None)
+        same = ws is not None and ws['Np'] == int(Np) and ws['dtype'] == self.dtype.str
+        if same and ws['cap'] >= batch and (ws['grad'] or not grad):
+            return ws
+        cap, grad = int(batch), bool(grad)
+        if ws is not None:
+            if same:                 # grow, never shrink: logp_chain and dlogp_chain alternate inside one optimiser
+                cap, grad = max(cap, ws['cap']), grad or ws['grad']
+            for b in ws['bufs']:
+                b.free()
+        dev = self.device
+        n3 = 3 if grad else 1
+        mats = [dev.alloc(cap * (Np + _lib.G3_RHS_PAD), Np, self.dtype) for _ in range(n3)]
+        W = dev.alloc(cap * Np, _lib.G3_PAD, self.dtype)
+        vecs = [dev.alloc(cap, Np, self.dtype) for _ in range(2 if grad else 1)]
+        ws = dict(Np=int(Np), dtype=self.dtype.str, cap=cap, grad=grad, K=mats[0], Y=mats[1] if grad else None,
+                  Ki=mats[2] if grad else None, W=W, a=vecs[0], al=vecs[1] if grad else None, bufs=mats + [W] + vecs)
+        self._chain_ws = ws
+        return ws
+
     def dlogp_chain(self, chain, batch=None):
         """one dlogp per row of a flat-parameter chain, shape (rows, ndim) -- what fixed_dlogp averages
         (stochastic.py:554-564: a loop of single gradients in the reference).  `batch` rows at a time
-        share ONE Gram launch, ONE factorisation sweep (g3_gp_factor_batched) and ONE K^-1 sweep
-        (g3_gp_dlogp_batched); the O(N) chain-rule pieces stay on the host."""
+        share ONE Gram launch, ONE factorisation sweep (g3_gp_factor_batched_fields) and ONE K^-1 sweep with the
+        members' alpha and kernel-parameter sums in launches that carry the member in grid.y
+        (g3_gp_dlogp_batched_fields); the O(N) chain-rule pieces are array arithmetic over the rows on the host."""
         chain = np.atleast_2d(np.asarray(chain, dtype=np.float64))
         n_rows = len(chain)
         out = np.zeros((n_rows, self.active.ndim), dtype=self.dtype)
@@ -197,38 +223,100 @@ class GaussianProcess(EllipticalProcess):
             batch = int(4e9 // (3 * kstride * self.dtype.itemsize))
         batch = max(1, min(int(batch), n_rows, _lib.G3_MAX_BATCH))
         Xd = dev.upload(X)
-        K, Y, Ki = (dev.alloc(batch * (Np + _lib.G3_RHS_PAD), Np, self.dtype) for _ in range(3))
-        W = dev.alloc(batch * Np, _lib.G3_PAD, self.dtype)
-        a, al = dev.alloc(batch, Np, self.dtype), dev.alloc(batch, Np, self.dtype)
+        ws = self._chain_workspace(batch, Np, True)
+        K, Y, Ki, W, a, al = ws['K'], ws['Y'], ws['Ki'], ws['W'], ws['a'], ws['al']
+        t = self.dtype.type
         for lo in range(0, n_rows, batch):
-            live, progs, deltas, vals = [], [], [], []
-            for i in range(lo, min(lo + batch, n_rows)):
-                values, _ = self._values(self.active.array_to_dict(chain[i]))
-                with np.errstate(all='ignore'):
-                    delta = np.asarray(self.f_mapping.inv(y, values), dtype=self.dtype) - self.f_location(X, values)
-                    det_m = self.f_mapping.logdet_dinv(y, values)
-                if not np.all(np.isfinite(delta)) or not np.all(np.isfinite(det_m)):     # constant -1e30 branch
-                    out[i] = self._flat_gradient(values, self._potential_gradient(values))
-                    continue
-                live.append(i)
-                progs.append(self._prog(self.f_kernel_noise, values, d))
-                deltas.append(delta)
-                vals.append(values)
-            if not live:
-                continue
-            stats = dev.gp_factor_batched(progs, Xd, N, d, dev.upload(np.stack(deltas).astype(self.dtype)), K, kstride, W, a)
-            gmap = dev.grad_layout(progs[0])
-            slots = dev.gp_dlogp_batched(progs, gmap, Xd, N, d, K, kstride, W, a, Y, Ki, al)
-            alphas = dev.download(al, len(live), N).astype(np.float64)
-            for j, i in enumerate(live):
-                nat = self._potential_gradient(vals[j])
-                st = stats[j]
-                if np.isfinite(st['logdet']) and st['nonfinite'] == 0:
-                    self._chain_rule(vals[j], X, y, nat, progs[j], gmap, slots[j], alphas[j], d)
-                out[i] = self._flat_gradient(vals[j], nat)
-        for b in (K, Y, Ki, W, a, al):
-            b.free()
+            hi = min(lo + batch, n_rows)
+            B = hi - lo
+            # the block's host side in NumPy passes over all rows (as logp_chain): values, programs as template + fields,
+            # warped observations, mean; the device then does factor, K^-1, alpha and the kernel-parameter sums of every
+            # member in batched launches, and the chain rule below is array arithmetic over the rows
+            values_b, _ = self._values_rows(chain[lo:hi])
+            tmpl, offs, fields = compile_spec_rows(self.f_kernel_noise.spec(values_b, d),
+                                                   self.f_kernel_noise.spec(self._values_row(values_b, 0), d), d, B)
+            with np.errstate(all='ignore'):
+                delta = (np.asarray(self.f_mapping.inv_rows(y, values_b, B), dtype=self.dtype)
+                         - np.asarray(self.f_location.rows(X, values_b, B), dtype=self.dtype))
+                det_m = np.asarray(self.f_mapping.logdet_dinv_rows(y, values_b, B), dtype=self.dtype)
+            bad = ~(np.isfinite(delta).all(axis=1) & np.isfinite(det_m))                  # constant -1e30 branch
+            if bad.any():
+                delta = np.where(bad[:, None], t(0), delta)
+            st = dev.gp_factor_batched_fields(tmpl, offs, fields, Xd, N, d, dev.upload(np.ascontiguousarray(delta, dtype=self.dtype)),
+                                              K, kstride, W, a)
+            gmap = dev.grad_layout(tmpl)
+            slots = dev.gp_dlogp_batched_fields(tmpl, offs, fields, gmap, Xd, N, d, K, kstride, W, a, Y, Ki, al)
+            alphas = dev.download(al, B, N).astype(np.float64)
+            ok = ~bad & np.isfinite(st[:, 0]) & (st[:, 2] == 0)
+            nat = self._potential_gradient_rows(values_b, B)
+            self._chain_rule_rows(values_b, X, y, nat, tmpl, gmap, slots, alphas, d, ok, B)
+            out[lo:hi] = self._flat_gradient_rows(values_b, nat, B)
         return out
+
+    def _potential_gradient_rows(self, values_b, B):
+        nat = {v.name: np.zeros((B,) + tuple(v.shape)) for v in self.model.vars}
+        for _, reg, c, sel in self.model.potentials:                # hypers/__init__.py:97-109
+            for h in sel:
+                hv = np.asarray(values_b[h.name], dtype=np.float64)
+                nat[h.name] = nat[h.name] + (-c * np.sign(hv) if reg == 'L1' else -2.0 * c * hv)
+        return nat
+
+    def _chain_rule_rows(self, values_b, X, y, nat, prog, gmap, slots, alphas, d, ok, B):
+        """_chain_rule for B rows at once: slots (B, nslots), alphas (B, N); rows with ok False get no likelihood term"""
+        from ..device import spec_leaves
+        by_name = {v.name: v for v in self.model.vars}
+        okf = ok.astype(np.float64)
+        with np.errstate(all='ignore'):
+            slots = np.where(ok[:, None], slots, 0.0)
+            alphas = np.where(ok[:, None], alphas, 0.0)
+
+        def add(name, g):            # g: (B,) for a scalar hyper, (B, size) otherwise
+            shp = tuple(by_name[name].shape)
+            nat[name] = nat[name] + np.asarray(g, dtype=np.float64).reshape((B,) + shp)
+        refs = spec_leaves(self.f_kernel_noise.spec(_Refs(), d))
+        fld = {'SE': dict(rate=2), 'OU': dict(rate=2), 'MAT32': dict(rate=2), 'MAT52': dict(rate=2),
+               'RQ': dict(rate=2, alpha=3), 'COS': dict(freq=2), 'SINC': dict(freq=2),
+               'SIN': dict(freq=2, rate=3), 'SM': dict(freq=2, rate=3), 'NOISE': {}, 'WN': {}}
+        for l, lf in enumerate(refs):
+            nd = prog.leaf[l].ndims
+            for pname, idx in dict(var=1, **fld[lf[0]]).items():
+                ref = lf[idx]
+                if not isinstance(ref, _Ref) or ref.name not in by_name:
+                    continue
+                slot = getattr(gmap, pname)[l]
+                if pname in ('var', 'alpha'):
+                    add(ref.name, slots[:, slot])
+                else:
+                    gk = slots[:, slot:slot + nd]
+                    add(ref.name, gk if by_name[ref.name].shape else gk.sum(axis=1))
+        # location: d m / d hyper is the same for every row for the means on the path (linear in their hypers)
+        if getattr(self.f_location, 'JAC_CONSTANT', False):
+            for h, J in self.f_location.grad(X, self._values_row(values_b, 0)):
+                if getattr(h, 'name', None) in by_name:
+                    gj = alphas.dot(np.asarray(J, dtype=np.float64))           # (B, size)
+                    add(h.name, gj if by_name[h.name].shape else gj.sum(axis=1))
+        else:
+            for j in range(B):
+                for h, J in self.f_location.grad(X, self._values_row(values_b, j)):
+                    if getattr(h, 'name', None) in by_name:
+                        gj = alphas[j].dot(np.asarray(J, dtype=np.float64))
+                        nat[h.name][j] = nat[h.name][j] + (gj.reshape(by_name[h.name].shape) if by_name[h.name].shape else gj.sum())
+        with np.errstate(all='ignore'):
+            for h, dinv, dlogdet in self.f_mapping.grad_rows(y, values_b, B):
+                if getattr(h, 'name', None) in by_name:
+                    g = -(alphas * np.asarray(dinv, dtype=np.float64)).sum(axis=1) + np.asarray(dlogdet, dtype=np.float64)
+                    add(h.name, np.where(ok, g, 0.0))
+
+    def _flat_gradient_rows(self, values_b, nat, B):
+        flat = []
+        for v in self.model.vars:
+            g = np.asarray(nat[v.name], dtype=np.float64).reshape(B, -1)
+            if v.positive:
+                g = g * np.asarray(values_b[v.name], dtype=np.float64).reshape(B, -1)
+            flat.append(g)
+        flat = np.concatenate(flat, axis=1) if flat else np.zeros((B, 0))
+        flat = np.where(np.isnan(flat), 0.0, np.where(np.isinf(flat), float(np.float32(1e10)), flat))   # tt_to_num
+        return flat.astype(self.dtype)
 
     # ---- many hyper-parameter vectors on the same observations (stochastic.py:515-520)
     def logp_chain(self, chain, prior=False, batch=None):
@@ -255,9 +343,8 @@ class GaussianProcess(EllipticalProcess):
             batch = int(4e9 // (kstride * self.dtype.itemsize))
         batch = max(1, min(int(batch), n_rows, _lib.G3_MAX_BATCH))
         Xd = dev.upload(X)
-        K = dev.alloc(batch * (Np + _lib.G3_RHS_PAD), Np, self.dtype)
-        W = dev.alloc(batch * Np, _lib.G3_PAD, self.dtype)
-        a = dev.alloc(batch, Np, self.dtype)
+        ws = self._chain_workspace(batch, Np, False)
+        K, W, a = ws['K'], ws['W'], ws['a']
         npi = t(-0.5) * t(N) * np.log(t(2.0 * np.pi))
         for lo in range(0, n_rows, batch):
             hi = min(lo + batch, n_rows)

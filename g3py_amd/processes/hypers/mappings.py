@@ -26,6 +26,14 @@ class Mapping(Hypers):
             return np.array([self.logdet_dinv(y, {k: np.asarray(v)[j] for k, v in values_rows.items()})
                              for j in range(B)], dtype=y.dtype)
 
+    def grad_rows(self, y, values_rows, B):
+        """grad for B rows of hyper values: [(hyper, (B, N), (B,))].  Base: row by row."""
+        per = [self.grad(y, {k: np.asarray(v)[j] for k, v in values_rows.items()}) for j in range(B)]
+        if not per or not per[0]:
+            return []
+        return [(per[0][i][0], np.stack([np.asarray(p[i][1], dtype=np.float64) for p in per]),
+                 np.array([float(p[i][2]) for p in per])) for i in range(len(per[0]))]
+
     def grad(self, y, values=None):
         """[(hyper, d inv(y) / d hyper (length N), d logdet_dinv(y) / d hyper)] in natural space:
         the pieces th_dlogp needs from the warping (mappings.py:88-215, 309-333 differentiated)"""
@@ -47,6 +55,9 @@ class Identity(Mapping):
 
     def logdet_dinv_rows(self, y, values_rows, B):
         return np.zeros(B, dtype=y.dtype)
+
+    def grad_rows(self, y, values_rows, B):
+        return []
 
 
 class LinearMapping(Mapping):
@@ -86,6 +97,12 @@ class LinearMapping(Mapping):
         t = y.dtype.type
         shift, scale = self._p(values, t)
         return [(self.shift, np.ones_like(y), t(0)), (self.scale, -y / scale ** 2, -t(y.shape[0]) / scale)]
+
+    def grad_rows(self, y, values_rows, B):
+        t = y.dtype.type
+        shift, scale = self._p_rows(values_rows, B, t)
+        return [(self.shift, np.ones((B, y.shape[0]), dtype=y.dtype), np.zeros(B, dtype=y.dtype)),
+                (self.scale, -y[None, :] / scale[:, None] ** 2, -t(y.shape[0]) / scale)]
 
 
 class LogShifted(Mapping):

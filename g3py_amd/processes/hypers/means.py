@@ -18,6 +18,8 @@ class Mean(Hypers):
         """m(x) for B rows of hyper values at once (values_rows[name][j] = row j) -> (B, N).  Base: row by row."""
         return np.stack([self(x, {k: np.asarray(v)[j] for k, v in values_rows.items()}) for j in range(B)])
 
+    JAC_CONSTANT = True     # d m(x) / d hyper does not depend on the hyper values (Zero, Bias, Linear: linear in them)
+
     def jac(self, x, values):
         """[(hyper, d m(x) / d hyper as an N x size array)] for the free hypers -- what Theano's
         reverse mode propagates through means.py:117-159 for th_dlogp"""

@@ -360,6 +360,14 @@ int g3_gp_dlogp_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, con
                         int64_t kstride, const void* invd_dev, const void* a_dev, g3_dtype dt, void* Y_dev,
                         void* Kinv_dev, void* alpha_dev, double* out_host);
 
+/* The same with the members' programs given as g3_gp_factor_batched_fields takes them (template + per-member doubles at byte
+ * offsets of g3_kernel_prog): what the binding of dlogp_chain / fixed_dlogp (stochastic.py:554-564) packs per chain block.
+ * Argument numbers in negative return codes follow this signature. */
+int g3_gp_dlogp_batched_fields(g3_ctx* ctx, const g3_kernel_prog* tmpl_host, int batch, const double* fields_host,
+                               const int32_t* offsets_host, int nfield, const g3_grad_map* map, const void* X_dev, int64_t N,
+                               int64_t ldx, int d, const void* L_dev, int64_t ldl, int64_t kstride, const void* invd_dev,
+                               const void* a_dev, g3_dtype dt, void* Y_dev, void* Kinv_dev, void* alpha_dev, double* out_host);
+
 /* Latent draws of the sampler (g3py/processes/gaussian.py:89-95, before the mapping):
  *     out[i][s] = loc[i] + sum_j L[i][j] Z[j][s]
  * L_dev: lower Cholesky factor of the prior / posterior covariance of the M query points, stored

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, '.')
 import g3py_amd as g3
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rng = np.random.default_rng(0)
 for N in (64, 128, 256):
     d = 3
@@ -16,13 +16,11 @@ for N in (64, 128, 256):
     a0 = gp.active.dict_to_array(gp.params_default)
     chain = a0 + 0.15 * rng.standard_normal((B, len(a0)))
     gp.dlogp_chain(chain[:64])
+    gp.dlogp_chain(chain)
     ts = []
-    for _ in range(3):
+    for _ in range(7):
         t0 = time.perf_counter(); g = gp.dlogp_chain(chain); ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     want = np.array([gp.dlogp(r, array=True) for r in chain[:16]])
     err = np.max(np.abs(g[:16] - want) / (np.abs(want) + 1e-12))
     print('dlogp_chain N=%d B=%d: %.2f ms = %.1f k rows/s   max rel diff vs one-at-a-time (16 rows) %.1e' % (N, B, t * 1e3, B / t / 1e3, err), flush=True)
-    if N == 128:
-        pr = cProfile.Profile(); pr.enable(); gp.dlogp_chain(chain); pr.disable()
-        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(18); print(s.getvalue()[:3500])

@@ -775,3 +775,50 @@ def test_chain_fields_abi_equals_programs_abi(N):
         o2[0] = bad
         with pytest.raises(g3.G3Error, match='status -5'):
             dev.gp_factor_batched_fields(tmpl, o2, fields, Xd, N, d, dd, K, kstride, W, a)
+
+
+@pytest.mark.parametrize('case', ['wgp_boxcox_linear_l2', 'gp_periodic_product', 'wgp_linearmap_bias_small'])
+def test_dlogp_chain_block_path_equals_row_by_row(case):
+    """dlogp_chain's block path -- programs as template + fields (g3_gp_dlogp_batched_fields), the members' alpha and
+    kernel-parameter sums in launches that carry the member in grid.y, the chain rule as array arithmetic over the rows --
+    against one dlogp per row, including rows on the -1e30 branch, the -inf Jacobian and the jitter schedule."""
+    import g3py_amd as g3
+    rng = np.random.default_rng(41)
+    if case == 'wgp_boxcox_linear_l2':
+        N, d = 200, 2
+        X = rng.uniform(0, 4, (N, d))
+        y = np.exp(0.3 * np.sin(X.sum(1))) + 0.02 * rng.standard_normal(N) + 1.0
+        k = g3.SE(X)
+        k.set_potential('var', 'L2', c=0.3)
+        gp = g3.WGP(space=X[:4], location=g3.Linear(X), kernel=k + g3.RQ(X), mapping=g3.BoxCoxLinear(y))
+    elif case == 'gp_periodic_product':
+        N, d = 150, 2
+        X = rng.uniform(0, 4, (N, d))
+        y = np.sin(X.sum(1)) + 0.05 * rng.standard_normal(N)
+        gp = g3.GP(space=X[:4], location=g3.Zero(), kernel=g3.MAT52(X) * g3.COS(X) + 0.5 * g3.OU(X))
+    else:
+        N, d = 96, 3
+        X = np.repeat(rng.uniform(0, 3, (N // 2, d)), 2, axis=0)          # duplicated inputs: singular without noise
+        y = np.sin(X.sum(1)) + 2.0
+        gp = g3.WGP(space=X[:4], location=g3.Bias(X), kernel=g3.MAT32(X), mapping=g3.LinearMapping(y))
+    gp.observed(X, y)
+    base = gp.active.dict_to_array(gp.params)
+    chain = base[None, :] + 0.1 * rng.standard_normal((9, len(base)))
+    sizes = [(v.key, v.size) for v in gp.model.vars]
+
+    def at(key):
+        i = [k for k, _ in sizes].index(key)
+        return sum(n for _, n in sizes[:i])
+    noise = at(gp.name + '_Noise_var_log_')
+    jit = case == 'wgp_linearmap_bias_small'
+    chain[3, noise] = -800.0 if jit else np.log(1e-3)     # exp underflows: no noise at all -> singular K, the jitter schedule
+    if case == 'wgp_boxcox_linear_l2':
+        chain[5, at('WGP_BoxCoxLinear_shift')] = -50.0                      # log of negative numbers: the -1e30 branch
+    got = gp.dlogp_chain(chain, batch=5)                                    # two blocks: 5 + 4 rows
+    ref = np.array([gp.dlogp(c, array=True) for c in chain])
+    rest = np.arange(9) != 3 if jit else np.ones(9, dtype=bool)
+    for g in (got, gp.dlogp_chain(chain)):
+        np.testing.assert_allclose(g[rest], ref[rest], rtol=1e-8, atol=1e-8)
+        if jit:       # the jittered factor has condition ~ 1 / jitter: the two summation orders of K^-1 agree to that
+            scale = np.abs(ref[3]).max()
+            np.testing.assert_allclose(g[3], ref[3], rtol=1e-4, atol=1e-6 * scale)
