@@ -174,6 +174,18 @@ class GaussianProcess(EllipticalProcess):
                 nat[h.name] = nat[h.name] + (-c * np.sign(hv) if reg == 'L1' else -2.0 * c * hv)
         return nat
 
+    def _chain_density(self, values_b, st, det_m, N, B):
+        """the rows' observed log-density from the device statistics st = [logdet, quad, ...] (B, 6): the Gaussian
+        -n/2 log 2 pi - beta/2 - sum log L_ii + logdet_dinv (gaussian.py:208-224), evaluated in the process dtype"""
+        t = self.dtype.type
+        npi = t(-0.5) * t(N) * np.log(t(2.0 * np.pi))
+        return npi + t(-0.5) * st[:, 1].astype(self.dtype) - st[:, 0].astype(self.dtype) + det_m
+
+    def _chain_dlogp_scale(self, values_b, st, N, nat, ok, B):
+        """rows' s in d logp / d beta = -s / 2 (None: the Gaussian's s = 1); a density with its own hypers adds their
+        gradient terms to `nat` here (rows with ok False: none)"""
+        return None
+
     def _chain_workspace(self, batch, Np, grad):
         """device buffers of logp_chain / dlogp_chain, kept between calls (samplers and optimisers evaluate chain after
         chain on one data set; a GB-sized hipMalloc + hipFree per call costs more than the evaluation: 250 - 390 ms spikes
@@ -208,9 +220,10 @@ class GaussianProcess(EllipticalProcess):
         chain = np.atleast_2d(np.asarray(chain, dtype=np.float64))
         n_rows = len(chain)
         out = np.zeros((n_rows, self.active.ndim), dtype=self.dtype)
-        custom_scale = type(self)._dlogp_scale is not GaussianProcess._dlogp_scale
+        custom_scale = (type(self)._dlogp_scale is not GaussianProcess._dlogp_scale
+                        and type(self)._chain_dlogp_scale is GaussianProcess._chain_dlogp_scale)
         if not self.is_observed or n_rows == 0 or custom_scale:
-            for i in range(n_rows):          # Student-t scaling differs per member: one at a time
+            for i in range(n_rows):          # a density with a per-member scale and no row form of it: one at a time
                 out[i] = self.dlogp(chain[i], array=True)
             return out
         dev = self.device
@@ -245,10 +258,17 @@ class GaussianProcess(EllipticalProcess):
             st = dev.gp_factor_batched_fields(tmpl, offs, fields, Xd, N, d, dev.upload(np.ascontiguousarray(delta, dtype=self.dtype)),
                                               K, kstride, W, a)
             gmap = dev.grad_layout(tmpl)
-            slots = dev.gp_dlogp_batched_fields(tmpl, offs, fields, gmap, Xd, N, d, K, kstride, W, a, Y, Ki, al)
-            alphas = dev.download(al, B, N).astype(np.float64)
             ok = ~bad & np.isfinite(st[:, 0]) & (st[:, 2] == 0)
             nat = self._potential_gradient_rows(values_b, B)
+            s = self._chain_dlogp_scale(values_b, st, N, nat, ok, B)
+            if s is not None:     # G = s alpha alpha^T - K^-1: the device gets sqrt(s) a and returns sqrt(s) alpha
+                with np.errstate(all='ignore'):
+                    rs = np.where(ok, np.sqrt(s), 1.0)
+                dev.copy_in(a, (dev.download(a, B, Np) * rs[:, None].astype(self.dtype)).astype(self.dtype))
+            slots = dev.gp_dlogp_batched_fields(tmpl, offs, fields, gmap, Xd, N, d, K, kstride, W, a, Y, Ki, al)
+            alphas = dev.download(al, B, N).astype(np.float64)
+            if s is not None:
+                alphas = alphas * rs[:, None]
             self._chain_rule_rows(values_b, X, y, nat, tmpl, gmap, slots, alphas, d, ok, B)
             out[lo:hi] = self._flat_gradient_rows(values_b, nat, B)
         return out
@@ -330,8 +350,8 @@ class GaussianProcess(EllipticalProcess):
         t = self.dtype.type
         out = np.empty(n_rows, dtype=self.dtype)
         if prior or not self.is_observed or n_rows == 0:
-            for i in range(n_rows):
-                out[i] = self.logp(chain[i], array=True, prior=True)
+            if n_rows:                      # the free variables' terms only (th_logp with prior=True): no device work
+                out[:] = self._values_rows(chain)[1].astype(self.dtype)
             return out
         dev = self.device
         X = self._x(self.inputs)
@@ -345,7 +365,6 @@ class GaussianProcess(EllipticalProcess):
         Xd = dev.upload(X)
         ws = self._chain_workspace(batch, Np, False)
         K, W, a = ws['K'], ws['W'], ws['a']
-        npi = t(-0.5) * t(N) * np.log(t(2.0 * np.pi))
         for lo in range(0, n_rows, batch):
             hi = min(lo + batch, n_rows)
             B = hi - lo
@@ -365,8 +384,7 @@ class GaussianProcess(EllipticalProcess):
             dd = dev.upload(np.ascontiguousarray(delta, dtype=self.dtype))
             st = dev.gp_factor_batched_fields(tmpl, offs, fields, Xd, N, d, dd, K, kstride, W, a)
             with np.errstate(all='ignore'):
-                lp = logjac.astype(self.dtype) + (npi + t(-0.5) * st[:, 1].astype(self.dtype)
-                                                  - st[:, 0].astype(self.dtype) + det_m)
+                lp = logjac.astype(self.dtype) + self._chain_density(values_b, st, det_m, N, B).astype(self.dtype)
             bad |= ~np.isfinite(st[:, 0]) | (st[:, 2] > 0)                                # gaussian.py:237
             out[lo:hi] = np.where(bad, logjac.astype(self.dtype) + t(SENTINEL), lp)
         return out

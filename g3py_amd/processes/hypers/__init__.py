@@ -208,6 +208,10 @@ class Freedom(Hypers):
     def __call__(self, values=None):
         return float(self.bound) + float(np.asarray(value_of(self.degree, values or {})))
 
+    def rows(self, values_rows, B):
+        """nu for B rows of hyper values -> (B,) float64"""
+        return float(self.bound) + np.broadcast_to(np.asarray(value_of(self.degree, values_rows), dtype=np.float64).reshape(-1), (B,))
+
 
 def value_of(h, values):
     """numeric value of a hyper slot: HyperVar -> looked up (natural space), constant -> itself"""

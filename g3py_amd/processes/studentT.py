@@ -61,6 +61,38 @@ class StudentTProcess(EllipticalProcess):
             nat[deg.name] = nat[deg.name] + g
         return (nu + n) / (nu - 2.0 + beta)
 
+    # ---- chains of hyper-parameter vectors: the Gaussian block path with the Student-t density and scale per row
+    logp_chain = GaussianProcess.logp_chain
+    dlogp_chain = GaussianProcess.dlogp_chain
+    _chain_workspace = GaussianProcess._chain_workspace
+    _potential_gradient_rows = GaussianProcess._potential_gradient_rows
+    _chain_rule_rows = GaussianProcess._chain_rule_rows
+    _flat_gradient_rows = GaussianProcess._flat_gradient_rows
+
+    def _chain_density(self, values_b, st, det_m, N, B):
+        """th_loglike above for B rows: st = [logdet, quad, ...] per row"""
+        t = self.dtype.type
+        nu = self.f_degree.rows(values_b, B).astype(self.dtype)
+        n, beta = t(N), st[:, 1].astype(self.dtype)
+        r1 = t(-0.5) * (nu + n) * np.log1p(beta / (nu - t(2)))                           # :124
+        gauss = -n * t(0.5) * np.log(t(2.0 * np.float32(np.pi)))                         # :125
+        r2 = ((gammaln((nu + n) * 0.5) - gammaln(nu * 0.5)).astype(self.dtype)
+              - t(0.5) * n * np.log((nu - t(2)) * t(np.float32(np.pi))))
+        r2 = np.where(t(np.float32(1e6)) <= nu, gauss, r2)
+        return (r1 + r2 - st[:, 0].astype(self.dtype) + det_m).astype(self.dtype)       # :127-135
+
+    def _chain_dlogp_scale(self, values_b, st, N, nat, ok, B):
+        """_dlogp_scale above for B rows"""
+        nu, n, beta = self.f_degree.rows(values_b, B), float(N), st[:, 1].astype(np.float64)
+        deg = self.f_degree.degree
+        with np.errstate(all='ignore'):
+            if isinstance(deg, HyperVar) and deg.name in nat:
+                g = -0.5 * np.log1p(beta / (nu - 2.0)) + 0.5 * (nu + n) * beta / ((nu - 2.0) * (nu - 2.0 + beta))
+                g = g + np.where(float(np.float32(1e6)) <= nu, 0.0,
+                                 0.5 * digamma((nu + n) * 0.5) - 0.5 * digamma(nu * 0.5) - 0.5 * n / (nu - 2.0))
+                nat[deg.name] = nat[deg.name] + np.where(ok, g, 0.0).reshape(nat[deg.name].shape)
+            return (nu + n) / (nu - 2.0 + beta)
+
     # ---- posterior scaling (studentT.py:36-49)
     def th_scaling(self, space, inputs, outputs, vector, params, prior=False, noise=False):
         t = self.dtype.type

@@ -822,3 +822,29 @@ def test_dlogp_chain_block_path_equals_row_by_row(case):
         if jit:       # the jittered factor has condition ~ 1 / jitter: the two summation orders of K^-1 agree to that
             scale = np.abs(ref[3]).max()
             np.testing.assert_allclose(g[3], ref[3], rtol=1e-4, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize('warped', [False, True])
+def test_student_t_chains_use_the_block_path_and_equal_row_by_row(warped):
+    """StudentTProcess.logp_chain / dlogp_chain: the Gaussian block path with the t density and the per-row scale
+    s = (nu + n) / (nu - 2 + beta) (studentT.py:114-146) against one evaluation per row; prior=True is the free
+    variables' terms alone"""
+    import g3py_amd as g3
+    rng = np.random.default_rng(53)
+    N, d = 140, 2
+    X = rng.uniform(0, 4, (N, d))
+    y = np.exp(0.3 * np.sin(X.sum(1))) + 0.03 * rng.standard_normal(N) + 1.0
+    if warped:
+        tp = g3.WarpedStudentTProcess(space=X[:4], location=g3.Bias(X), kernel=g3.SE(X), mapping=g3.LinearMapping(y))
+    else:
+        tp = g3.StudentTProcess(space=X[:4], location=g3.Bias(X), kernel=g3.MAT52(X) + g3.COS(X))
+    tp.observed(X, y)
+    base = tp.active.dict_to_array(tp.params)
+    chain = base[None, :] + 0.1 * rng.standard_normal((7, len(base)))
+    chain[2, :] = base - 40.0 * (np.arange(len(base)) == len(base) - 1)      # (harmless shift of the last variable)
+    want = np.array([tp.logp(c, array=True) for c in chain])
+    np.testing.assert_allclose(tp.logp_chain(chain, batch=4), want, rtol=1e-10)
+    np.testing.assert_allclose(tp.logp_chain(chain, prior=True), [tp.logp(c, array=True, prior=True) for c in chain], rtol=1e-12)
+    ref = np.array([tp.dlogp(c, array=True) for c in chain])
+    np.testing.assert_allclose(tp.dlogp_chain(chain, batch=4), ref, rtol=1e-8, atol=1e-8)
+    assert type(tp).dlogp_chain is g3.GaussianProcess.dlogp_chain
