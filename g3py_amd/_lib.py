@@ -77,7 +77,9 @@ _SIGS = {
     'g3_gram_diag': ([_P, C.POINTER(KernelProg), _P, _I64, _I64, C.c_int, C.c_int, _P], C.c_int),
     'g3_cov_lift': ([_P, _P, _I64, _I64, C.c_int], C.c_int),
     'g3_gram_path_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
+    'g3_grad_path_stats': ([_P, C.POINTER(C.c_double)], C.c_int),
     'g3_gram_jit_check': ([C.POINTER(KernelProg), C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int64], C.c_int),
+    'g3_grad_jit_check': ([C.POINTER(KernelProg), C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int64], C.c_int),
     'g3_scrub': ([_P, _P, _I64, _I64, _I64, C.c_int], C.c_int),
     'g3_gemm_nt': ([_P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, C.c_double, C.c_double, C.c_int,
                     C.c_int], C.c_int),

@@ -875,6 +875,97 @@ static int gram_grad_se(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, con
   return G3_OK;
 }
 
+static bool same_shape(const g3_kernel_prog* a, const g3_kernel_prog* b) {
+  if (a->nleaf != b->nleaf || a->nprod != b->nprod) return false;
+  for (int l = 0; l < a->nleaf; ++l) {
+    if (a->leaf[l].kind != b->leaf[l].kind || a->leaf[l].ndims != b->leaf[l].ndims) return false;
+    for (int k = 0; k < a->leaf[l].ndims; ++k)
+      if (a->leaf[l].dims[k] != b->leaf[l].dims[k]) return false;
+  }
+  for (int q = 0; q < a->nprod; ++q) {
+    if (a->prod[q].nfac != b->prod[q].nfac) return false;
+    for (int f = 0; f < a->prod[q].nfac; ++f)
+      if (a->prod[q].fac[f] != b->prod[q].fac[f]) return false;
+  }
+  return true;
+}
+
+// The gradient kernel generated for the members' common structure (g3_gram_jit.hip::g3_grad_jit): compiled at first use,
+// cached; it accumulates g3_grad_layout's standard slots, routed to the caller's map here.  *handled = false: none
+// (no hipRTC, too many slots, members of different structure) -- the caller interprets.
+static int gram_grad_generated(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const g3_grad_map* map, const void* X, int64_t N,
+                               int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, int64_t gstride, const void* alpha,
+                               int64_t astride, double* out_host, bool* handled, int64_t row0, int64_t row1) {
+  *handled = false;
+  int ns = 0;
+  hipFunction_t fn = g3i_grad_jit_function(ctx, &progs[0], d, dt, &ns);
+  if (!fn) return G3_OK;
+  for (int b = 1; b < batch; ++b)
+    if (!same_shape(&progs[0], &progs[b])) return G3_OK;
+  const int64_t bi0 = row0 / GG_T, bi1 = (row1 + GG_T - 1) / GG_T;
+  const int64_t ntiles = bi1 * (bi1 + 1) / 2 - bi0 * (bi0 + 1) / 2;
+  int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
+  if (batch > 1) {
+    const int per = (int)((8192 + batch - 1) / batch);
+    if (nblocks > per) nblocks = per < 1 ? 1 : per;
+  }
+  const int ostride = (int)g3_roundup(ns, 32);
+  const size_t pbytes = (size_t)batch * nblocks * ns * sizeof(double);
+  const size_t obytes = (size_t)batch * ostride * sizeof(double);
+  const size_t gbytes = batch > 1 ? (size_t)batch * sizeof(g3_kernel_prog) : 0;
+  int rc = g3i_ensure_work(ctx, pbytes + obytes + gbytes);
+  if (rc) return rc;
+  double* partial = (double*)ctx->work;
+  double* dout = (double*)((char*)ctx->work + pbytes);
+  const g3_kernel_prog* dprog = nullptr;
+  if (batch > 1) {
+    g3_kernel_prog* dp_all = (g3_kernel_prog*)((char*)ctx->work + pbytes + obytes);
+    G3_HIP(hipMemcpyAsync(dp_all, progs, gbytes, hipMemcpyHostToDevice, ctx->stream));
+    dprog = dp_all;
+  } else {
+    rc = g3i_upload_prog(ctx, progs, 0, &dprog);
+    if (rc) return rc;
+  }
+  struct {
+    const void* prog; const void* X; long long N, ldx; const void* G; long long ldg; const void* alpha; double* partial;
+    long long row0, row1, gstride, astride;
+  } args = {dprog, X, N, ldx, G, ldg, alpha, partial, row0, row1, gstride, astride};
+  size_t asz = sizeof(args);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+  int rec = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)batch * (row0 == 0 && row1 == N ? (double)N * (N + 1) / 2 : (double)ntiles * GG_T * GG_T) * g3_esize(dt));
+  if (hipModuleLaunchKernel(fn, (unsigned)nblocks, (unsigned)batch, 1, GG_THREADS, 1, 1, 0, ctx->stream, nullptr, cfg) != hipSuccess) {
+    (void)hipGetLastError();
+    g3i_prof_end(ctx, rec);
+    return G3_OK;                  // not handled: the interpreter takes it
+  }
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(ns, (unsigned)batch), dim3(256), 0, ctx->stream, partial, nblocks, ns, dout, ostride);
+  G3_LAUNCH_CHECK();
+  g3i_prof_end(ctx, rec);
+  std::vector<double> hv((size_t)batch * ostride);
+  G3_HIP(hipMemcpyAsync(hv.data(), dout, obytes, hipMemcpyDeviceToHost, ctx->stream));
+  G3_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->grad_paths[1] += 1;
+  // standard layout -> the caller's map (slot -1: not wanted)
+  g3_grad_map stdm;
+  if (g3_grad_layout(&progs[0], &stdm) != 0 || stdm.nslots != ns) return G3_ERR_HIP;
+  for (int b = 0; b < batch; ++b) {
+    const double* h = hv.data() + (size_t)b * ostride;
+    double* o = out_host + (size_t)b * map->nslots;
+    for (int s2 = 0; s2 < map->nslots; ++s2) o[s2] = 0.0;
+    for (int l = 0; l < progs[0].nleaf; ++l) {
+      const int nd = progs[0].leaf[l].ndims;
+      if (map->var[l] >= 0 && stdm.var[l] >= 0) o[map->var[l]] = h[stdm.var[l]];
+      if (map->alpha[l] >= 0 && stdm.alpha[l] >= 0) o[map->alpha[l]] = h[stdm.alpha[l]];
+      if (map->rate[l] >= 0 && stdm.rate[l] >= 0)
+        for (int k = 0; k < nd; ++k) o[map->rate[l] + k] = h[stdm.rate[l] + k];
+      if (map->freq[l] >= 0 && stdm.freq[l] >= 0)
+        for (int k = 0; k < nd; ++k) o[map->freq[l] + k] = h[stdm.freq[l] + k];
+    }
+  }
+  *handled = true;
+  return G3_OK;
+}
+
 // `batch` members (programs of one structure, G and alpha gstride / astride elements apart, out_host batch x nslots) in
 // launches that carry the member in grid.y and ONE copy back: a chain row costs no launch and no host round trip of its own.
 int g3i_gram_grad_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const g3_grad_map* map, const void* X, int64_t N,
@@ -903,8 +994,15 @@ int g3i_gram_grad_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, c
       default: break;
     }
 #undef G3_SE_CASE
+    if (!r && done) ctx->grad_paths[0] += 1;
     if (r || done) return r;
   }
+  {   // a kernel generated for this expression's structure (register accumulators, folded leaf formulas)
+    bool done = false;
+    const int r = gram_grad_generated(ctx, progs, batch, map, X, N, ldx, d, dt, G, ldg, gstride, alpha, astride, out_host, &done, row0, row1);
+    if (r || done) return r;
+  }
+  ctx->grad_paths[2] += 1;
   const int dp = d | 1;
   const size_t fixed = ((size_t)2 * GG_T * dp + 2 * GG_T + (size_t)G3_MAXLEAF * GG_THREADS) * sizeof(double);
   const size_t lds_max = 160 * 1024;
@@ -1143,3 +1241,9 @@ extern "C" int g3_gp_dlogp_batched_fields(g3_ctx* ctx, const g3_kernel_prog* tmp
   return (rc <= -4 && rc >= -18) ? rc - 3 : rc;
 }
 
+extern "C" int g3_grad_path_stats(g3_ctx* ctx, double out_host[3]) {
+  if (!ctx) return -1;
+  if (!out_host) return -2;
+  for (int i = 0; i < 3; ++i) out_host[i] = (double)ctx->grad_paths[i];
+  return G3_OK;
+}

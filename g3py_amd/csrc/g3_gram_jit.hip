@@ -216,6 +216,305 @@ g3_gram_jit(const jprog* __restrict__ prog, const T* __restrict__ X1, i64 n1, i6
 }
 )JIT";
 
+// ---- the kernel-parameter sums of the gradient (g3_grad.hip::gram_grad_kernel) for ONE expression structure: leaf kinds,
+// dimensions and the product table are compile-time, so every slot index is a constant and the accumulators are registers
+// (the interpreter keeps them in LDS: one read-modify-write per slot and pair), and the leaf formulas are straight-line code.
+const char* kJitGradSource = R"JIT(
+typedef JT T;
+typedef long long i64;
+#define GG_T 64
+#define GG_THREADS 256
+#define GG_PI 3.14159265358979323846
+enum { K_SE = 0, K_OU = 1, K_MAT32 = 2, K_MAT52 = 3, K_RQ = 4, K_COS = 5, K_SIN = 6, K_SINC = 7, K_SM = 8, K_NOISE = 9, K_WN = 10 };
+struct jleaf { int kind; int ndims; int dims[JMAXD]; double var; double alpha; double rate[JMAXD]; double freq[JMAXD]; };
+struct jprod { double coef; int nfac; int fac[JMAXFAC]; int pad[3]; };
+struct jprog { int nleaf; int nprod; double shift; jleaf leaf[JMAXLEAF]; jprod prod[JMAXPROD]; };
+static_assert(sizeof(jprog) == JPROG_BYTES, "g3_kernel_prog layout");
+
+JTABLES
+
+// the standard slot layout of g3_grad_layout: per leaf var, [alpha], [freq...], [rate...]
+constexpr int slots_of(int kind, int nd) {
+  return (kind == K_NOISE || kind == K_WN) ? 1 : kind == K_RQ ? 2 + nd : (kind == K_SIN || kind == K_SM) ? 1 + 2 * nd : 1 + nd;
+}
+constexpr int slot_base(int L) {
+  int s = 0;
+  for (int l = 0; l < L; ++l) s += slots_of(jkind[l], jnd[l]);
+  return s;
+}
+constexpr int JNS = slot_base(JNL);
+constexpr int JNSA = JNS > 0 ? JNS : 1;
+constexpr int JNLA = JNL > 0 ? JNL : 1;
+static_assert(JNS == JNSLOTS, "slot layout");
+constexpr bool any_multi() {
+  for (int p = 0; p < JNP; ++p) if (jnfac[p] > 1) return true;
+  return false;
+}
+constexpr bool JMULTI = any_multi();
+
+// value of leaf L (variance included) for the pair -- g3_grad.hip::leaf_value with the kind folded
+template <int L>
+__device__ __forceinline__ double leaf_val(const jleaf& lf, const double* xi, const double* xj, bool diag) {
+  constexpr int kind = jkind[L], nd = jnd[L];
+  if constexpr (kind == K_NOISE || kind == K_WN) {
+    return diag ? lf.var : 0.0;
+  } else if constexpr (kind == K_SE || kind == K_MAT32 || kind == K_MAT52 || kind == K_RQ) {
+    double D = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double dx = xi[jdims[L][k]] - xj[jdims[L][k]];
+      D += (dx * dx) * (0.5 * lf.rate[k] * lf.rate[k]);
+    }
+    if constexpr (kind == K_SE) return lf.var * exp(-D);
+    if constexpr (kind == K_MAT32) { const double s = sqrt(3.0 * D); return lf.var * ((1.0 + s) * exp(-s)); }
+    if constexpr (kind == K_MAT52) { const double s = sqrt(5.0 * D); return lf.var * ((1.0 + s + 5.0 * D / 3.0) * exp(-s)); }
+    return lf.var * pow(1.0 + D / lf.alpha, -lf.alpha);
+  } else if constexpr (kind == K_OU) {
+    double D = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) D += fabs(xi[jdims[L][k]] - xj[jdims[L][k]]) * lf.rate[k];
+    return lf.var * exp(-D);
+  } else if constexpr (kind == K_SIN) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double v = sin(GG_PI * (xi[jdims[L][k]] - xj[jdims[L][k]]) * lf.freq[k]);
+      s += (v * v) * lf.rate[k];
+    }
+    return lf.var * exp(2.0 * s);
+  } else {     // COS, SINC, SM
+    constexpr bool sinc = kind == K_SINC;
+    constexpr double cs = sinc ? 2.0 * GG_PI * GG_PI : 2.0 * GG_PI;
+    double p = 1.0, s = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double dx = xi[jdims[L][k]] - xj[jdims[L][k]];
+      const double th = cs * dx * lf.freq[k];
+      p *= sinc ? (dx != 0.0 ? sin(th) / th : 1.0) : cos(th);
+      s += (dx * dx) * (lf.rate[k] * lf.rate[k]);
+    }
+    const double env = kind == K_SM ? exp(-2.0 * GG_PI * GG_PI * s) : 1.0;
+    return lf.var * (env * p);
+  }
+}
+
+// w * d(var * k)/d(param) for every parameter of leaf L into its slots -- g3_grad.hip::leaf_grad with the kind folded
+template <int L>
+__device__ __forceinline__ void leaf_grad(const jleaf& lf, const double* xi, const double* xj, bool diag, double w, double (&acc)[JNSA]) {
+  constexpr int kind = jkind[L], nd = jnd[L], s0 = slot_base(L);
+  const double var = lf.var;
+  const double wv = w * var;
+  if constexpr (kind == K_NOISE || kind == K_WN) {
+    if (diag) acc[s0] += w;
+  } else if constexpr (kind == K_SE || kind == K_MAT32 || kind == K_MAT52 || kind == K_RQ) {
+    constexpr int srate = s0 + (kind == K_RQ ? 2 : 1);
+    double D = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double dx = xi[jdims[L][k]] - xj[jdims[L][k]];
+      D += (dx * dx) * (0.5 * lf.rate[k] * lf.rate[k]);
+    }
+    double kv, dkdD;
+    if constexpr (kind == K_SE) {
+      kv = exp(-D); dkdD = -kv;
+    } else if constexpr (kind == K_MAT32) {
+      const double s = sqrt(3.0 * D), e = exp(-s);
+      kv = (1.0 + s) * e; dkdD = -1.5 * e;
+    } else if constexpr (kind == K_MAT52) {
+      const double s = sqrt(5.0 * D), e = exp(-s);
+      kv = (1.0 + s + 5.0 * D / 3.0) * e; dkdD = -(5.0 / 6.0) * (1.0 + s) * e;
+    } else {
+      const double al = lf.alpha, b = 1.0 + D / al;
+      kv = pow(b, -al); dkdD = -kv / b;
+      acc[s0 + 1] += wv * kv * (-log(b) + D / (al + D));
+    }
+    acc[s0] += w * kv;
+    const double c = wv * dkdD;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double dx = xi[jdims[L][k]] - xj[jdims[L][k]];
+      acc[srate + k] += c * lf.rate[k] * (dx * dx);
+    }
+  } else if constexpr (kind == K_OU) {
+    double D = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) D += fabs(xi[jdims[L][k]] - xj[jdims[L][k]]) * lf.rate[k];
+    const double kv = exp(-D);
+    acc[s0] += w * kv;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) acc[s0 + 1 + k] += -wv * kv * fabs(xi[jdims[L][k]] - xj[jdims[L][k]]);
+  } else if constexpr (kind == K_SIN) {
+    constexpr int sfreq = s0 + 1, srate = s0 + 1 + nd;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double v = sin(GG_PI * (xi[jdims[L][k]] - xj[jdims[L][k]]) * lf.freq[k]);
+      s += (v * v) * lf.rate[k];
+    }
+    const double kv = exp(2.0 * s);
+    acc[s0] += w * kv;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double dx = xi[jdims[L][k]] - xj[jdims[L][k]];
+      const double v = sin(GG_PI * dx * lf.freq[k]);
+      acc[srate + k] += wv * kv * 2.0 * (v * v);
+      acc[sfreq + k] += wv * kv * (2.0 * GG_PI) * lf.rate[k] * dx * sin(2.0 * GG_PI * dx * lf.freq[k]);
+    }
+  } else {     // COS, SINC, SM: value = env * prod_k f_k ; d/dfreq_m = env * f'_m * prod_{k != m} f_k
+    constexpr bool sinc = kind == K_SINC;
+    constexpr double cs = sinc ? 2.0 * GG_PI * GG_PI : 2.0 * GG_PI;
+    constexpr int sfreq = s0 + 1, srate = s0 + 1 + nd;
+    double p = 1.0, s = 0.0;
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+      const double dx = xi[jdims[L][k]] - xj[jdims[L][k]];
+      const double th = cs * dx * lf.freq[k];
+      p *= sinc ? (dx != 0.0 ? sin(th) / th : 1.0) : cos(th);
+      s += (dx * dx) * (lf.rate[k] * lf.rate[k]);
+    }
+    const double env = kind == K_SM ? exp(-2.0 * GG_PI * GG_PI * s) : 1.0;
+    const double kv = env * p;
+    acc[s0] += w * kv;
+#pragma unroll
+    for (int m = 0; m < nd; ++m) {
+      const double dx = xi[jdims[L][m]] - xj[jdims[L][m]];
+      const double th = cs * dx * lf.freq[m];
+      double fm, dfm;
+      if (sinc) {
+        fm = dx != 0.0 ? sin(th) / th : 1.0;
+        dfm = dx != 0.0 ? (cos(th) - fm) / lf.freq[m] : 0.0;
+      } else {
+        fm = cos(th);
+        dfm = -cs * dx * sin(th);
+      }
+      double others;
+      if (fm != 0.0) {
+        others = p / fm;
+      } else {
+        others = 1.0;
+#pragma unroll
+        for (int k = 0; k < nd; ++k) {
+          if (k == m) continue;
+          const double dk = xi[jdims[L][k]] - xj[jdims[L][k]];
+          const double tk = cs * dk * lf.freq[k];
+          others *= sinc ? (dk != 0.0 ? sin(tk) / tk : 1.0) : cos(tk);
+        }
+      }
+      acc[sfreq + m] += wv * env * dfm * others;
+      if constexpr (kind == K_SM) acc[srate + m] += wv * kv * (-4.0 * GG_PI * GG_PI) * (dx * dx) * lf.rate[m];
+    }
+  }
+}
+
+template <int L>
+__device__ __forceinline__ void all_vals(const jprog* __restrict__ prog, const double* xi, const double* xj, bool diag, double (&lv)[JNLA]) {
+  if constexpr (L < JNL) {
+    lv[L] = leaf_val<L>(prog->leaf[L], xi, xj, diag);
+    all_vals<L + 1>(prog, xi, xj, diag, lv);
+  }
+}
+
+// dK/d(leaf L) = sum over the products that contain it of coef * the other factors (first occurrence removed)
+template <int L>
+__device__ __forceinline__ double dk_dleaf(const jprog* __restrict__ prog, const double (&lv)[JNLA]) {
+  double q = 0.0;
+#pragma unroll
+  for (int p = 0; p < JNP; ++p) {
+    bool has = false;
+    double v = prog->prod[p].coef;
+#pragma unroll
+    for (int f = 0; f < JMAXFAC; ++f)
+      if (f < jnfac[p]) {
+        if (jfac[p][f] == L && !has) has = true;
+        else v *= lv[jfac[p][f]];
+      }
+    if (has) q += v;
+  }
+  return q;
+}
+
+template <int L>
+__device__ __forceinline__ void all_grads(const jprog* __restrict__ prog, const double* xi, const double* xj, bool diag, double g,
+                                          const double (&lv)[JNLA], double (&acc)[JNSA]) {
+  if constexpr (L < JNL) {
+    const double q = dk_dleaf<L>(prog, lv);
+    if (q != 0.0) leaf_grad<L>(prog->leaf[L], xi, xj, diag, g * q, acc);
+    all_grads<L + 1>(prog, xi, xj, diag, g, lv, acc);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(GG_THREADS)
+g3_grad_jit(const jprog* __restrict__ prog, const T* __restrict__ X, i64 N, i64 ldx, const T* __restrict__ G, i64 ldg,
+            const T* __restrict__ alpha, double* __restrict__ partial, i64 row0, i64 row1, i64 gstride, i64 astride) {
+  // rows [row0, row1) of the lower triangle; grid.y = batch member (its program, K^-1, alpha, partial sums)
+  prog += blockIdx.y;
+  G += (i64)blockIdx.y * gstride;
+  alpha += (i64)blockIdx.y * astride;
+  partial += (size_t)blockIdx.y * gridDim.x * JNSA;
+  constexpr int dp = JD | 1;
+  __shared__ double xi_s[GG_T * dp], xj_s[GG_T * dp], ai_s[GG_T], aj_s[GG_T];
+  __shared__ double red[JNSA * (GG_THREADS / 64)];
+  const int tid = threadIdx.x;
+  double acc[JNSA];
+#pragma unroll
+  for (int s = 0; s < JNSA; ++s) acc[s] = 0.0;
+  const i64 bi0 = row0 / GG_T, bi1 = (row1 + GG_T - 1) / GG_T;
+  const i64 id0 = bi0 * (bi0 + 1) / 2, ntiles = bi1 * (bi1 + 1) / 2 - id0;
+  for (i64 idl = blockIdx.x; idl < ntiles; idl += gridDim.x) {
+    const i64 id = id0 + idl;
+    i64 bi = (i64)((sqrt(1.0 + 8.0 * (double)id) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
+    while (bi * (bi + 1) / 2 > id) --bi;
+    const i64 bj = id - bi * (bi + 1) / 2;
+    const i64 i0 = bi * GG_T, j0 = bj * GG_T;
+    __syncthreads();
+    for (int e = tid; e < GG_T * JD; e += GG_THREADS) {
+      const int r = e / JD, c = e - r * JD;
+      xi_s[r * dp + c] = i0 + r < row1 ? (double)X[(i0 + r) * ldx + c] : 0.0;
+      xj_s[r * dp + c] = j0 + r < N ? (double)X[(j0 + r) * ldx + c] : 0.0;
+    }
+    if (tid < GG_T) ai_s[tid] = i0 + tid < row1 ? (double)alpha[i0 + tid] : 0.0;
+    else if (tid < 2 * GG_T) aj_s[tid - GG_T] = j0 + tid - GG_T < N ? (double)alpha[j0 + tid - GG_T] : 0.0;
+    __syncthreads();
+    const int c = tid & (GG_T - 1);
+    const i64 j = j0 + c;
+    double xj[JD];
+#pragma unroll
+    for (int q = 0; q < JD; ++q) xj[q] = xj_s[c * dp + q];
+    for (int rr = tid >> 6; rr < GG_T; rr += GG_THREADS / GG_T) {
+      const i64 i = i0 + rr;
+      if (i >= row1 || j > i) continue;
+      const bool diag = i == j;
+      const double* xi = xi_s + rr * dp;
+      const double g = (diag ? 0.5 : 1.0) * (ai_s[rr] * aj_s[c] - (double)G[(i - row0) * ldg + j]);
+      double lv[JNLA];
+      if constexpr (JMULTI) all_vals<0>(prog, xi, xj, diag, lv);
+      else {
+#pragma unroll
+        for (int l = 0; l < JNLA; ++l) lv[l] = 1.0;
+      }
+      all_grads<0>(prog, xi, xj, diag, g, lv, acc);
+    }
+  }
+  // block reduction
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int s = 0; s < JNS; ++s) {
+    double v = acc[s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[s * (GG_THREADS / 64) + wv] = v;
+  }
+  __syncthreads();
+  if (tid < JNS) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < GG_THREADS / 64; ++q) v += red[tid * (GG_THREADS / 64) + q];
+    partial[(size_t)blockIdx.x * JNSA + tid] = v;
+  }
+}
+)JIT";
+
 // ---- hipRTC, loaded on demand
 struct Rtc {
   void* h = nullptr;
@@ -313,22 +612,23 @@ std::string structure_tables(const g3_kernel_prog* p, int d, int* ntrig_out) {
 }
 
 // compile the source specialised by `tables` for gfx950; 0 = ok (code object in *code), else the compiler's log   (g_mu held)
-int compile_structure(const std::string& tables, g3_dtype dt, std::string* code, std::string* log) {
+int compile_structure(const std::string& tables, g3_dtype dt, std::string* code, std::string* log, int grad_slots = -1) {
   Rtc* r = rtc();
   if (!r) { *log = "libhiprtc not available"; return -1; }
-  std::string src = kJitSource;
+  std::string src = grad_slots >= 0 ? kJitGradSource : kJitSource;     // grad_slots >= 0: the gradient kernel, with its slot count
   src.replace(src.find("JTABLES"), 7, tables);
   void* pr = nullptr;
   if (r->CreateProgram(&pr, src.c_str(), "g3_gram_jit.hip", 0, nullptr, nullptr) != 0) { *log = "hiprtcCreateProgram failed"; return -2; }
-  char o1[64], o2[64], o3[64], o4[64], o5[64], o6[64];
+  char o1[64], o2[64], o3[64], o4[64], o5[64], o6[64], o7[64];
+  snprintf(o7, sizeof(o7), "-DJNSLOTS=%d", grad_slots >= 0 ? grad_slots : 0);
   snprintf(o1, sizeof(o1), "-DJT=%s", dt == G3_F64 ? "double" : "float");
   snprintf(o2, sizeof(o2), "-DJMAXD=%d", G3_MAXD);
   snprintf(o3, sizeof(o3), "-DJMAXLEAF=%d", G3_MAXLEAF);
   snprintf(o4, sizeof(o4), "-DJMAXPROD=%d", G3_MAXPROD);
   snprintf(o5, sizeof(o5), "-DJMAXFAC=%d", G3_MAXFAC);
   snprintf(o6, sizeof(o6), "-DJPROG_BYTES=%d", (int)sizeof(g3_kernel_prog));
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", o1, o2, o3, o4, o5, o6};
-  const int cr = r->CompileProgram(pr, 9, opts);
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", o1, o2, o3, o4, o5, o6, o7};
+  const int cr = r->CompileProgram(pr, 10, opts);
   size_t ls = 0;
   r->GetProgramLogSize(pr, &ls);
   if (ls > 1) { log->assign(ls, '\0'); r->GetProgramLog(pr, &(*log)[0]); }
@@ -344,7 +644,61 @@ int compile_structure(const std::string& tables, g3_dtype dt, std::string* code,
   return rc;
 }
 
+// the number of slots of g3_grad_layout's standard map for this program (what the generated gradient kernel accumulates)
+int std_grad_slots(const g3_kernel_prog* p) {
+  int s = 0;
+  for (int l = 0; l < p->nleaf; ++l) {
+    const int kd = p->leaf[l].kind, nd = p->leaf[l].ndims;
+    s += (kd == G3_K_NOISE || kd == G3_K_WN) ? 1 : kd == G3_K_RQ ? 2 + nd : (kd == G3_K_SIN || kd == G3_K_SM) ? 1 + 2 * nd : 1 + nd;
+  }
+  return s;
+}
+
 }  // namespace
+
+extern "C" int g3_grad_jit_check(const g3_kernel_prog* prog, int d, g3_dtype dt, int64_t* code_bytes, char* log, int64_t log_bytes) {
+  if (!prog) return -1;
+  if (g3i_validate_prog(prog, d)) return -2;
+  int ntrig = 0;
+  const std::string tables = structure_tables(prog, d, &ntrig);
+  std::string code, lg;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int rc = compile_structure(tables, dt, &code, &lg, std_grad_slots(prog));
+  if (code_bytes) *code_bytes = (int64_t)code.size();
+  if (log && log_bytes > 0) snprintf(log, (size_t)log_bytes, "%s", lg.c_str());
+  return rc;
+}
+
+// The generated gradient kernel (g3_grad_jit) for (prog's structure, d, dtype) on the context's device, compiled at first use
+// and cached; nullptr when there is none (no hipRTC, more than G3_GRAD_JIT_MAXSLOTS register accumulators, a failed
+// compilation: the caller interprets).  *nslots: the standard slot count the kernel accumulates.
+hipFunction_t g3i_grad_jit_function(g3_ctx* ctx, const g3_kernel_prog* prog_host, int d, g3_dtype dt, int* nslots) {
+  if (ctx->tune.grad_interpret || !ctx->tune.gram_jit) return nullptr;
+  const int ns = std_grad_slots(prog_host);
+  *nslots = ns;
+  if (ns < 1 || ns > G3_GRAD_JIT_MAXSLOTS) return nullptr;
+  int ntrig = 0;
+  const std::string tables = structure_tables(prog_host, d, &ntrig);
+  const std::string key = std::to_string(ctx->device) + (dt == G3_F64 ? "|f64|grad|" : "|f32|grad|") + tables;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) return it->second.failed ? nullptr : it->second.fn;
+  Entry ent;
+  ent.failed = true;
+  std::string code, log;
+  if (compile_structure(tables, dt, &code, &log, ns) == 0) {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, "g3_grad_jit") == hipSuccess) {
+      ent.fn = fn;
+      ent.failed = false;
+    }
+  } else if (getenv("G3_JIT_VERBOSE")) {
+    fprintf(stderr, "libg3hip: generated gradient kernel did not compile:\n%s\n", log.c_str());
+  }
+  g_cache[key] = ent;
+  return ent.failed ? nullptr : ent.fn;
+}
 
 // No GPU needed: does the kernel generated for this expression compile for gfx950?  Returns 0 and the code object's size,
 // or the compiler's status with its log (tests/test_host.py runs the whole kernel zoo through it on the build host).

@@ -21,6 +21,7 @@ struct g3_ctx {
   int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
   G3hTune tune;            // tuning knobs, read from the environment once at g3_ctx_create
   unsigned long long gram_paths[3];   // Gram launches so far: compile-time table, generated at first use, interpreted
+  unsigned long long grad_paths[3];   // the same for the gradient's kernel-parameter sums
   FILE* gemm_log;          // G3_GEMM_LOG=<file>: one line per MFMA GEMM / stripe-solve launch (scripts/launch_table.py)
   bool info_clean;         // d_info is known to be zero: left so by a synchronised evaluation (info_stream == nullptr and
                            // info_sync), or cleared on info_stream with no factorisation queued since (g3i_reset_info)
@@ -181,6 +182,9 @@ int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_d
 int g3i_gram_grad(g3_ctx* ctx, const g3_kernel_prog* prog, const g3_grad_map* map, const void* X, int64_t N, int64_t ldx,
                   int d, g3_dtype dt, const void* G, int64_t ldg, const void* alpha, double* out_host,
                   int64_t row0 = 0, int64_t nrows = -1);
+// generated gradient kernel (g3_gram_jit.hip); at most this many register accumulators per thread
+#define G3_GRAD_JIT_MAXSLOTS 40
+hipFunction_t g3i_grad_jit_function(g3_ctx* ctx, const g3_kernel_prog* prog_host, int d, g3_dtype dt, int* nslots);
 int g3i_gram_grad_batched(g3_ctx* ctx, const g3_kernel_prog* progs, int batch, const g3_grad_map* map, const void* X, int64_t N,
                           int64_t ldx, int d, g3_dtype dt, const void* G, int64_t ldg, int64_t gstride, const void* alpha,
                           int64_t astride, double* out_host, int64_t row0 = 0, int64_t nrows = -1);

@@ -197,6 +197,12 @@ class Device:
         _check(self, self.lib.g3_gram_path_stats(self.ctx, out), 'g3_gram_path_stats')
         return {'table': int(out[0]), 'generated': int(out[1]), 'interpreted': int(out[2])}
 
+    def grad_path_stats(self):
+        """the same for the gradient's kernel-parameter sums"""
+        out = (C.c_double * 3)()
+        _check(self, self.lib.g3_grad_path_stats(self.ctx, out), 'g3_grad_path_stats')
+        return {'table': int(out[0]), 'generated': int(out[1]), 'interpreted': int(out[2])}
+
     # ---- kernels (thin, argument-checked wrappers)
     def gram(self, prog, X1, X2, d, out, n1pad, n2pad, flags):
         dt = _lib.dtype_code(out.dtype)

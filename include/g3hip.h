@@ -143,9 +143,14 @@ int g3_cov_lift(g3_ctx* ctx, void* K_dev, int64_t n, int64_t ld, g3_dtype dt);
  * KernelSum / KernelProd / KernelScale / KernelShift tree, kernels.py:192-244), interpreted].  G3_GRAM_JIT=0 or a
  * missing libhiprtc leaves the interpreter; all three evaluate the same formulas. */
 int g3_gram_path_stats(g3_ctx* ctx, double out_host[3]);
+/* The same three counters for the kernel-parameter sums of the gradient (g3_gram_grad, g3_gp_dlogp*): compile-time table,
+ * generated at first use (g3_gram_jit.hip::g3_grad_jit), interpreted. */
+int g3_grad_path_stats(g3_ctx* ctx, double out_host[3]);
 /* Build-host check (no GPU, no context): does the kernel generated for this expression compile for gfx950?  0 and the
  * size of the code object, or hipRTC's status and its log (-1: libhiprtc not available). */
 int g3_gram_jit_check(const g3_kernel_prog* prog_host, int d, g3_dtype dt, int64_t* code_bytes, char* log, int64_t log_bytes);
+/* The same for the generated kernel of the kernel-parameter sums of the gradient (g3_gram_grad and the dlogp entry points). */
+int g3_grad_jit_check(const g3_kernel_prog* prog, int d, g3_dtype dt, int64_t* code_bytes, char* log, int64_t log_bytes);
 /* tt_to_num over a dense n1 x n2 matrix (tensors.py:90-92) */
 int g3_scrub(g3_ctx* ctx, void* A_dev, int64_t n1, int64_t n2, int64_t ld, g3_dtype dt);
 

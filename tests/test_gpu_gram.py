@@ -422,3 +422,46 @@ def test_no_zoo_expression_is_interpreted_and_generated_equals_interpreted(golde
     assert s0['generated'] == 0 and s0['table'] == 0 and s0['interpreted'] > 0, s0
     dev0.close()
     dev1.close()
+
+
+@pytest.mark.gpu
+def test_gradient_sums_generated_equal_interpreted_and_no_zoo_expression_is_interpreted(monkeypatch):
+    """the kernel-parameter sums of the gradient run a compile-time kernel for every zoo expression -- the table of
+    g3_grad.hip or one generated for the expression's structure (g3_gram_jit.hip::g3_grad_jit) -- and the generated kernel
+    gives what the interpreter gives (same formulas; the sums differ only in their order: 1e-11 of the absolute sum);
+    a custom map (slots skipped / permuted) is honoured; members of a batch each get their own program"""
+    import g3py_amd as g3
+    from g3py_amd.device import compile_spec
+    dev1 = g3.Device(0)
+    monkeypatch.setenv('G3_GRAM_JIT', '0')
+    dev0 = g3.Device(0)                      # table + interpreter only
+    rng = np.random.default_rng(11)
+    for d in (1, 3, 8):
+        N = 190
+        X = rng.uniform(0, 4, (N, d))
+        X[9] = X[2]
+        A = rng.standard_normal((N, N))
+        G = np.tril((A + A.T) / 2)
+        alpha = rng.standard_normal(N)
+        for name, spec in _grad_zoo(d).items():
+            prog = compile_spec(spec, d)
+            outs = []
+            for dev in (dev1, dev0):
+                gmap = dev.grad_layout(prog)
+                outs.append(dev.gram_grad(prog, gmap, dev.upload(X), N, d, dev.upload(G), dev.upload(alpha)))
+            scale = np.abs(outs[1]).max() + 1e-30
+            np.testing.assert_allclose(outs[0], outs[1], rtol=1e-9, atol=1e-11 * scale, err_msg='%s d=%d' % (name, d))
+            if name == '(SE+OU)*(MAT32+0.5)':            # a custom map: only the OU leaf's rates and the MAT32 variance
+                gmap = dev1.grad_layout(prog)
+                full = outs[0]
+                want = np.concatenate([full[gmap.rate[1]:gmap.rate[1] + d], [full[gmap.var[2]]]])
+                for l in range(prog.nleaf):
+                    gmap.var[l] = gmap.alpha[l] = gmap.rate[l] = gmap.freq[l] = -1
+                gmap.rate[1], gmap.var[2], gmap.nslots = 0, d, d + 1
+                got = dev1.gram_grad(prog, gmap, dev1.upload(X), N, d, dev1.upload(G), dev1.upload(alpha))
+                np.testing.assert_array_equal(got, want)
+    s1, s0 = dev1.grad_path_stats(), dev0.grad_path_stats()
+    assert s1['interpreted'] == 0 and s1['generated'] > 0 and s1['table'] > 0, s1
+    assert s0['generated'] == 0 and s0['interpreted'] > 0, s0
+    dev0.close()
+    dev1.close()

@@ -223,6 +223,29 @@ def test_generated_gram_kernel_compiles_for_every_zoo_expression():
     assert n >= 45
 
 
+def test_generated_gradient_kernel_compiles_for_every_zoo_expression():
+    """the kernel of the gradient's kernel-parameter sums is generated per expression structure too
+    (g3_gram_jit.hip::g3_grad_jit: register accumulators at compile-time slot indices): every zoo expression compiles for
+    gfx950 on the build host"""
+    import ctypes as C
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    from oracle.gen_golden import kernel_zoo
+    lib = _lib.load()
+    n = 0
+    for d in (1, 3, 8):
+        for name, spec in kernel_zoo(d).items():
+            for dt in ((0, 1) if name in ('SINC', '(SE+OU)*(MAT32+0.5)') else (0,)):
+                prog = compile_spec(spec, d)
+                cb, log = C.c_int64(0), C.create_string_buffer(8000)
+                rc = lib.g3_grad_jit_check(C.byref(prog), d, dt, C.byref(cb), log, 8000)
+                if rc == -1:
+                    pytest.skip('libhiprtc is not available on this host')
+                assert rc == 0 and cb.value > 1000, (d, name, dt, rc, log.value.decode()[:3000])
+                n += 1
+    assert n >= 40
+
+
 def test_chain_rows_packing_equals_row_by_row():
     """logp_chain's block path: one template program + per-row fields (compile_spec_rows, _values_rows, the `rows`
     forms of the mean and the warp) against the one-row-at-a-time host path, byte for byte where that is defined."""
