@@ -188,6 +188,8 @@ struct g3_dist {
   char* avec = nullptr;         // 1 x Np: a = L^-1 delta, broadcast for the mean
   char* dots = nullptr;         // 2 x 128 scratch of rows_dot_ss, one pair per right-hand-side chunk of this rank
   double* blkstats = nullptr;   // 4 doubles per owned block: per-block reductions stay on the device until ONE copy fetches them
+  std::vector<char> xs_seen;    // the prediction points of the last evaluation (M x d, packed): the cross-solve rows V in the
+                                // driver belong to THEM, and posterior_cov / draws refuse any other Xs
   int* info_dev = nullptr;
   double phase_calls[2] = {0, 0}, phase_ms[2] = {0, 0};   // as of the last g3_dist_comm_stats
   bool serial_coll = false;     // G3_DIST_SERIAL_COLL=1 (read at creation): the two communicators are never in flight together
@@ -1066,6 +1068,27 @@ static int stats(g3_dist* D, double* logdet, double* quad, double* mean, double*
   return G3_OK;
 }
 
+// packed host copy of the M x d prediction points (a few tens of KB)
+static int fetch_xs(g3_dist* D, const void* Xs_dev, int64_t ldxs, std::vector<char>* out) {
+  out->resize((size_t)D->M * D->d * D->es);
+  if (out->empty()) return G3_OK;
+  G3D_HIP(hipMemcpy2DAsync(out->data(), (size_t)D->d * D->es, Xs_dev, (size_t)ldxs * D->es, (size_t)D->d * D->es, (size_t)D->M,
+                           hipMemcpyDeviceToHost, D->ctx->stream));
+  G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+  return G3_OK;
+}
+static int same_xs_as_evaluated(g3_dist* D, const void* Xs_dev, int64_t ldxs) {
+  std::vector<char> now;
+  int rc = fetch_xs(D, Xs_dev, ldxs, &now);
+  if (rc) return rc;
+  if (now.size() != D->xs_seen.size() || (now.size() && memcmp(now.data(), D->xs_seen.data(), now.size()) != 0)) {
+    snprintf(D->err, sizeof(D->err), "the cross-solve rows in the driver belong to other prediction points: evaluate "
+             "g3_dist_gp_factor_predict with these Xs first");
+    return -3;
+  }
+  return G3_OK;
+}
+
 extern "C" int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* prog_cross, const void* X_dev,
                                          int64_t ldx, const void* delta_dev, const void* Xs_dev, int64_t ldxs, double out_host[5],
                                          double* mean_host, double* ss_host) {
@@ -1094,6 +1117,10 @@ extern "C" int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog,
   out_host[3] = (double)D->last_tries;
   out_host[4] = (double)D->last_fallback;
   for (int64_t i = 0; i < D->M; ++i) { mean_host[i] = mm[i]; ss_host[i] = sv[i]; }
+  if (D->M > 0) {
+    rc = fetch_xs(D, Xs_dev, ldxs, &D->xs_seen);
+    if (rc) return mark_failed(D, rc);
+  }
   return G3_OK;
 }
 
@@ -1199,6 +1226,8 @@ extern "C" int g3_dist_posterior_cov(g3_dist* D, const g3_kernel_prog* prog, con
   if (!cov_dev) return -5;
   if (ldc < D->Mp) return -6;
   g3_dev_guard _dg(D->ctx);
+  int rcx = same_xs_as_evaluated(D, Xs_dev, ldxs);
+  if (rcx) return rcx;
   return posterior_cov(D, prog, Xs_dev, ldxs, (char*)cov_dev, ldc);
 }
 
@@ -1216,6 +1245,10 @@ extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f,
   if (!out_host) return -8;
   if (g3i_validate_prog(prog_f, D->d)) return -2;
   g3_dev_guard _dg(D->ctx);
+  {
+    const int rcx = same_xs_as_evaluated(D, Xs_dev, ldxs);
+    if (rcx) return rcx;
+  }
   const int64_t M = D->M, Mp = D->Mp;
   const size_t es = D->es;
   hipStream_t s = D->ctx->stream;

@@ -451,7 +451,8 @@ int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog_noise, cons
  * covariance, without for the f process -- NOISE / WN leaves act on the true diagonal as in kernel.cov(Xs)), from the
  * last g3_dist_gp_factor_predict at the same Xs: every rank forms the lower part of the rows of its chunks, the matrix
  * is all-gathered and mirrored, and EVERY rank's cov_dev (roundup(M,128) square, row stride ldc, zero outside M x M)
- * receives the full symmetric matrix. */
+ * receives the full symmetric matrix.  The driver remembers the prediction points of its last evaluation: any other
+ * Xs is refused (-3, text in g3_dist_last_error) instead of being combined with cross-solve rows that belong elsewhere. */
 int g3_dist_posterior_cov(g3_dist* D, const g3_kernel_prog* prog, const void* Xs_dev, int64_t ldxs, void* cov_dev,
                           int64_t ldc);
 

@@ -584,3 +584,38 @@ def test_eight_rank_schedule_at_the_full_headline_size_reproduces_the_oracle_pin
     # what a rank would receive: (P - 1) / P of the lower triangle in panels + the diagonal factors it does not own
     assert 4.0e9 < min(recv) and max(recv) < 5.5e9, recv
     dev.close()
+
+
+def test_posterior_covariance_refuses_other_prediction_points():
+    """the cross-solve rows V = K(Xs, X) L^-T live in the driver from the last evaluation: g3_dist_posterior_cov / _draws
+    at any OTHER Xs would silently combine K(Xs', Xs') with the V of Xs -- the driver remembers the points it evaluated
+    and refuses; at the same points the covariance equals the oracle's"""
+    import g3py_amd as g3
+    from g3py_amd.distributed import NativeDistributedGP
+    from g3py_amd import _lib
+    from oracle import g3_oracle as orc
+    N, d, M = 500, 2, 70
+    X, y, Xs = synth(N, d, M, 91)
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    spec_n = orc.with_noise(spec_f, 0.1)
+    dev = g3.Device.default()
+    Xd, Xsd, yd = dev.upload(X), dev.upload(Xs), dev.upload(y)
+    gp = NativeDistributedGP(dev, None, 0, 1, N, d, M, nb=256, transport='callbacks')
+    gp.step(spec_n, spec_f, Xd, Xsd, yd)
+    Mp = _lib.roundup(M)
+    out = dev.alloc(Mp, Mp, np.float64)
+    gp.posterior_cov(spec_f, Xsd, out)
+    cov = dev.download(out, M, M)
+    Kxx = orc.kernel_cov(spec_f, X, None, np.float64) + 0.1 * np.eye(N)
+    Ksx = orc.kernel_cov(spec_f, Xs, X, np.float64)
+    want = orc.kernel_cov(spec_f, Xs, None, np.float64) - Ksx @ np.linalg.solve(Kxx, Ksx.T)
+    np.testing.assert_allclose(cov, want, atol=1e-9)
+    Xs2 = Xs.copy()
+    Xs2[3, 0] += 1e-3
+    with pytest.raises(g3.G3Error, match='other prediction points'):
+        gp.posterior_cov(spec_f, dev.upload(Xs2), out)
+    with pytest.raises(g3.G3Error, match='other prediction points'):
+        gp.draws(spec_f, dev.upload(Xs2), np.zeros(M), np.zeros((M, 2)))
+    gp.step(spec_n, spec_f, Xd, dev.upload(Xs2), yd)            # evaluated there: accepted now
+    gp.posterior_cov(spec_f, dev.upload(Xs2), out)
+    gp.close()
