@@ -285,7 +285,6 @@ class GaussianProcess(EllipticalProcess):
         """_chain_rule for B rows at once: slots (B, nslots), alphas (B, N); rows with ok False get no likelihood term"""
         from ..device import spec_leaves
         by_name = {v.name: v for v in self.model.vars}
-        okf = ok.astype(np.float64)
         with np.errstate(all='ignore'):
             slots = np.where(ok[:, None], slots, 0.0)
             alphas = np.where(ok[:, None], alphas, 0.0)
