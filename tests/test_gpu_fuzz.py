@@ -113,3 +113,88 @@ def test_random_shape_gradient_matches_oracle(dev, case):
         want, scale = 0.5 * np.sum(G * dK), 0.5 * np.sum(np.abs(G * dK)) + 1e-30
         got = slots[getattr(gmap, pname)[leaf] + (0 if k is None else k)]
         assert abs(got - want) < 1e-8 * scale, (N, d, spec_n, leaf, pname, k, got, want)
+
+
+def _random_tree(rng, d, depth=0):
+    """a random kernel expression: leaves of every family, sums / products / scales / shifts up to depth 3, with column
+    subsets -- within one g3_kernel_prog's limits (checked by the caller)"""
+    rate = np.exp(rng.uniform(-0.6, 0.4, d))
+    freq = rng.uniform(0.05, 0.3, d)
+
+    def leaf():
+        kind = str(rng.choice(['SE', 'OU', 'MAT32', 'MAT52', 'RQ', 'COS', 'SIN', 'SINC', 'SM', 'WN']))
+        nd = int(rng.integers(1, d + 1))
+        dims = None if nd == d else np.sort(rng.choice(d, nd, replace=False))
+        r, f = (rate, freq) if dims is None else (rate[dims], freq[dims])
+        var = float(rng.uniform(0.3, 1.5))
+        if kind in ('SE', 'OU', 'MAT32', 'MAT52'):
+            return (kind, var, r, dims)
+        if kind == 'RQ':
+            return (kind, var, r, float(rng.uniform(0.8, 3.0)), dims)
+        if kind in ('COS', 'SINC'):
+            return (kind, var, f, dims)
+        if kind in ('SIN', 'SM'):
+            return (kind, var, f, 0.3 * r, dims)
+        return ('WN', var, dims)
+    if depth >= 3 or rng.uniform() < 0.25 + 0.2 * depth:
+        return leaf()
+    op = str(rng.choice(['sum', 'prod', 'scale', 'shift'], p=[0.4, 0.35, 0.15, 0.1]))
+    if op in ('sum', 'prod'):
+        return (op, _random_tree(rng, d, depth + 1), _random_tree(rng, d, depth + 1))
+    return (op, float(rng.uniform(0.3, 2.0)), _random_tree(rng, d, depth + 1))
+
+
+@pytest.mark.parametrize('seed', [20260, 7, 424242])
+def test_random_expressions_generated_kernels_equal_the_interpreter(monkeypatch, seed):
+    """random kernel expression trees (every leaf family, column subsets, sums / products / scales / shifts): the Gram
+    kernel and the gradient kernel GENERATED for the expression's structure (g3_gram_jit.hip) against the interpreter
+    on a second context (G3_GRAM_JIT=0, G3_GRAM_NOFAST=1, G3_GRAD_GENERIC=1), square and cross blocks"""
+    import g3py_amd as g3
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec, G3Error
+    dev1 = g3.Device(0)
+    monkeypatch.setenv('G3_GRAM_JIT', '0')
+    monkeypatch.setenv('G3_GRAM_NOFAST', '1')
+    monkeypatch.setenv('G3_GRAD_GENERIC', '1')
+    dev0 = g3.Device(0)
+    rng = np.random.default_rng(seed)
+    done = 0
+    for trial in range(60):
+        if done >= 10:
+            break
+        d = int(rng.integers(1, 5))
+        spec = _random_tree(rng, d)
+        try:
+            prog = compile_spec(spec, d)
+        except G3Error:
+            continue                      # more leaves / products than one program holds
+        if prog.nleaf < 2:
+            continue
+        done += 1
+        N, M = int(rng.integers(70, 260)), int(rng.integers(3, 90))
+        X, Xs = rng.uniform(0, 4, (N, d)), rng.uniform(0, 4, (M, d))
+        X[5] = X[1]
+        Np, Mp = _lib.roundup(N), _lib.roundup(M)
+        got = []
+        for dev in (dev1, dev0):
+            Xd, Xsd = dev.upload(X), dev.upload(Xs)
+            K = dev.alloc(Np, Np, np.float64)
+            dev.gram(prog, Xd, None, d, K, Np, Np, 0)
+            C = dev.alloc(Mp, Np, np.float64)
+            dev.gram(prog, Xsd, Xd, d, C, Mp, Np, 0)
+            A = rng.standard_normal((N, N)) if dev is dev1 else A
+            alpha = rng.standard_normal(N) if dev is dev1 else alpha
+            gmap = dev.grad_layout(prog)
+            g = dev.gram_grad(prog, gmap, Xd, N, d, dev.upload(np.tril((A + A.T) / 2)), dev.upload(alpha))
+            got.append((dev.download(K, N, N), dev.download(C, M, N), g))
+        (K1, C1, g1), (K0, C0, g0) = got
+        np.testing.assert_allclose(K1, K0, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(K0).max()), err_msg=repr(spec))
+        np.testing.assert_allclose(C1, C0, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(C0).max()), err_msg=repr(spec))
+        np.testing.assert_allclose(g1, g0, rtol=1e-8, atol=1e-10 * (np.abs(g0).max() + 1e-30), err_msg=repr(spec))
+    assert done >= 8
+    s1, s0 = dev1.gram_path_stats(), dev0.gram_path_stats()
+    assert s1['interpreted'] == 0 and s0['generated'] == 0 and s0['table'] == 0, (s1, s0)
+    q1, q0 = dev1.grad_path_stats(), dev0.grad_path_stats()
+    assert q1['generated'] > 0 and q0['generated'] == 0 and q0['table'] == 0 and q0['interpreted'] > 0, (q1, q0)
+    dev0.close()
+    dev1.close()
