@@ -198,3 +198,43 @@ def test_random_expressions_generated_kernels_equal_the_interpreter(monkeypatch,
     assert q1['generated'] > 0 and q0['generated'] == 0 and q0['table'] == 0 and q0['interpreted'] > 0, (q1, q0)
     dev0.close()
     dev1.close()
+
+
+@pytest.mark.parametrize('seed', list(range(1, 13)))
+def test_random_processes_chain_block_paths_equal_row_by_row(seed):
+    """random processes through the public API -- kernel objects combined with + and *, every mean and warp on the path,
+    Gaussian and Student-t -- logp_chain / dlogp_chain (block host path, template + fields, members in grid.y) against
+    one logp / dlogp per row"""
+    import g3py_amd as g3
+    rng = np.random.default_rng(seed)
+    N, d = int(rng.integers(40, 300)), int(rng.integers(1, 4))
+    X = rng.uniform(0, 4, (N, d))
+    y = np.exp(0.3 * np.sin(X.sum(1))) + 0.03 * rng.standard_normal(N) + 1.0
+    fams = [g3.SE, g3.OU, g3.MAT32, g3.MAT52, g3.RQ, g3.COS, g3.SM]
+
+    def kern(i):
+        return fams[int(rng.integers(len(fams)))](X, name='K%d' % i)
+    k = kern(0)
+    for i in range(1, int(rng.integers(1, 4))):
+        k = (k + kern(i)) if rng.uniform() < 0.6 else (k * kern(i))
+    if rng.uniform() < 0.3:
+        k = float(rng.uniform(0.5, 2.0)) * k
+    mean = [g3.Zero, g3.Bias, g3.Linear][int(rng.integers(3))](X)
+    warp = [None, g3.LinearMapping, g3.BoxCoxLinear, g3.LogShifted, g3.ArcsinhLinear][int(rng.integers(5))]
+    student = rng.uniform() < 0.35
+    if warp is None:
+        cls = g3.StudentTProcess if student else g3.GaussianProcess
+        gp = cls(space=X[:3], location=mean, kernel=k)
+    else:
+        cls = g3.WarpedStudentTProcess if student else g3.WarpedGaussianProcess
+        gp = cls(space=X[:3], location=mean, kernel=k, mapping=warp(y))
+    gp.observed(X, y)
+    base = gp.active.dict_to_array(gp.params)
+    chain = base[None, :] + 0.08 * rng.standard_normal((6, len(base)))
+    want = np.array([gp.logp(c, array=True) for c in chain], dtype=np.float64)
+    got = np.asarray(gp.logp_chain(chain, batch=4), dtype=np.float64)
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(got)) and fin.sum() >= 4, (want, got)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
+    ref = np.array([gp.dlogp(c, array=True) for c in chain])
+    np.testing.assert_allclose(gp.dlogp_chain(chain, batch=4), ref, rtol=2e-7, atol=1e-7 * (np.abs(ref).max() + 1.0))
