@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/midchain; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for N in 1024 2048; do
+for N in ${NS:-1024 2048}; do
 rm -rf $OUT/t$N
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t$N -- python3 $R/scripts/r4_midchain_one.py $N 96 2>&1 | grep "N="
 f=$(ls $OUT/t$N/*/*kernel_stats.csv | head -1)
