@@ -90,6 +90,8 @@ _SIGS = {
     'g3_potrf_robust': ([_P, _P, _I64, _P, _I64, _I64, C.c_int, C.c_int, C.POINTER(C.c_int),
                          C.POINTER(C.c_int), C.POINTER(C.c_double)], C.c_int),
     'g3_trsm_rlt': ([_P, _P, _I64, _I64, _P, _I64, _I64, C.c_int, _P], C.c_int),
+    'g3_trtri_full': ([_P, _P, _I64, _P, _P, _P, _P, C.c_int], C.c_int),
+    'g3_trsm_full': ([_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, C.c_int], C.c_int),
     'g3_logp_terms': ([_P, _P, _I64, _I64, _P, C.c_int, C.POINTER(C.c_double)], C.c_int),
     'g3_diag_stats': ([_P, _P, _I64, _I64, C.c_int, C.POINTER(C.c_double)], C.c_int),
     'g3_diag_add': ([_P, _P, _I64, _I64, C.c_int, C.c_double], C.c_int),

@@ -26,21 +26,17 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   // measured, a bulk stream WITHOUT the low priority costs 2 % (N = 8192) to 10 % (N = 32768) of the step
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
-  // chain server (g3_potrf.hip): the chain of a sweep on resident workgroups.  OFF unless G3_CHAIN=1: what it gains
-  // (the 512-block chain step 0.45 -> 0.24 ms in-sweep, N <= 8192 4 ... 15 % faster) depends on which compute pipe the
-  // hardware queues of its streams land on, which HIP gives no control over -- an unlucky placement costs 2x (DESIGN.md
-  // section 4).  The knobs are read ONCE here: G3_CHAIN_WGS workgroups of a server launch, G3_CHAIN_LDS bytes of LDS each
-  // asks for, G3_CHAIN_MIN_N / G3_CHAIN_MAX_N the matrices it is used for.
-  // (its streams and control block are created at the first chain sweep, g3_potrf.hip)
   ctx->tune = g3h_tune_from_env();
   {
     const char* lg = getenv("G3_GEMM_LOG");
     ctx->gemm_log = (lg && *lg) ? fopen(lg, "a") : nullptr;
   }
+#ifdef G3_CHAIN_SERVER   // measurement variant (scripts/variants/chain_server.inc): G3_CHAIN=1 puts the chain of a sweep on resident workgroups
   ctx->chain_wgs = g3h_env_int("G3_CHAIN", 0) ? g3h_env_int("G3_CHAIN_WGS", 16) : 0;
   ctx->chain_lds = g3h_env_int("G3_CHAIN_LDS", 0);
   ctx->chain_min_n = g3h_env_int("G3_CHAIN_MIN_N", 0);
   ctx->chain_max_n = g3h_env_int("G3_CHAIN_MAX_N", 10240);
+#endif
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_info, G3_MAX_BATCH * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 64 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_prog, G3_PROG_SLOTS * sizeof(g3_kernel_prog));
@@ -85,6 +81,7 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
     for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
     free(ctx->la_ev);
   }
+#ifdef G3_CHAIN_SERVER
   for (hipStream_t* st : {&ctx->chain_stream, &ctx->chain_stream2, &ctx->chain_sA, &ctx->chain_sB})
     if (*st) {
       (void)hipStreamSynchronize(*st);
@@ -93,6 +90,7 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   for (hipEvent_t* ev : {&ctx->chain_ev, &ctx->chain_ev2, &ctx->chain_ev3})
     if (*ev) (void)hipEventDestroy(*ev);
   if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
+#endif
   if (ctx->gemm_log) fclose(ctx->gemm_log);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -716,10 +714,12 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     G3_HIP(hipStreamSynchronize(ctx->stream));
     *info = *ctx->h_info;
+#ifdef G3_CHAIN_SERVER
     if (g3i_chain_gave_up(ctx, *info)) {   // (cannot happen twice: the server is off after the first time)
       snprintf(ctx->err, sizeof(ctx->err), "chain server gave up inside a jitter retry");
       return G3_ERR_HIP;
     }
+#endif
     return G3_OK;
   };
   // scalars of the evaluation: log-determinant, quadratic form, guards (and mean / sum of squares per query)
@@ -754,6 +754,7 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
     rc = finish();
     if (rc) return rc;
     info = (int)st4[4];
+#ifdef G3_CHAIN_SERVER
     if (g3i_chain_gave_up(ctx, info)) {
       // the resident chain workgroups ran into their wall-clock limit (they are off from now on): this evaluation is
       // redone with the launch-per-kernel sweep
@@ -767,6 +768,7 @@ static int gp_factor_impl(g3_ctx* ctx, const g3_kernel_prog* prog, const void* X
       if (rc) return rc;
       info = (int)st4[4];
     }
+#endif
   }
   double tries = 0, fallback = 0;
   const int info0 = info;
@@ -872,17 +874,6 @@ struct MemberProgs {
     for (int i = 0; i < nfield; ++i) memcpy((char*)out + offs[i], &fields[(size_t)b * nfield + i], sizeof(double));
   }
 };
-
-// a byte offset that names one of the double members of g3_kernel_prog (shift, leaf var / alpha / rate / freq, product coef)
-static int field_offset_ok(int32_t off) {
-  if (off < 0 || off % 8 || (size_t)off + 8 > sizeof(g3_kernel_prog)) return 0;
-  if ((size_t)off == offsetof(g3_kernel_prog, shift)) return 1;
-  const size_t l0 = offsetof(g3_kernel_prog, leaf), p0 = offsetof(g3_kernel_prog, prod);
-  if ((size_t)off >= l0 && (size_t)off < l0 + sizeof(g3_leaf) * G3_MAXLEAF)
-    return ((size_t)off - l0) % sizeof(g3_leaf) >= offsetof(g3_leaf, var);
-  if ((size_t)off >= p0) return ((size_t)off - p0) % sizeof(g3_prod) == offsetof(g3_prod, coef);
-  return 0;
-}
 
 __global__ void __launch_bounds__(256) expand_progs_kernel(g3_kernel_prog* dst, const g3_kernel_prog* tmpl,
                                                           const double* fields, const int32_t* offs, int nfield) {
@@ -1065,7 +1056,7 @@ extern "C" int g3_gp_factor_batched_fields(g3_ctx* ctx, const g3_kernel_prog* tm
   if (nfield < 0 || nfield > G3_MAX_FIELDS) return -6;
   if (nfield && (!fields || !offsets)) return -4;
   for (int i = 0; i < nfield; ++i)
-    if (!field_offset_ok(offsets[i])) return -5;
+    if (!g3h_field_offset_ok(offsets[i])) return -5;
   MemberProgs mp;
   mp.tmpl = tmpl;
   mp.fields = fields;

@@ -195,6 +195,18 @@ struct g3_dist {
   bool serial_coll = false;     // G3_DIST_SERIAL_COLL=1 (read at creation): the two communicators are never in flight together
   bool keep = false;            // g3_dist_set_keep: every block's inverses are kept (the reference of a replay)
   char* wstore = nullptr;       // Np x 128: block inverses of all diagonal blocks, in block order
+  char* vstore = nullptr;       // Np x nb: the full inverses V_k = L_kk^-1 of all diagonal blocks (keep && fullinv)
+  // Panel solve as ONE product (round 5): the owner of diagonal block k inverts the whole nb x nb factor on its look-ahead
+  // stream (g3i_trtri_full: recursive doubling from the 128-block inverses, 7 small launches at nb = 1024) and broadcasts
+  // V_k = L_kk^-1 -- nb x nb, less than the (L, W) pair it replaces -- and every rank's rows of panel k become X V_k^T: one
+  // K-triangular MFMA GEMM instead of a 20-step stripe recursion that ran at ~4 TFLOP/s on a rank's few stripes.
+  // G3_DIST_FULLINV=0 (read at creation) or a block height that is not 128 * 2^q <= 2048 keeps the stripe solve.
+  bool want_fullinv = true, fullinv = false;
+  char* vt = nullptr;           // nb x nb scratch of the inversion: V^T
+  char* ubuf = nullptr;         // nb x nb scratch of the inversion: (L21 V11)^T per pair
+  char* rbuf = nullptr;         // (rows_rhs + rows_inv) x nb: the right-hand-side rows of a panel, solved out of place
+  int plan_gen = 0;             // bumped by every g3_dist_plan: a replay notices a re-planned reference
+  int replay_refs = 0;          // replay drivers that read this driver's factor: it refuses re-plan / destroy meanwhile
   // phases timed with the collectives' event machinery: 3 = a diagonal block's update + factorisation, 4 = a panel solve
   // gradient mode (g3_dist_set_grad): N / P more right-hand-side rows -- the identity, which the sweep turns into the
   // rank's rows of L^-T -- and the rank's rows of K^-1 = L^-T L^-1
@@ -223,8 +235,10 @@ namespace {
 // all-reduces return the rank's own contribution.  What this times is everything except the fabric.
 struct ReplayTransport : Transport {
   g3_dist* self = nullptr;
-  const g3_dist* ref = nullptr;
+  g3_dist* ref = nullptr;
+  int ref_gen = -1;               // plan generation of the reference this replay was planned against
   int what = G3_HINT_NONE, index = -1;
+  bool ref_ok() const;            // the reference still holds the factor this replay was planned against
   void hint(int w, int i) override { what = w; index = i; }
   int fail(const char* m) { snprintf(err, sizeof(err), "%s", m); return G3_ERR_HIP; }
   int bcast(void* buf, size_t bytes, int root, hipStream_t s) override;
@@ -270,7 +284,12 @@ static int perm_of(const g3_dist* D, int k, std::vector<int32_t>* idx) { return 
 static inline char* Aat(const g3_dist* D, int64_t row, int64_t col) { return D->A + ((size_t)row * D->Np + col) * D->es; }
 static inline char* Lof(const g3_dist* D, int k) { return D->dbuf[k % 2]; }
 static inline char* Wof(const g3_dist* D, int k) { return D->dbuf[k % 2] + (size_t)D->nb * D->nb * D->es; }
-static inline size_t dbuf_bytes(const g3_dist* D) { return ((size_t)D->nb * D->nb + (size_t)D->nb * 128) * D->es; }
+static inline char* Vof(const g3_dist* D, int k) { return D->dbuf[k % 2] + ((size_t)D->nb * D->nb + (size_t)D->nb * 128) * D->es; }
+// one broadcast buffer: L (nb x nb), its 128-block inverses (nb x 128) and, with the full inverse, V (nb x nb)
+static inline size_t dbuf_bytes(const g3_dist* D) { return ((size_t)D->nb * D->nb * (D->fullinv ? 2 : 1) + (size_t)D->nb * 128) * D->es; }
+// what travels: V alone with the full inverse (the owner keeps L in its matrix), else L and the block inverses
+static inline char* bc_ptr(const g3_dist* D, int k) { return D->fullinv ? Vof(D, k) : D->dbuf[k % 2]; }
+static inline size_t bc_bytes(const g3_dist* D) { return (D->fullinv ? (size_t)D->nb * D->nb : (size_t)D->nb * D->nb + (size_t)D->nb * 128) * D->es; }
 
 // all blocks of a panel that other ranks would send, in ONE launch (a hipMemcpy2DAsync per 2 MB block costs ~20 us each:
 // 70 ms per evaluation at nb = 512, which would be the replay's own artefact, not the schedule's)
@@ -292,12 +311,22 @@ __global__ void replay_panel_kernel(char* __restrict__ recv, const char* __restr
   }
 }
 
+bool ReplayTransport::ref_ok() const {
+  return ref && ref->planned && ref->keep && ref->A && ref->wstore && (!self->fullinv || ref->vstore) && ref->plan_gen == ref_gen;
+}
+
 int ReplayTransport::bcast(void* buf, size_t bytes, int root, hipStream_t s) {
   const g3_dist* D = self;
   if (root == D->rank) return G3_OK;
+  if (!ref_ok()) return fail("replay: the reference driver was re-planned or released after this replay was planned");
   const size_t es = D->es;
   if (what == G3_HINT_DIAG) {
-    if (index < 0 || index >= D->nblk || bytes != dbuf_bytes(D)) return fail("replay: bad diagonal-factor broadcast");
+    if (index < 0 || index >= D->nblk || bytes != bc_bytes(D)) return fail("replay: bad diagonal-factor broadcast");
+    if (D->fullinv) {              // V_jj = L_jj^-1 as the reference's owner computed it
+      if (hipMemcpyAsync(buf, ref->vstore + (size_t)index * D->nb * D->nb * es, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail("replay: copy of an inverted diagonal factor failed");
+      return G3_OK;
+    }
     // L_jj (nb x nb, leading dimension nb) out of the reference's full factor, then its nb x 128 block inverses
     const char* src = ref->A + ((size_t)index * D->nb * ref->Np + (size_t)index * D->nb) * es;
     if (hipMemcpy2DAsync(buf, (size_t)D->nb * es, src, (size_t)ref->Np * es, (size_t)D->nb * es, (size_t)D->nb, hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -320,6 +349,7 @@ int ReplayTransport::allgather(const void* send, void* recv, size_t bytes, hipSt
   const g3_dist* D = self;
   if (what != G3_HINT_PANEL || index < 0 || index >= D->nblk - 1)
     return fail("replay transport: this all-gather is not part of g3_dist_gp_factor_predict");
+  if (!ref_ok()) return fail("replay: the reference driver was re-planned or released after this replay was planned");
   const int k = index;
   const size_t es = D->es, blk = (size_t)D->nb * D->nb * es;
   std::vector<int32_t> idx;
@@ -442,6 +472,7 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
     return G3_ERR_HIP;
   }
   D->serial_coll = g3h_env_int("G3_DIST_SERIAL_COLL", 0) != 0;
+  D->want_fullinv = g3h_env_int("G3_DIST_FULLINV", 1) != 0;
   g3_ctx_set_stream(D->ctx_look, D->s_look);
   g3_ctx_set_stream(D->ctx_bulk, D->s_bulk);
   D->ctx_bulk->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
@@ -506,6 +537,10 @@ extern "C" int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb
 
 extern "C" int g3_dist_set_keep(g3_dist* D, int on) {
   if (!D) return -1;
+  if (D->replay_refs > 0) {
+    snprintf(D->err, sizeof(D->err), "g3_dist_set_keep: %d replay driver(s) still read this driver's factor", D->replay_refs);
+    return -2;
+  }
   D->keep = on != 0;
   D->planned = false;          // the store of the block inverses is part of the plan: re-plan
   return G3_OK;
@@ -524,6 +559,8 @@ extern "C" int g3_dist_create_replay(g3_ctx* ctx, g3_dist* reference, int rank, 
   if (!t) { g3_dist_destroy(D); return G3_ERR_NOMEM; }
   t->self = D;
   t->ref = reference;
+  reference->replay_refs += 1;       // released by g3_dist_destroy of the replay
+  D->want_fullinv = reference->fullinv;   // the replayed rank must run the schedule the reference ran
   D->tr = t;
   *out = D;
   return G3_OK;
@@ -531,8 +568,9 @@ extern "C" int g3_dist_create_replay(g3_ctx* ctx, g3_dist* reference, int rank, 
 
 static void free_plan(g3_dist* D) {
   void* bufs[] = {D->A, D->dbuf[0], D->dbuf[1], D->send[0], D->send[1], D->gath[0], D->gath[1], D->gath[2], D->avec, D->dots,
-                  D->Kinv, D->alpha_dev, D->agath, D->wstore, D->blkstats};
+                  D->Kinv, D->alpha_dev, D->agath, D->wstore, D->blkstats, D->vstore, D->vt, D->ubuf, D->rbuf};
   D->blkstats = nullptr;
+  D->vstore = D->vt = D->ubuf = D->rbuf = nullptr;
   for (void* b : bufs) if (b) (void)hipFree(b);
   D->A = D->dbuf[0] = D->dbuf[1] = D->send[0] = D->send[1] = D->gath[0] = D->gath[1] = D->gath[2] = D->avec = D->dots = nullptr;
   D->Kinv = D->alpha_dev = D->agath = nullptr;
@@ -545,6 +583,12 @@ static void free_plan(g3_dist* D) {
 
 extern "C" int g3_dist_destroy(g3_dist* D) {
   if (!D) return -1;
+  if (D->replay_refs > 0) {          // a replay copies out of this driver's buffers in every collective
+    snprintf(D->err, sizeof(D->err), "g3_dist_destroy: %d replay driver(s) still read this driver's factor; destroy them first", D->replay_refs);
+    return -2;
+  }
+  if (ReplayTransport* rt = dynamic_cast<ReplayTransport*>(D->tr))
+    if (rt->ref && rt->ref->replay_refs > 0) rt->ref->replay_refs -= 1;
   g3_dev_guard _dg(D->ctx);
   (void)hipStreamSynchronize(D->ctx->stream);
   if (D->s_look) (void)hipStreamSynchronize(D->s_look);
@@ -569,9 +613,15 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   if (d < 1 || d > G3_MAXCOLS) return -3;
   if (M < 0) return -4;
   if (nb < 128 || nb % 128) return -5;
+  if (D->replay_refs > 0) {
+    snprintf(D->err, sizeof(D->err), "g3_dist_plan: %d replay driver(s) still read this driver's factor", D->replay_refs);
+    return -6;
+  }
   g3_dev_guard _dg(D->ctx);
   G3D_HIP(hipStreamSynchronize(D->ctx->stream));
   free_plan(D);
+  D->plan_gen += 1;
+  D->fullinv = D->want_fullinv && nb <= 2048 && ((nb / 128) & (nb / 128 - 1)) == 0;
   D->N = N; D->d = d; D->M = M; D->nb = nb; D->dt = dt; D->es = g3_esize(dt);
   D->Np = g3_roundup(N, nb);
   D->nblk = (int)(D->Np / nb);
@@ -600,6 +650,8 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   G3D_HIP(hipMemsetAsync(D->A, 0, (rows ? rows : 1) * D->Np * D->es, D->ctx->stream));
   for (int i = 0; i < 2; ++i) {
     G3D_HIP(hipMalloc((void**)&D->dbuf[i], dbuf_bytes(D)));
+    // (the blocks of V above the block diagonal are never written: keep them zero for whoever reads V densely)
+    G3D_HIP(hipMemsetAsync(D->dbuf[i], 0, dbuf_bytes(D), D->ctx->stream));
     G3D_HIP(hipMalloc((void**)&D->send[i], (size_t)D->cmax * nb * nb * D->es));
     G3D_HIP(hipMemsetAsync(D->send[i], 0, (size_t)D->cmax * nb * nb * D->es, D->ctx->stream));
   }
@@ -613,16 +665,28 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   G3D_HIP(hipMalloc((void**)&D->dots, (D->my_chunks.size() + 1) * 2 * 128 * D->es));
   G3D_HIP(hipMalloc((void**)&D->blkstats, (D->my_blocks.size() + 1) * 4 * sizeof(double)));
   if (D->keep) G3D_HIP(hipMalloc((void**)&D->wstore, (size_t)D->Np * 128 * D->es));
+  if (D->fullinv) {
+    if (D->keep) G3D_HIP(hipMalloc((void**)&D->vstore, (size_t)D->Np * nb * D->es));
+    G3D_HIP(hipMalloc((void**)&D->vt, (size_t)nb * nb * D->es));
+    G3D_HIP(hipMalloc((void**)&D->ubuf, (size_t)nb * nb * D->es));
+    G3D_HIP(hipMemsetAsync(D->vt, 0, (size_t)nb * nb * D->es, D->ctx->stream));
+    G3D_HIP(hipMemsetAsync(D->ubuf, 0, (size_t)nb * nb * D->es, D->ctx->stream));
+    const size_t rr = (size_t)(D->rows_rhs + D->rows_inv);
+    G3D_HIP(hipMalloc((void**)&D->rbuf, (rr ? rr : 1) * nb * D->es));
+  }
   if (D->grad) {
     G3D_HIP(hipMalloc((void**)&D->Kinv, (size_t)(D->rows_mat ? D->rows_mat : 1) * D->Np * D->es));
     G3D_HIP(hipMalloc((void**)&D->alpha_dev, (size_t)D->Np * D->es));
     G3D_HIP(hipMalloc((void**)&D->agath, (size_t)D->world * D->cmax_all * nb * D->es));
   }
   if (ReplayTransport* rt = dynamic_cast<ReplayTransport*>(D->tr)) {
-    if (rt->ref->Np != D->Np || rt->ref->nb != D->nb || rt->ref->dt != D->dt || rt->ref->M != D->M || D->grad) {
-      snprintf(D->err, sizeof(D->err), "replay: the plan must repeat the reference's (N, M, nb, dtype) and gradient mode is not replayed");
+    if (rt->ref->Np != D->Np || rt->ref->nb != D->nb || rt->ref->dt != D->dt || rt->ref->M != D->M || D->grad ||
+        rt->ref->fullinv != D->fullinv || !rt->ref->planned || !rt->ref->keep) {
+      snprintf(D->err, sizeof(D->err), "replay: the plan must repeat the reference's (N, M, nb, dtype, panel-solve mode) and gradient "
+               "mode is not replayed");
       return -6;
     }
+    rt->ref_gen = rt->ref->plan_gen;
   }
   D->ev.resize(D->nblk + 6);
   for (auto& e : D->ev) G3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -710,8 +774,13 @@ static int factor_block(g3_dist* D, g3_ctx* cx, int k) {
   G3D_RC(cx, g3_copy2d(cx, Lof(D, k), D->nb, Dk, D->Np, D->nb, D->nb, D->dt));
   G3D_RC(cx, g3_potrf_nowait(cx, Lof(D, k), D->nb, D->nb, D->dt, Wof(D, k), D->info_dev));
   G3D_RC(cx, g3_copy2d(cx, Dk, D->Np, Lof(D, k), D->nb, D->nb, D->nb, D->dt));
+  // V_k = L_kk^-1 for everybody's panel solve (a failed pivot leaves the flag of cx set: the launches below are no-ops)
+  if (D->fullinv) G3D_RC(cx, g3i_trtri_full(cx, Lof(D, k), D->nb, Wof(D, k), Vof(D, k), D->vt, D->ubuf, D->dt));
   if (D->keep && D->wstore)
     G3D_HIP(hipMemcpyAsync(D->wstore + (size_t)k * D->nb * 128 * D->es, Wof(D, k), (size_t)D->nb * 128 * D->es, hipMemcpyDeviceToDevice,
+                           cx->stream));
+  if (D->keep && D->vstore)
+    G3D_HIP(hipMemcpyAsync(D->vstore + (size_t)k * D->nb * D->nb * D->es, Vof(D, k), (size_t)D->nb * D->nb * D->es, hipMemcpyDeviceToDevice,
                            cx->stream));
   return G3_OK;
 }
@@ -739,29 +808,50 @@ static int solve_and_gather(g3_dist* D, int k, hipEvent_t ev_solved) {
   const bool own_next = k + 1 < D->nblk && owner_of(D, k + 1) == D->rank;
   const int64_t head = (own_next && m > nb) ? nb : 0;
   bool released = false;
+  const int64_t mine = D->rows_mat - r_lo;          // my matrix rows below block k (m - mine right-hand-side rows follow them)
+  const bool gathers = D->nblk - 1 - k > 0;
+  std::vector<int32_t> idx;
+  const int cnt = gathers ? perm_of(D, k, &idx) : 0;
+  // my rows go straight into my slot of the gather buffer and the all-gather runs in place (send = recv + rank * bytes):
+  // no staging copy, and RCCL skips the local block -- at one rank the collective moves nothing at all
+  const size_t gbytes = (size_t)cnt * nb * nb * D->es;
+  char* slot = gathers ? D->gath[k % 3] + (size_t)D->rank * gbytes : nullptr;
   if (m > 0) {
     int rcp = coll_begin(D, G3_PH_SOLVE, D->ctx->stream, 0.0);
     if (rcp) return rcp;
-    if (head > 0) {
-      G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), head, D->Np, D->dt, Wof(D, k)));
-      G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
-      released = true;
+    if (D->fullinv) {
+      // X <- X V_k^T, out of place: the matrix rows land in my slot of the gather buffer (and are copied back into the
+      // local matrix, which the staircase launches and the look-ahead read), the right-hand-side rows go through rbuf
+      const char* V = Vof(D, k);
+      if (head > 0) {
+        G3D_RC(D->ctx, g3i_gemm_nt_ktri(D->ctx, slot, nb, Aat(D, r_lo, c0), D->Np, V, nb, head, nb, 1.0, 0.0, D->dt));
+        G3D_RC(D->ctx, g3_copy2d(D->ctx, Aat(D, r_lo, c0), D->Np, slot, nb, head, nb, D->dt));
+        G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
+        released = true;
+      }
+      if (mine - head > 0)
+        G3D_RC(D->ctx, g3i_gemm_nt_ktri(D->ctx, slot + (size_t)head * nb * D->es, nb, Aat(D, r_lo + head, c0), D->Np, V, nb, mine - head, nb,
+                                        1.0, 0.0, D->dt));
+      if (m - mine > 0)
+        G3D_RC(D->ctx, g3i_gemm_nt_ktri(D->ctx, D->rbuf, nb, Aat(D, D->rows_mat, c0), D->Np, V, nb, m - mine, nb, 1.0, 0.0, D->dt));
+      if (mine - head > 0)
+        G3D_RC(D->ctx, g3_copy2d(D->ctx, Aat(D, r_lo + head, c0), D->Np, slot + (size_t)head * nb * D->es, nb, mine - head, nb, D->dt));
+      if (m - mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, Aat(D, D->rows_mat, c0), D->Np, D->rbuf, nb, m - mine, nb, D->dt));
+    } else {
+      if (head > 0) {
+        G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo, c0), head, D->Np, D->dt, Wof(D, k)));
+        G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
+        released = true;
+      }
+      G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo + head, c0), m - head, D->Np, D->dt, Wof(D, k)));
+      if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, slot, nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
     }
-    G3D_RC(D->ctx, g3_trsm_rlt(D->ctx, Lof(D, k), nb, nb, Aat(D, r_lo + head, c0), m - head, D->Np, D->dt, Wof(D, k)));
     rcp = coll_end(D, D->ctx->stream);
     if (rcp) return rcp;
   }
   // (ranks that do not own block k+1: the event only orders the broadcast buffer's reuse behind this solve)
   if (!released) G3D_HIP(hipEventRecord(ev_solved, D->ctx->stream));
-  if (D->nblk - 1 - k <= 0) return G3_OK;
-  std::vector<int32_t> idx;
-  const int cnt = perm_of(D, k, &idx);
-  const int64_t mine = D->rows_mat - r_lo;
-  // my rows go straight into my slot of the gather buffer and the all-gather runs in place (send = recv + rank * bytes):
-  // no staging copy, and RCCL skips the local block -- at one rank the collective moves nothing at all
-  const size_t gbytes = (size_t)cnt * nb * nb * D->es;
-  char* slot = D->gath[k % 3] + (size_t)D->rank * gbytes;
-  if (mine > 0) G3D_RC(D->ctx, g3_copy2d(D->ctx, slot, nb, Aat(D, r_lo, c0), D->Np, mine, nb, D->dt));
+  if (!gathers) return G3_OK;
   int rc = do_allgather(D, slot, D->gath[k % 3], gbytes, D->ctx->stream, G3_HINT_PANEL, k);
   if (rc) return rc;
   if (D->serial_coll) G3D_HIP(hipEventRecord(D->ev[D->nblk + 5], D->ctx->stream));    // "panel k is gathered"
@@ -796,7 +886,7 @@ static int lookahead(g3_dist* D, int j, hipEvent_t after, hipEvent_t ev_solved, 
   // G3_DIST_SERIAL_COLL=1 is the conservative schedule: the broadcast waits until the gather of panel j-1 has been
   // issued AND completed on this rank, so every rank issues the two communicators strictly one after the other.
   if (D->serial_coll && j >= 1 && D->nblk - j > 0) G3D_HIP(hipStreamWaitEvent(D->s_look, D->ev[D->nblk + 5], 0));
-  rc = do_bcast(D, D->dbuf[j % 2], dbuf_bytes(D), owner_of(D, j), D->s_look, G3_HINT_DIAG, j);
+  rc = do_bcast(D, bc_ptr(D, j), bc_bytes(D), owner_of(D, j), D->s_look, G3_HINT_DIAG, j);
   if (rc) return rc;
   G3D_HIP(hipEventRecord(joined, D->s_look));
   return G3_OK;
@@ -840,7 +930,7 @@ static int factor(g3_dist* D, const g3_kernel_prog* prog, const g3_kernel_prog* 
     if (!rc) rc = coll_end(D, sA);
     if (rc) return rc;
   }
-  rc = do_bcast(D, D->dbuf[0], dbuf_bytes(D), owner_of(D, 0), sA, G3_HINT_DIAG, 0);
+  rc = do_bcast(D, bc_ptr(D, 0), bc_bytes(D), owner_of(D, 0), sA, G3_HINT_DIAG, 0);
   if (rc) return rc;
   rc = solve_and_gather(D, 0, ev_sv);
   if (rc) return rc;

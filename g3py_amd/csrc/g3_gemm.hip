@@ -72,7 +72,9 @@ gemm_nt_kernel(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t l
     brow = (int64_t)tab.b_blk[sblk] * tab.b_nb + (n0 - sblk * tab.b_nb);
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_tile<T, BM, BN, WM, WN, NSTAGE>(C, ldc, A + (int64_t)m0 * lda, lda, B + brow * ldb, ldb, K, alpha, beta, m0, n0,
+  // B lower triangular (k_tri): row j of B is zero beyond column j, so this column tile's reduction ends at n0 + BN
+  const int Kt = (tab.k_tri && n0 + BN < K) ? n0 + BN : K;
+  gemm_tile<T, BM, BN, WM, WN, NSTAGE>(C, ldc, A + (int64_t)m0 * lda, lda, B + brow * ldb, ldb, Kt, alpha, beta, m0, n0,
                                        lower_only, doff, failed, smem);
 }
 
@@ -140,10 +142,11 @@ static int launch_cfg(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
   // (>= 4096 tiles: the P2b launches, as in rounds 1-2 when nothing smaller used this tile; the column updates that take it
   //  since round 3 -- 1024 .. 4095 tiles -- are tagged MID so that the bulk figure stays comparable)
   const int tag = (BM == 128 && BN == 128) ? (nv >= 4096 ? G3_TAG_GEMM_BIG : G3_TAG_GEMM_MID) : G3_TAG_GEMM_SMALL;
-  const int pr = g3i_prof_begin(ctx, tag, 2.0 * shape_elems(sh) * (double)k);
+  const double kmean = sh.k_tri ? 0.5 * ((double)k + (double)BN) : (double)k;     // triangular B: K grows with the column tile
+  const int pr = g3i_prof_begin(ctx, tag, 2.0 * shape_elems(sh) * kmean);
   if (FILE* lg = ctx->gemm_log)   // G3_GEMM_LOG=<file>: one line per launch, joined with a kernel trace by scripts/launch_table.py
     fprintf(lg, "gemm %d %d %d %lld %lld %lld %d %lld %.9e %d\n", BM, BN, NT / 64, (long long)sh.m, (long long)sh.n, (long long)k, sh.kind,
-            nv, 2.0 * shape_elems(sh) * (double)k, g3_on_bulk_stream(ctx) ? 1 : 0);
+            nv, 2.0 * shape_elems(sh) * kmean, g3_on_bulk_stream(ctx) ? 1 : 0);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds_req, ctx->stream, (T*)C, ldc, (const T*)A, lda,
                      (const T*)B, ldb, (int)k, (T)alpha, (T)beta, ctx->d_info,
                      g3_bstride_of(ctx, C), g3_bstride_of(ctx, A), g3_bstride_of(ctx, B), tab);
@@ -184,7 +187,7 @@ static int launch_t(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t ld
   // The big tile from gemm_big_min tiles on, and from 1024 tiles on when K >= 1024 (round 3, scripts/r3_sweep2.sh: N = 32768
   // 204.0 -> 203.3 ms, config 3 33.54 -> 33.43; at K = 512 -- config 2 -- the small tile stays better: 7.25 vs 7.31 ms)
   const int64_t big_min = ctx->tune.gemm_big_min;
-  if (all128 && (blocks128 >= big_min || (blocks128 >= 1024 && k >= 1024 && big_min == 4096)))
+  if (all128 && (blocks128 >= big_min || (blocks128 >= ctx->tune.gemm_big_min_k && k >= 1024 && big_min == 4096)))
     return launch_cfg<T, 128, 128, 64, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
   return launch_cfg<T, 64, 64, 32, 32, STAGES>(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, sh);
 }
@@ -199,7 +202,7 @@ int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda
                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                    g3_dtype dt, int lower_only, int wide) {
   if (m == 0 || n == 0) return G3_OK;
-  const GemmShape sh{lower_only ? 1 : 0, m, n, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr};
+  const GemmShape sh{lower_only ? 1 : 0, m, n, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, wide);
 }
 
@@ -209,13 +212,23 @@ int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, c
   return g3i_gemm_nt_ex(ctx, C, ldc, A, lda, B, ldb, m, n, k, alpha, beta, dt, lower_only, 0);
 }
 
+// C[m x n] = alpha * A[m x n] * V^T + beta * C with V (n x n, row-major) LOWER triangular: the panel solve X L^-T as ONE
+// product against the explicitly inverted factor V = L^-1; the column tile at n0 reduces over K = n0 + BN only (half the
+// flops of the dense product).  C must not alias A.
+int g3i_gemm_nt_ktri(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* V, int64_t ldv, int64_t m, int64_t n,
+                     double alpha, double beta, g3_dtype dt) {
+  if (m == 0 || n == 0) return G3_OK;
+  const GemmShape sh{0, m, n, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 1};
+  return launch_dt(ctx, C, ldc, A, lda, V, ldv, n, alpha, beta, dt, sh, 0);
+}
+
 // trapezoid: only elements with col <= row + diag_off are produced (diag_off = 0: lower triangle
 // of a C whose top-left corner lies on the diagonal; > 0: C starts diag_off columns left of it)
 int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                      int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                      g3_dtype dt, int64_t diag_off) {
   if (m == 0 || n == 0) return G3_OK;
-  const GemmShape sh{1, m, n, diag_off, 0, nullptr, nullptr, 0, nullptr, 0, nullptr};
+  const GemmShape sh{1, m, n, diag_off, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
 }
 
@@ -281,7 +294,7 @@ int g3i_gemm_nt_stair(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t 
     if (seg_cols[s] > n) n = seg_cols[s];
   }
   if (m == 0 || n == 0) return G3_OK;
-  const GemmShape sh{2, m, n, 0, nseg, seg_rows, seg_cols, b_nb, b_perm, nperm, seg_diag};
+  const GemmShape sh{2, m, n, 0, nseg, seg_rows, seg_cols, b_nb, b_perm, nperm, seg_diag, 0};
   return launch_dt(ctx, C, ldc, A, lda, B, ldb, k, alpha, beta, dt, sh, 0);
 }
 

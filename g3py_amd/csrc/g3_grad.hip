@@ -1231,7 +1231,7 @@ extern "C" int g3_gp_dlogp_batched_fields(g3_ctx* ctx, const g3_kernel_prog* tmp
   if (nfield < 0 || nfield > G3_MAX_FIELDS) return -6;
   if (nfield && (!fields || !offsets)) return -4;
   for (int i = 0; i < nfield; ++i)
-    if (offsets[i] < 0 || offsets[i] % 8 || (size_t)offsets[i] + 8 > sizeof(g3_kernel_prog)) return -5;
+    if (!g3h_field_offset_ok(offsets[i])) return -5;      // the same rule as g3_gp_factor_batched_fields (g3_host.h)
   std::vector<g3_kernel_prog> progs((size_t)batch, *tmpl);
   for (int b = 0; b < batch; ++b)
     for (int i = 0; i < nfield; ++i)

@@ -2,6 +2,7 @@
 // same text is compiled into the library AND into the CPU sanitizer harness (tests/host_asan/, g++
 // -fsanitize=address,undefined) that exercises the index arithmetic without a GPU.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -30,6 +31,7 @@ struct G3hTune {
   int nb_head;            // G3_NB_HEAD     leading panels of half / quarter width (-1: one for n <= 16384, else none)
   int side_lds;           // G3_SIDE_LDS    least LDS a bulk-stream GEMM launch asks for (54000; 0: what it needs)
   int64_t gemm_big_min;   // G3_GEMM_BIG_MIN  least number of 128 x 128 tiles for the big tile (4096)
+  int64_t gemm_big_min_k; // G3_GEMM_BIG_MIN_K  ... when K >= 1024 (1024): a rank's staircase at P = 8 has 1/8 of the tiles
   int64_t trsm_thin_max;  // G3_TRSM_THIN_MAX panel rows up to which the stripe solve uses 16-row stripes (2048)
   int64_t trsm_wide_min;  // G3_TRSM_WIDE_MIN panel rows from which it uses 64-row stripes (12288; 0: never)
   int64_t trsm_split_min; // G3_TRSM_SPLIT_MIN panel rows from which the solve is split at the launch level (0: never)
@@ -51,6 +53,8 @@ static inline G3hTune g3h_tune_from_env() {
   t.side_lds = g3h_env_int("G3_SIDE_LDS", 54000);
   e = getenv("G3_GEMM_BIG_MIN");
   t.gemm_big_min = e ? atoll(e) : 4096;
+  e = getenv("G3_GEMM_BIG_MIN_K");
+  t.gemm_big_min_k = e ? atoll(e) : 1024;
   e = getenv("G3_TRSM_THIN_MAX");
   t.trsm_thin_max = e ? atoll(e) : 2048;
   e = getenv("G3_TRSM_WIDE_MIN");
@@ -135,6 +139,9 @@ struct RasterTab {
   // b_blk[s] -- the gathered panel of the multi-GPU sweep arrives rank-major, not in global order
   int b_nb;                                 // 0: B is in logical order
   unsigned short b_blk[G3_RASTER_MAX];
+  // B is LOWER triangular (row j of B is zero beyond column j): the column tile at n0 only needs K = n0 + BN.  The product
+  // against an explicitly inverted diagonal factor, X L^-T = X V^T with V = L^-1 (multi-GPU panel solve, g3_dist.hip)
+  int k_tri;
 };
 
 
@@ -153,6 +160,7 @@ struct GemmShape {
   // which only the lower triangle is wanted: tiles entirely above it are not launched (the elements above the
   // diagonal inside a launched tile are still written -- the strict upper part of a diagonal block is scratch)
   const int64_t* seg_diag;
+  int k_tri;                // dense only: B is lower triangular, column tile n0 stops at K = n0 + BN
 };
 
 static inline double shape_elems(const GemmShape& sh) {
@@ -238,6 +246,7 @@ static inline long long build_raster(const GemmShape& sh, RasterTab* tab) {
   tab->g[ng].prefix = (int)total;
   tab->g[ng].row0 = 0;
   tab->g[ng].nrows = 1;
+  tab->k_tri = (sh.kind == 0 && sh.k_tri) ? 1 : 0;
   tab->b_nb = 0;
   if (sh.b_nb > 0 && sh.b_perm) {
     if (sh.nperm > G3_RASTER_MAX || sh.b_nb % BN) return -1;
@@ -485,5 +494,18 @@ static inline int g3h_validate_prog(const g3_kernel_prog* p, int d) {
     for (int f = 0; f < p->prod[q].nfac; ++f)
       if (p->prod[q].fac[f] < 0 || p->prod[q].fac[f] >= p->nleaf) return 1;
   }
+  return 0;
+}
+
+// ---- chains: ONE template program plus the doubles that differ per member (g3_gp_factor_batched_fields,
+// g3_gp_dlogp_batched_fields).  A byte offset is valid iff it names one of the double members of g3_kernel_prog
+// (shift, a leaf's var / alpha / rate / freq, a product's coef) -- never a count, a kind or an index the device follows.
+static inline int g3h_field_offset_ok(int32_t off) {
+  if (off < 0 || off % 8 || (size_t)off + 8 > sizeof(g3_kernel_prog)) return 0;
+  if ((size_t)off == offsetof(g3_kernel_prog, shift)) return 1;
+  const size_t l0 = offsetof(g3_kernel_prog, leaf), p0 = offsetof(g3_kernel_prog, prod);
+  if ((size_t)off >= l0 && (size_t)off < l0 + sizeof(g3_leaf) * G3_MAXLEAF)
+    return ((size_t)off - l0) % sizeof(g3_leaf) >= offsetof(g3_leaf, var);
+  if ((size_t)off >= p0) return ((size_t)off - p0) % sizeof(g3_prod) == offsetof(g3_prod, coef);
   return 0;
 }

@@ -30,7 +30,7 @@ struct g3_ctx {
   bool fuse256;            // factor 256-wide diagonal blocks with the one-launch kernel (chain-bound sizes)
   bool adopted;            // stream belongs to the caller
   bool bulk_role;          // this context's stream carries bulk updates beside another context's chain (multi-GPU driver)
-  // chain server (g3_potrf.hip): the critical-path chain of a sweep on resident workgroups
+#ifdef G3_CHAIN_SERVER   // measurement variant only (scripts/variants/chain_server.inc): the chain of a sweep on resident workgroups
   unsigned* chain_ctl;     // device: counters and per-panel flags of the running server
   hipStream_t chain_sA, chain_sB;            // the chain sweep's own chain / bulk streams (created with the two below)
   hipStream_t chain_stream, chain_stream2;   // streams of the server's two kernels (diagonal workgroup, workers)
@@ -39,6 +39,7 @@ struct g3_ctx {
   int chain_lds;           // LDS bytes a server workgroup asks for (0: what it needs)
   int64_t chain_min_n, chain_max_n;   // matrices the server is used for
   bool chain_broken;       // a server gave up (wall-clock limit): launches per kernel from then on
+#endif
   // batch mode (g3_gp_factor_batched): every MFMA GEMM and diagonal-block launch of a sweep acts on
   // `batch` matrices at once (grid.y); operands inside the block-inverse buffer [bw_base, +bw_bytes)
   // are `bstride_w` elements apart, everything else `bstride` elements
@@ -131,9 +132,12 @@ static inline int64_t g3_bstride_of(const g3_ctx* ctx, const void* p) {
   return (ctx->bw_base && c >= ctx->bw_base && c < ctx->bw_base + ctx->bw_bytes) ? ctx->bstride_w : ctx->bstride;
 }
 
-// launches issued now go to a low-priority bulk stream (classic sweep: side_stream; chain sweep: chain_sB)
+// launches issued now go to the low-priority bulk stream of the look-ahead sweep
 static inline bool g3_on_bulk_stream(const g3_ctx* ctx) {
-  return ctx->stream == ctx->side_stream || (ctx->chain_sB && ctx->stream == ctx->chain_sB);
+#ifdef G3_CHAIN_SERVER
+  if (ctx->chain_sB && ctx->stream == ctx->chain_sB) return true;
+#endif
+  return ctx->stream == ctx->side_stream;
 }
 
 static inline size_t g3_esize(g3_dtype dt) { return dt == G3_F64 ? 8 : 4; }
@@ -147,6 +151,9 @@ int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, c
 int g3i_gemm_nt_ex(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                    int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
                    g3_dtype dt, int lower_only, int wide);
+// C = alpha A V^T + beta C, V (n x n) lower triangular: column tile n0 reduces over K = n0 + BN only (C must not alias A)
+int g3i_gemm_nt_ktri(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* V, int64_t ldv, int64_t m, int64_t n,
+                     double alpha, double beta, g3_dtype dt);
 // only elements with col <= row + diag_off (trapezoid; 0 = lower triangle of a diagonal-anchored C)
 int g3i_gemm_nt_trap(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                      int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,
@@ -164,6 +171,9 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
 int g3i_trsm_rlt(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, void* B, int64_t m,
                  int64_t ldb, g3_dtype dt, const void* invd);
 int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtype dt, void* invd);
+// V = L^-1 (n x n lower, n = 128 * 2^q <= 2048) from the 128-block inverses W; Vt and U are n x n scratch (Vt = V^T on return
+// except for the last level); all compact (leading dimension n)
+int g3i_trtri_full(g3_ctx* ctx, const void* L, int64_t n, const void* W, void* V, void* Vt, void* U, g3_dtype dt);
 int g3i_reset_info(g3_ctx* ctx);
 bool g3i_info_known_zero(const g3_ctx* ctx);
 // g3_diag_stats / g3_logp_terms / g3_rows_dot_ss results left in device memory (no host synchronisation): 3 / 4 doubles
@@ -173,9 +183,11 @@ int g3i_logp_terms_dev(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const 
 // workgroup per member, one launch (g3_potrf.hip)
 int g3i_small_factor_batched(g3_ctx* ctx, void* K, int64_t ld, int64_t kstride, void* W, int64_t wstride, const void* delta, int64_t ldd,
                              void* a, int64_t astride, double* dstats, int batch, int64_t n, int64_t np, g3_dtype dt);
+#ifdef G3_CHAIN_SERVER
 // true when `info` says the chain server gave up: it is switched off for this context (one line on stderr)
 bool g3i_chain_gave_up(g3_ctx* ctx, int info);
 #define G3_INFO_CHAIN 0x40000000   // pivot-flag value: the chain server gave up (never a pivot index)
+#endif
 int g3i_diag_add(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, double value);
 // A[0:rows, 0:cols) *= factor (stream-ordered)
 int g3i_scale(g3_ctx* ctx, void* A, int64_t rows, int64_t cols, int64_t ld, g3_dtype dt, double factor);

@@ -953,339 +953,6 @@ int g3i_ensure_work(g3_ctx* ctx, size_t bytes) {
   return G3_OK;
 }
 
-// =======================================================================================
-// Chain server (round 4): the critical-path chain of the look-ahead sweep as RESIDENT workgroups.
-//
-// What rounds 2-3 measured as "the diagonal kernels run 1.5-2.6x slower inside a sweep" is not the speed they run at:
-// a resident potrf256 workgroup takes 103 us beside streaming bulk updates against 86 us alone
-// (profiles/r04_probe_resident.txt).  The rest of the 134 us (config 2) ... 249 us (config 4) a LAUNCH of it shows in the
-// trace is the wait for 512 threads x 130 VGPRs + 76 KB of LDS to come free on some CU, and every dependent launch of the
-// chain pays it again.  So the chain's workgroups are launched ONCE per factorisation and stay: one kernel of NWG
-// workgroups (512 threads each) walks the panel list of the sweep; the streams only carry the wide, throughput-bound rest.
-//
-// Job s (panel s: columns [c, c+n), next panel e = width of panel s+1 columns): the square region
-// Q = A[c : c+n+e, c : c+n+e]; factor its first n columns right-looking in 256-wide steps and apply them to all of Q:
-//   step j:  D  workgroup 0      potrf256 / diag128 of the step's diagonal block (the only serial part)
-//            T  workers          rows below it, inside Q:  X <- X L_jj^-T  in 32-row stripes (stripe-local recursion)
-//            S  workers          trailing update inside the panel's own columns, the next step's diagonal block first
-//   stage 3  workers             the NEXT panel's diagonal block  -= X X^T  (K = n): job s+1 can start at once
-// Everything below / right of Q is done by ordinary launches: trsm_rest(s) and Ua_rest(s) on the chain stream, the bulk
-// updates on the side stream.  Hand-offs (all agent scope, MI355X_MICROARCH.md "inter-workgroup visibility"):
-//   server -> streams  potrf[s] (L_ss and its block inverses final), panel[s] (rows of block s+1 solved): one-wave wait kernels
-//   streams -> server  rest[s] (Ua_rest(s-1) has updated the extra rows), bulk[s] (P2a(s-1) has updated the next diagonal
-//                      block): one-wave post kernels behind the launch in question
-//   inside the server  monotonic counters: c_diag (steps finished by workgroup 0), c_T / c_S (worker barriers), c_Sd
-//                      (next diagonal block updated), c_3 (stage 3 done)
-// Producer: stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: release fence, s_waitcnt, relaxed counter add.
-// Consumer: lane 0 polls (relaxed, s_sleep) -> acquire fence -> s_waitcnt -> workgroup barrier -> plain loads.
-// Every wait has a wall-clock limit; on expiry the server raises ABORT (all waits, in the server and in the wait
-// kernels, then return at once) and leaves G3_INFO_CHAIN in the pivot flag: the host reports an error instead of hanging.
-constexpr int CH_MAXP = 254;                 // panels one server launch can walk (boundaries travel in the kernel arguments)
-enum { CH_ERR = 0, CH_ABORT = 32, CH_C3B = 64, CH_CDIAG = 96, CH_CT = 128, CH_CSD = 160, CH_CS = 192, CH_C3A = 224,
-       CH_POTRF = 256, CH_PANEL = CH_POTRF + CH_MAXP + 2, CH_REST = CH_PANEL + CH_MAXP + 2, CH_BULK = CH_REST + CH_MAXP + 2,
-       CH_WORDS = CH_BULK + CH_MAXP + 2 };   // counters on 128-byte lines of their own, then the per-panel flags
-constexpr unsigned long long CH_TIMEOUT = 400000000ull;   // 4 s of the 100 MHz wall clock without progress
-
-#ifdef G3_CHAIN_TRACE   // measurement build: 100 MHz timestamps of workgroup 0 (role 0), worker 0 (role 1) and the last worker (role 2)
-__device__ unsigned long long g3_chain_ts[CH_MAXP * 16 * 3];
-extern "C" int g3x_chain_trace(unsigned long long* out, int zero) {
-  if (zero) {
-    static unsigned long long z[CH_MAXP * 16 * 3];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g3_chain_ts), z, sizeof(z));
-  }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g3_chain_ts), sizeof(g3_chain_ts));
-}
-#define CH_TS(slot) do { if (threadIdx.x == 0 && (me <= 0 || me == NW - 1)) g3_chain_ts[(s * 16 + (slot)) * 3 + (me < 0 ? 0 : (me == 0 ? 1 : 2))] = wall_clock64(); } while (0)
-#else
-#define CH_TS(slot) do { } while (0)
-#endif
-
-struct ChainArgs {
-  void* A;
-  int64_t ld;
-  void* W;
-  int* info;
-  unsigned* ctl;
-  int nblk;
-  int nw;                                    // worker workgroups
-  int bnd[CH_MAXP + 2];                      // first column of every panel, then n
-};
-
-__device__ __forceinline__ unsigned ch_load(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ch_fail(unsigned* ctl, int* info, unsigned code) {
-  __hip_atomic_store(ctl + CH_ERR, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(ctl + CH_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  atomicCAS(info, 0, G3_INFO_CHAIN);
-}
-// one lane: spin until *p >= target; false on abort / timeout
-__device__ __forceinline__ bool ch_spin(unsigned* ctl, int* info, const unsigned* p, unsigned target, unsigned code) {
-  bool ok = true;
-  if (ch_load(p) < target) {
-    const unsigned long long t0 = wall_clock64();
-    unsigned spins = 0;
-    while (ch_load(p) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 31u) == 0) {
-        if (ch_load(ctl + CH_ABORT) != 0) { ok = false; break; }
-        if (wall_clock64() - t0 > CH_TIMEOUT) { ch_fail(ctl, info, code); ok = false; break; }
-      }
-    }
-  }
-  return ok;
-}
-// whole workgroup: wait until *p >= target, then acquire.  `dead` is a sticky LDS word (set once, never cleared).
-__device__ __forceinline__ bool ch_wait(unsigned* ctl, int* info, const unsigned* p, unsigned target, unsigned code, int* dead) {
-  if (threadIdx.x == 0) {
-    if (!ch_spin(ctl, info, p, target, code)) *dead = 1;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  return *dead == 0;
-}
-// whole workgroup: everything this workgroup has stored becomes visible, then *p += 1 (or *p = v)
-__device__ __forceinline__ void ch_signal(unsigned* p, bool add, unsigned v) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (add) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// posted behind a launch of a stream: "that launch is complete" (the stream orders it, the kernel boundary releases it)
-__global__ void chain_post_kernel(unsigned* flag) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-// in front of a launch of a stream: hold the stream until the server has set the flag
-__global__ void chain_wait_kernel(unsigned* ctl, int idx, int* info) {
-  if (threadIdx.x == 0) {
-    (void)ch_spin(ctl, info, ctl + idx, 1u, 100u);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-
-// a 128-wide step (the last step of a panel whose width is an odd multiple of 128): kept out of line so that the loop of
-// the diagonal kernel holds one inlined body only, the fused 256-wide factorisation
-template <typename T>
-__device__ __noinline__ void chain_diag128_step(T* Ajj, int64_t ld, T* Wj, int* info, int64_t rb, DiagLds<T>& S) {
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = wv < 4 ? wv : 11 - wv;
-  switch (w) {
-    case 0: diag128_wave<T, true, 0>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    case 1: diag128_wave<T, true, 1>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    case 2: diag128_wave<T, true, 2>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    case 3: diag128_wave<T, true, 3>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    case 4: diag128_wave<T, true, 4>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    case 5: diag128_wave<T, true, 5>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    case 6: diag128_wave<T, true, 6>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-    default: diag128_wave<T, true, 7>(Ajj, ld, Wj, (int64_t)G3_LB, info, rb, S, lane); break;
-  }
-}
-
-// ---- the diagonal workgroup: a kernel of its own (ONE workgroup), so that the fused 256-wide factorisation keeps the
-// register allocation it has as a stand-alone kernel.  It is launched once per sweep and owns its CU's registers
-// (no 128-VGPR squeeze any more: nothing has to fit beside it, it is placed before the bulk updates start).
-template <typename T>
-#ifndef G3_CHAIN_DIAG_WAVES
-#define G3_CHAIN_DIAG_WAVES 2   // 256 VGPRs: 86-93 us per 256-block beside bulk updates; with the 128 of potrf256_kernel (needed there to fit beside a bulk workgroup) the loop around it spills: 154-170 us
-#endif
-#ifdef G3_CHAIN_DIAG_VGPR
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(G3_CHAIN_DIAG_VGPR))) chain_diag_kernel(const ChainArgs a) {
-#else
-__global__ void __launch_bounds__(512, G3_CHAIN_DIAG_WAVES) chain_diag_kernel(const ChainArgs a) {
-#endif
-  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
-  __shared__ int dead;
-  if (threadIdx.x == 0) dead = 0;
-  __syncthreads();
-  T* const A = (T*)a.A;
-  T* const Wall = (T*)a.W;
-  const int64_t ld = a.ld;
-  unsigned* const ctl = a.ctl;
-  int* const info = a.info;
-  const int NW = a.nw, me = -1;
-  (void)me;
-  DiagLds<T>& S = *reinterpret_cast<DiagLds<T>*>(ch_smem);
-  const int lane0 = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = wv < 4 ? wv : 11 - wv;       // block rows dealt 0 1 2 3 | 7 6 5 4 (see potrf256_kernel)
-  unsigned nd = 0, nSd = 0, n3 = 0;
-  for (int s = 0; s < a.nblk; ++s) {
-    const int c0 = a.bnd[s], n = a.bnd[s + 1] - c0;
-    T* const Q = A + (int64_t)c0 * ld + c0;
-    T* const Wq = Wall + (int64_t)(c0 / G3_LB) * G3_LB * G3_LB;
-    const int nsteps = (n + 2 * G3_LB - 1) / (2 * G3_LB);
-    for (int j = 0; j < nsteps; ++j) {
-      const int cj = 2 * G3_LB * j, wj = (n - cj < 2 * G3_LB) ? n - cj : 2 * G3_LB;
-      bool ok = true;
-      if (j > 0) ok = ch_wait(ctl, info, ctl + CH_CSD, (unsigned)NW * (++nSd), 11u, &dead);
-      else if (s > 0) ok = ch_wait(ctl, info, ctl + CH_C3A, (unsigned)NW * (++n3), 13u, &dead);
-      if (!ok) return;                         // (s == 0: the launch is ordered behind everything queued before the sweep)
-      CH_TS(2 * j);          // diagonal step j may start
-      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        T* Ajj = Q + (int64_t)cj * ld + cj;
-        T* Wj = Wq + (int64_t)(cj / G3_LB) * G3_LB * G3_LB;
-        const int64_t rb = c0 + cj;
-        // the lane index is laundered once per step: nothing derived from it is loop-invariant, so the per-lane index
-        // arithmetic of the factorisation is NOT hoisted out of the panel loop and kept live across it (hoisted, the
-        // kernel spilled 1.4 KB per lane at the 128 VGPRs it must stay within to leave room for a bulk workgroup)
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        if (wj == 2 * G3_LB) {
-          switch (w) {
-            case 0: potrf256_wave<T, 0>(Ajj, ld, Wj, info, rb, S, lane); break;
-            case 1: potrf256_wave<T, 1>(Ajj, ld, Wj, info, rb, S, lane); break;
-            case 2: potrf256_wave<T, 2>(Ajj, ld, Wj, info, rb, S, lane); break;
-            case 3: potrf256_wave<T, 3>(Ajj, ld, Wj, info, rb, S, lane); break;
-            case 4: potrf256_wave<T, 4>(Ajj, ld, Wj, info, rb, S, lane); break;
-            case 5: potrf256_wave<T, 5>(Ajj, ld, Wj, info, rb, S, lane); break;
-            case 6: potrf256_wave<T, 6>(Ajj, ld, Wj, info, rb, S, lane); break;
-            default: potrf256_wave<T, 7>(Ajj, ld, Wj, info, rb, S, lane); break;
-          }
-        } else {
-          chain_diag128_step<T>(Ajj, ld, Wj, info, rb, S);
-        }
-      }
-      CH_TS(2 * j + 1);      // ... and is done
-      ch_signal(ctl + CH_CDIAG, false, ++nd);
-    }
-    // the off-diagonal blocks of L_ss were written (and released) by the workers before the last block could start
-    if (threadIdx.x == 0) __hip_atomic_store(ctl + CH_POTRF + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// ---- the workers' building blocks (not inlined: the kernel stays small, each tile shape keeps its own allocation)
-// one BM x 128 tile of a stripe: C = alpha A B^T + beta C (C may alias A: the tile spans the 128 output columns)
-template <typename T, int BM>
-__device__ __noinline__ void chain_stripe_tile(T* C, const T* gA, const T* gB, int64_t ld, int64_t ldb, int K, T alpha, T beta,
-                                               char* smem) {
-  gemm_tile<T, BM, 128, BM, 16, 2>(C, ld, gA, ld, gB, ldb, K, alpha, beta, 0, 0, false, 0, 0, smem);
-  __syncthreads();
-}
-// one 64 x 64 tile of a lower-triangular update C[m0.., n0..] -= A_rows B_rows^T
-template <typename T>
-__device__ __noinline__ void chain_syrk_tile(T* C, const T* gA, const T* gB, int64_t ld, int K, int m0, int n0, char* smem) {
-  gemm_tile<T, 64, 64, 32, 16, 2>(C, ld, gA, ld, gB, ld, K, T(-1), T(1), m0, n0, true, 0, 0, smem);
-}
-// rows [row0, row0 + nrows) of X (first column of the solve at X): X <- X L^-T for the nblk 128-column blocks of L
-// (its diagonal blocks' inverses in Winv), BM-row stripes dealt to the workers; per block b:
-// X_b -= X_{<b} L_{b,<b}^T, then X_b <- X_b W_b^T
-template <typename T, int BM>
-__device__ __forceinline__ void chain_solve_rows(T* X0, int64_t ld, int nrows, const T* L, const T* Winv, int nblk, int me, int NW,
-                                                 char* smem) {
-  for (int t = me; t < nrows / BM; t += NW) {
-    T* X = X0 + (int64_t)t * BM * ld;
-    for (int b = 0; b < nblk; ++b) {
-      if (b > 0) chain_stripe_tile<T, BM>(X + b * G3_LB, X, L + (int64_t)b * G3_LB * ld, ld, ld, b * G3_LB, T(-1), T(1), smem);
-      chain_stripe_tile<T, BM>(X + b * G3_LB, X + b * G3_LB, Winv + (int64_t)b * G3_LB * G3_LB, ld, (int64_t)G3_LB, G3_LB, T(1), T(0), smem);
-    }
-  }
-}
-template <typename T>
-__device__ __forceinline__ void chain_solve(T* X0, int64_t ld, int nrows, const T* L, const T* Winv, int nblk, int me, int NW, char* smem) {
-  // few rows: 16-row stripes, twice the workgroups with half the products each
-  if (nrows / 32 < NW) chain_solve_rows<T, 16>(X0, ld, nrows, L, Winv, nblk, me, NW, smem);
-  else chain_solve_rows<T, 32>(X0, ld, nrows, L, Winv, nblk, me, NW, smem);
-}
-// tiles (ti, tj), ti0 <= ti < ti1, tj <= ti and tj < tjmax, of C -= X X^T (C anchored on the diagonal), dealt round-robin
-template <typename T>
-__device__ __forceinline__ void chain_syrk(T* C, const T* X, int64_t ld, int K, int ti0, int ti1, int tjmax, int me, int NW, char* smem) {
-  int id = 0;
-  for (int ti = ti0; ti < ti1; ++ti)
-    for (int tj = 0; tj <= ti && tj < tjmax; ++tj, ++id)
-      if (id % NW == me) chain_syrk_tile<T>(C, X + (int64_t)ti * 64 * ld, X + (int64_t)tj * 64 * ld, ld, K, ti * 64, tj * 64, smem);
-}
-
-template <typename T>
-__global__ void __launch_bounds__(512, 4) chain_worker_kernel(const ChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
-  __shared__ int dead;
-  if (threadIdx.x == 0) dead = 0;
-  __syncthreads();
-  T* const A = (T*)a.A;
-  T* const Wall = (T*)a.W;
-  const int64_t ld = a.ld;
-  unsigned* const ctl = a.ctl;
-  int* const info = a.info;
-  const int NW = a.nw, me = (int)blockIdx.x;
-  unsigned nd = 0, nT = 0, nS = 0, n3b = 0;    // phases so far: the same sequence on every workgroup
-  auto failed_now = [&]() { return __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; };
-  for (int s = 0; s < a.nblk; ++s) {
-    const int c0 = a.bnd[s], n = a.bnd[s + 1] - c0;
-    const int e = (s + 1 < a.nblk) ? a.bnd[s + 2] - a.bnd[s + 1] : 0;
-    T* const Q = A + (int64_t)c0 * ld + c0;
-    T* const Wq = Wall + (int64_t)(c0 / G3_LB) * G3_LB * G3_LB;
-    const int nsteps = (n + 2 * G3_LB - 1) / (2 * G3_LB);
-    for (int j = 0; j < nsteps; ++j) {
-      const int cj = 2 * G3_LB * j, wj = (n - cj < 2 * G3_LB) ? n - cj : 2 * G3_LB;
-      if (!ch_wait(ctl, info, ctl + CH_CDIAG, ++nd, 21u, &dead)) return;
-      CH_TS(3 * j);            // saw diagonal step j
-      const int r0 = cj + wj;                       // first row below the step's diagonal block
-      const int rows_in = n - r0;                   // rows of the panel's own diagonal block still below it
-      if (rows_in <= 0) continue;
-      // everything below the first 256 rows of this panel's diagonal block got its last update from the previous job's
-      // stage 3: that must be complete on every worker
-      if (j == 0 && s > 0 && !ch_wait(ctl, info, ctl + CH_C3B, (unsigned)NW * n3b, 27u, &dead)) return;
-      const bool failed = failed_now();
-      // ---- T: X <- X L_jj^-T on columns [cj, cj + wj) of the rows [r0, n)
-      if (!failed)
-        chain_solve<T>(Q + (int64_t)r0 * ld + cj, ld, rows_in, Q + (int64_t)cj * ld + cj, Wq + (int64_t)(cj / G3_LB) * G3_LB * G3_LB,
-                       wj / G3_LB, me, NW, ch_smem);
-      CH_TS(3 * j + 1);        // own stripes done
-      ch_signal(ctl + CH_CT, true, 1u);
-      if (!ch_wait(ctl, info, ctl + CH_CT, (unsigned)NW * (++nT), 23u, &dead)) return;
-      CH_TS(3 * j + 2);        // all stripes done
-      // ---- S: Q[r0 : n, r0 : n] -= X X^T (X = columns [cj, cj + wj) of those rows), lower part, 64 x 64 tiles; the
-      // next step's diagonal block first: the diagonal workgroup goes on as soon as that is done
-      const int wn = (rows_in < 2 * G3_LB) ? rows_in : 2 * G3_LB;      // width of the next step
-      T* C = Q + (int64_t)r0 * ld + r0;
-      const T* X = Q + (int64_t)r0 * ld + cj;
-      if (!failed) chain_syrk<T>(C, X, ld, wj, 0, wn / 64, 1 << 30, me, NW, ch_smem);
-      ch_signal(ctl + CH_CSD, true, 1u);
-      if (!failed) chain_syrk<T>(C, X, ld, wj, wn / 64, rows_in / 64, 1 << 30, me, NW, ch_smem);
-      ch_signal(ctl + CH_CS, true, 1u);
-      if (!ch_wait(ctl, info, ctl + CH_CS, (unsigned)NW * (++nS), 24u, &dead)) return;
-      CH_TS(9 + j);            // trailing update of step j done everywhere
-    }
-    if (e > 0) {
-      // ---- the rows of the next panel's diagonal block, [n, n + e): they must carry Ua_rest(s-1) (hence P2a(s-2))
-      // before they are touched.  Its first 256 rows (H1) first, solved against all of L_ss and applied to the
-      // first diagonal block of the next panel (stage 3, K = n; that block must carry P2a(s-1)): the diagonal
-      // workgroup starts on job s+1 while the workers finish the other rows (H2).
-      const int e1 = e < 2 * G3_LB ? e : 2 * G3_LB;
-      CH_TS(11);               // panel factored, waiting for the extra rows
-      if (s > 0 && !ch_wait(ctl, info, ctl + CH_REST + s, 1u, 22u, &dead)) return;
-      CH_TS(12);               // extra rows available
-      bool failed = failed_now();
-      T* Xe = Q + (int64_t)n * ld;                  // the extra rows, first column of the panel
-      if (!failed) chain_solve<T>(Xe, ld, e1, Q, Wq, n / G3_LB, me, NW, ch_smem);
-      ch_signal(ctl + CH_CT, true, 1u);
-      if (!ch_wait(ctl, info, ctl + CH_CT, (unsigned)NW * (++nT), 26u, &dead)) return;
-      CH_TS(13);               // H1 solved everywhere
-      if (s > 0 && !ch_wait(ctl, info, ctl + CH_BULK + s, 1u, 25u, &dead)) return;
-      CH_TS(14);               // next diagonal block carries P2a(s-1)
-      failed = failed_now();
-      T* C = Q + (int64_t)n * ld + n;
-      if (!failed) chain_syrk<T>(C, Xe, ld, n, 0, e1 / 64, 1 << 30, me, NW, ch_smem);
-      ch_signal(ctl + CH_C3A, true, 1u);
-      CH_TS(15);               // own tiles of the next job's first diagonal block done
-      if (!failed && e > e1) chain_solve<T>(Xe + (int64_t)e1 * ld, ld, e - e1, Q, Wq, n / G3_LB, me, NW, ch_smem);
-      ch_signal(ctl + CH_CT, true, 1u);
-      if (!ch_wait(ctl, info, ctl + CH_CT, (unsigned)NW * (++nT), 28u, &dead)) return;
-      // the rows of block s+1 are solved: the chain stream may start Ua_rest(s)
-      if (me == 0 && threadIdx.x == 0) __hip_atomic_store(ctl + CH_PANEL + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!failed) chain_syrk<T>(C, Xe, ld, n, e1 / 64, e / 64, 1 << 30, me, NW, ch_smem);
-      ch_signal(ctl + CH_C3B, true, 1u);
-      ++n3b;
-    }
-  }
-}
 
 // ---- flat right-looking sweep over NB-wide panels, grouped into super-panels of G panels, with one
 // super-panel of look-ahead on two streams.
@@ -1397,200 +1064,15 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
   return G3_OK;
 }
 
-// ---- the same sweep with the chain on resident workgroups (chain server above).  Per panel s the streams carry:
-//   A:  wait potrf[s] . trsm_rest(s): rows below block s+1 .            -> event G(s)
-//       wait panel[s] . [wait B2a(s-1)] . Ua_rest(s): those rows of block column s+1 . post rest[s+1]
-//   B:  wait G(s) . P2a(s): block column s+2 . post bulk[s+1]          -> event B2a(s)
-//                   P2b(s): everything to the right of it              (the bulk)
-// and the server does the diagonal block, the rows of block s+1 and the update of diagonal block s+1 with panel s.
-template <typename T>
-static int potrf_lookahead_chain(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64_t NB, g3_dtype dt, int64_t E) {
-  const int64_t R = n + E;
-  std::vector<int64_t> bnd;
-  std::vector<int> gb;
-  g3h_panel_bounds(n, NB, 1, ctx->batch, ctx->tune, &bnd, &gb);
-  const int nblk = (int)bnd.size() - 1;
-  const int nev = 2 * nblk + 1;
-  if (ctx->la_nev < nev) {
-    if (ctx->la_ev) {
-      for (int i = 0; i < ctx->la_nev; ++i) (void)hipEventDestroy(ctx->la_ev[i]);
-      free(ctx->la_ev);
-    }
-    ctx->la_nev = nev;
-    ctx->la_ev = (hipEvent_t*)calloc(ctx->la_nev, sizeof(hipEvent_t));
-    if (!ctx->la_ev) return G3_ERR_NOMEM;
-    for (int i = 0; i < ctx->la_nev; ++i) G3_HIP(hipEventCreateWithFlags(&ctx->la_ev[i], hipEventDisableTiming));
-  }
-  hipEvent_t* evG = ctx->la_ev;
-  hipEvent_t* evB2a = ctx->la_ev + nblk;
-  hipEvent_t evJoin = ctx->la_ev[2 * nblk];
-  // The sweep runs on four streams of its own, created back to back at the first chain sweep (chain_sA for the wide
-  // kernels of the chain, chain_sB for the bulk updates, two for the server): the hardware deals queues to its compute
-  // pipes in creation order, and a stream whose queue shares a pipe with a resident kernel's queue crawls -- measured:
-  // the same sweep takes 6.0 or 10.7 ms depending on nothing but the order in which the streams were created.  The
-  // stream the caller sees (the context's own or an adopted one) only brackets the sweep.
-  hipStream_t sUser = ctx->stream;
-  hipStream_t sA = ctx->chain_sA, sB = ctx->chain_sB, sS = ctx->chain_stream;
-  G3_HIP(hipEventRecord(ctx->chain_ev, sUser));
-  G3_HIP(hipStreamWaitEvent(sA, ctx->chain_ev, 0));
-  ctx->stream = sA;
-  struct Restore {
-    g3_ctx* c; hipStream_t u;
-    ~Restore() { c->stream = u; }
-  } restore{ctx, sUser};
-  unsigned* ctl = ctx->chain_ctl;
-  // the control block is cleared behind everything queued on A (the previous sweep's wait kernels included); B and
-  // the server start behind that
-  G3_HIP(hipMemsetAsync(ctl, 0, CH_WORDS * sizeof(unsigned), sA));
-  G3_HIP(hipEventRecord(evJoin, sA));
-  G3_HIP(hipStreamWaitEvent(sB, evJoin, 0));
-  G3_HIP(hipStreamWaitEvent(sS, evJoin, 0));
-  {
-    ChainArgs ca;
-    ca.A = A;
-    ca.ld = ld;
-    ca.W = W;
-    ca.info = ctx->d_info;
-    ca.ctl = ctl;
-    ca.nblk = nblk;
-    for (int i = 0; i <= nblk; ++i) ca.bnd[i] = (int)bnd[i];
-    ca.nw = ctx->chain_wgs - 1;
-    auto kd = chain_diag_kernel<T>;
-    auto kw = chain_worker_kernel<T>;
-    constexpr int LDS_MAX = 160 * 1024 - 256;      // (the kernels have a few static bytes of their own)
-    int lds = 40960;                                // two staging buffers of the 32 x 128 stripe tile
-    if (ctx->chain_lds > lds) lds = ctx->chain_lds < LDS_MAX ? ctx->chain_lds : LDS_MAX;
-    static bool attr_set[G3_MAX_DEVICES][2] = {};
-    const int dev_slot = ctx->device & (G3_MAX_DEVICES - 1);
-    if (!attr_set[dev_slot][sizeof(T) == 8]) {
-      G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-      G3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-      attr_set[dev_slot][sizeof(T) == 8] = true;
-    }
-    hipLaunchKernelGGL(kd, dim3(1), dim3(512), (int)sizeof(DiagLds<T>), sS, ca);
-    G3_LAUNCH_CHECK();
-    G3_HIP(hipStreamWaitEvent(ctx->chain_stream2, evJoin, 0));
-    hipLaunchKernelGGL(kw, dim3((unsigned)ca.nw), dim3(512), lds, ctx->chain_stream2, ca);
-    G3_LAUNCH_CHECK();
-    G3_HIP(hipEventRecord(ctx->chain_ev2, ctx->chain_stream2));
-    G3_HIP(hipEventRecord(ctx->chain_ev3, sS));
-  }
-  auto update = [&](int64_t row0, int64_t col0, int64_t col1, int64_t k0, int64_t k1) -> int {
-    if (col1 <= col0 || row0 >= R || k1 <= k0) return G3_OK;
-    return g3i_gemm_nt_trap(ctx, A + row0 * ld + col0, ld, A + row0 * ld + k0, ld, A + col0 * ld + k0, ld, R - row0,
-                            col1 - col0, k1 - k0, -1.0, 1.0, dt, row0 - col0);
-  };
-  auto wait_flag = [&](hipStream_t st, int idx) -> int {
-    hipLaunchKernelGGL(chain_wait_kernel, dim3(1), dim3(64), 0, st, ctl, idx, ctx->d_info);
-    G3_LAUNCH_CHECK();
-    return G3_OK;
-  };
-  auto post_flag = [&](hipStream_t st, int idx) -> int {
-    hipLaunchKernelGGL(chain_post_kernel, dim3(1), dim3(64), 0, st, ctl + idx);
-    G3_LAUNCH_CHECK();
-    return G3_OK;
-  };
-  int rc = G3_OK;
-  for (int s = 0; s < nblk && !rc; ++s) {
-    const int64_t c = bnd[s], c1 = bnd[s + 1];
-    const bool has_next = s + 1 < nblk;
-    const int64_t c2 = has_next ? bnd[s + 2] : c1;        // first row the server does not touch in job s
-    // ---- stream A
-    rc = wait_flag(sA, CH_POTRF + s);
-    if (!rc && c2 < R)
-      rc = trsm_rec<T>(ctx, A + c * ld + c, c1 - c, ld, A + c2 * ld + c, R - c2, ld, W + (c / LB) * LB * LB, dt);
-    if (rc) break;
-    G3_HIP(hipEventRecord(evG[s], sA));
-    // ---- stream B: panel s applied to everything right of block column s+1 (needs only the rows below block s+1):
-    // block column s+2 first (the server's job s+1 waits for it), then the rest.  (Holding the far part of every update
-    // back by one panel, so that P2a never queues behind it, was measured and is slower: config 2 6.66 -> 7.06 ms -- while
-    // a far update takes longer than a panel the sweep is bound by the bulk stream, however its queue is ordered.)
-    if (c2 < n) {
-      const int64_t c3 = bnd[s + 3];
-      G3_HIP(hipStreamWaitEvent(sB, evG[s], 0));
-      ctx->stream = sB;
-      rc = update(c2, c2, c3, c, c1);                                    // P2a(s)
-      if (!rc) rc = post_flag(sB, CH_BULK + s + 1);
-      if (!rc && hipEventRecord(evB2a[s], sB) != hipSuccess) rc = G3_ERR_HIP;
-      if (!rc) rc = update(c3, c3, n, c, c1);                            // P2b(s)
-      ctx->stream = sA;
-      if (rc) break;
-    } else if (has_next) {
-      G3_HIP(hipEventRecord(evB2a[s], sB));
-    }
-    // ---- stream A again: block column s+1 below its diagonal block
-    if (has_next) {
-      rc = wait_flag(sA, CH_PANEL + s);
-      if (rc) break;
-      if (s >= 1) G3_HIP(hipStreamWaitEvent(sA, evB2a[s - 1], 0));
-      rc = update(c2, c1, c2, c, c1);                                    // Ua_rest(s)
-      if (!rc) rc = post_flag(sA, CH_REST + s + 1);
-    }
-  }
-  // join: A continues only after B has drained and the server has left
-  (void)hipEventRecord(evJoin, sB);
-  (void)hipStreamWaitEvent(sA, evJoin, 0);
-  (void)hipStreamWaitEvent(sA, ctx->chain_ev3, 0);
-  (void)hipStreamWaitEvent(sA, ctx->chain_ev2, 0);
-  (void)hipEventRecord(ctx->chain_ev, sA);
-  (void)hipStreamWaitEvent(sUser, ctx->chain_ev, 0);
-  return rc;
-}
+#ifdef G3_CHAIN_SERVER   // measurement variant only (scripts/variants/chain_server.inc, scripts/build_variant.sh)
+#include "../../scripts/variants/chain_server.inc"
+#endif
+
 
 int g3i_potrf(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, void* invd) {
   return g3i_potrf_tall(ctx, A, n, ld, dt, invd, 0);
 }
 
-bool g3i_chain_gave_up(g3_ctx* ctx, int info) {
-  if (info != G3_INFO_CHAIN) return false;
-  unsigned code = 0;
-  if (ctx->chain_ctl) (void)hipMemcpy(&code, ctx->chain_ctl + CH_ERR, sizeof(code), hipMemcpyDeviceToHost);
-  if (!ctx->chain_broken)
-    fprintf(stderr, "libg3hip: the resident chain workgroups made no progress for %.0f s (wait %u) -- another stream shares their "
-            "hardware queue, or the GPU is oversubscribed; this context falls back to one launch per chain kernel\n",
-            (double)CH_TIMEOUT * 1e-8, code);
-  ctx->chain_broken = true;
-  return true;
-}
-
-// the chain server is used for single (not batched) sweeps whose panel list fits its argument block; it needs its own
-// stream and control block (created with the context) and stays off once a launch of it has given up
-static bool g3i_chain_usable(g3_ctx* ctx, int64_t n, int64_t NB, int G) {
-  if (ctx->chain_wgs < 2 || ctx->chain_broken) return false;
-  if (ctx->batch > 1 || G != 1 || g3_on_bulk_stream(ctx) || ctx->bulk_role) return false;
-  if (NB > 1024) return false;
-  if (n < ctx->chain_min_n || n > ctx->chain_max_n) return false;
-  std::vector<int64_t> bnd;
-  std::vector<int> gb;
-  g3h_panel_bounds(n, NB, 1, ctx->batch, ctx->tune, &bnd, &gb);
-  if ((int)bnd.size() - 1 > CH_MAXP) return false;
-  if (!ctx->chain_ctl) {
-    // first use: the four streams back to back.  The server's two have a CU mask (all CUs), which gives them a hardware
-    // queue of their own -- HIP deals the queues of ordinary streams to several streams, and a stream that shares the
-    // queue of a resident kernel waits for that kernel to end.
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-    uint32_t mask[16];
-    for (int i = 0; i < 16; ++i) mask[i] = 0xffffffffu;
-    const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
-    if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->chain_sA, hipStreamNonBlocking, hi);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->chain_sB, hipStreamNonBlocking, lo);
-    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->chain_stream, words, mask);
-    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->chain_stream2, words, mask);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->chain_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->chain_ev2, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->chain_ev3, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->chain_ctl, CH_WORDS * sizeof(unsigned));
-    if (e != hipSuccess) {
-      ctx->chain_broken = true;
-      return false;
-    }
-  }
-  return true;
-}
 
 static int64_t g3i_panel_width(g3_ctx* ctx, int64_t n, int* G) {
   int64_t NB = ctx->nb_lookahead;
@@ -1624,10 +1106,12 @@ int g3i_potrf_tall(g3_ctx* ctx, void* A, int64_t n, int64_t ld, g3_dtype dt, voi
   int G = 1;
   int64_t NB = g3i_panel_width(ctx, n, &G);
   if (n >= 3 * NB) {
+#ifdef G3_CHAIN_SERVER
     if (g3i_chain_usable(ctx, n, NB, G)) {
       if (dt == G3_F64) return potrf_lookahead_chain<double>(ctx, (double*)A, n, ld, (double*)invd, NB, dt, E);
       return potrf_lookahead_chain<float>(ctx, (float*)A, n, ld, (float*)invd, NB, dt, E);
     }
+#endif
     if (dt == G3_F64) return potrf_lookahead<double>(ctx, (double*)A, n, ld, (double*)invd, NB, G, dt, E);
     return potrf_lookahead<float>(ctx, (float*)A, n, ld, (float*)invd, NB, G, dt, E);
   }
@@ -1730,16 +1214,134 @@ int g3i_trtri_blocks(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, g3_dtyp
   return G3_OK;
 }
 
+// ---- the FULL inverse V = L^-1 of a factored n x n diagonal block (n = 128 * 2^q <= 2048), from the inverses W of its
+// 128 x 128 diagonal blocks, by recursive doubling: with L = [L11 0; L21 L22] and V11, V22 known,
+//   V21 = -V22 L21 V11.
+// Both V and its transpose Vt are carried (the GEMM tile is "NT": C = A B^T with both operands k-contiguous), so every
+// product is one: Ut = Vt11 L21^T (= (L21 V11)^T);  V21 = -V22 Ut^T;  Vt12 = V21^T = -Ut V22^T.  Two dependent launches per
+// level, all pairs of a level in one launch (grid.y), triangular operands cut the reduction range per tile.  The multi-GPU
+// driver broadcasts V instead of (L, W): a rank's panel solve X L^-T is then ONE product X V^T on the matrix pipe instead of
+// a 20-step stripe recursion (g3_dist.hip).  Error: |V - L^-1| ~ kappa(L) eps per level.
+// All four matrices are compact n x n (leading dimension n); V's blocks above and Vt's blocks below the block diagonal are
+// never written and never read.
+template <typename T>
+__global__ void __launch_bounds__(256) trinv_seed_kernel(T* __restrict__ V, T* __restrict__ Vt, const T* __restrict__ W, int64_t ld) {
+  const T* w = W + (int64_t)blockIdx.x * G3_LB * G3_LB;
+  T* v = V + (int64_t)blockIdx.x * G3_LB * (ld + 1);
+  T* vt = Vt + (int64_t)blockIdx.x * G3_LB * (ld + 1);
+  for (int e = threadIdx.x + 256 * blockIdx.y; e < G3_LB * G3_LB; e += 256 * gridDim.y) {
+    const int i = e >> 7, j = e & (G3_LB - 1);
+    const T x = w[e];
+    v[(int64_t)i * ld + j] = x;
+    vt[(int64_t)j * ld + i] = x;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+trinv_mul_kernel(T* V, T* Vt, T* U, const T* L, int64_t ld, int h, int step, const int* __restrict__ info) {
+  const int failed = *info;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = h / 64;
+  const int ti = (int)blockIdx.x / nt, tj = (int)blockIdx.x % nt;
+  const int m0 = ti * 64, n0 = tj * 64;
+  const int64_t o = (int64_t)blockIdx.y * 2 * h;                 // first row / column of this pair
+  T* Up = U + o * ld + o;                                        // Ut of the pair (h x h)
+  if (step == 0) {
+    // Ut[a][b] = sum_{k >= a} Vt11[a][k] L21[b][k]
+    const T* A = Vt + o * ld + o;
+    const T* B = L + (o + h) * ld + o;
+    const int k0 = m0;
+    gemm_tile<T, 64, 64, 32, 32, STAGES>(Up, ld, A + (int64_t)m0 * ld + k0, ld, B + (int64_t)n0 * ld + k0, ld, h - k0, T(1), T(0), m0, n0,
+                                         false, G3_DENSE_OFF, failed, smem);
+  } else if (blockIdx.z == 0) {
+    // V21[i][j] = -sum_{k <= i} V22[i][k] Ut[j][k]
+    const T* A = V + (o + h) * ld + (o + h);
+    const int K = m0 + 64 < h ? m0 + 64 : h;
+    gemm_tile<T, 64, 64, 32, 32, STAGES>(V + (o + h) * ld + o, ld, A + (int64_t)m0 * ld, ld, Up + (int64_t)n0 * ld, ld, K, T(-1), T(0), m0, n0,
+                                         false, G3_DENSE_OFF, failed, smem);
+  } else {
+    // Vt12[j][i] = V21[i][j] = -sum_{k <= i} Ut[j][k] V22[i][k]
+    const T* B = V + (o + h) * ld + (o + h);
+    const int K = n0 + 64 < h ? n0 + 64 : h;
+    gemm_tile<T, 64, 64, 32, 32, STAGES>(Vt + o * ld + (o + h), ld, Up + (int64_t)m0 * ld, ld, B + (int64_t)n0 * ld, ld, K, T(-1), T(0), m0, n0,
+                                         false, G3_DENSE_OFF, failed, smem);
+  }
+}
+
+template <typename T>
+static int trtri_full_t(g3_ctx* ctx, const T* L, int64_t n, const T* W, T* V, T* Vt, T* U) {
+  constexpr int LDS = STAGES * (64 + 64) * ROWB;
+  hipLaunchKernelGGL((trinv_seed_kernel<T>), dim3((unsigned)(n / LB), 8), dim3(256), 0, ctx->stream, V, Vt, W, n);
+  G3_LAUNCH_CHECK();
+  for (int64_t h = LB; 2 * h <= n; h *= 2) {
+    const unsigned tiles = (unsigned)((h / 64) * (h / 64)), pairs = (unsigned)(n / (2 * h));
+    const int pr = g3i_prof_begin(ctx, G3_TAG_GEMM_SMALL, (double)pairs * 2.0 * (double)h * h * h);
+    hipLaunchKernelGGL((trinv_mul_kernel<T>), dim3(tiles, pairs, 1), dim3(256), LDS, ctx->stream, V, Vt, U, L, n, (int)h, 0, ctx->d_info);
+    G3_LAUNCH_CHECK();
+    hipLaunchKernelGGL((trinv_mul_kernel<T>), dim3(tiles, pairs, 2 * h < n ? 2 : 1), dim3(256), LDS, ctx->stream, V, Vt, U, L, n, (int)h, 1,
+                       ctx->d_info);
+    g3i_prof_end(ctx, pr);
+    G3_LAUNCH_CHECK();
+  }
+  return G3_OK;
+}
+
+// n = 128 * 2^q <= 2048; L, V, Vt, U compact n x n; W the 128 x 128 block inverses (n / 128 of them).  A failed pivot flag
+// (d_info of this context, left by the factorisation just before) turns the launches into no-ops.
+int g3i_trtri_full(g3_ctx* ctx, const void* L, int64_t n, const void* W, void* V, void* Vt, void* U, g3_dtype dt) {
+  if (n < LB || n > 2048 || (n & (n - 1)) != 0) return -3;
+  if (dt == G3_F64) return trtri_full_t<double>(ctx, (const double*)L, n, (const double*)W, (double*)V, (double*)Vt, (double*)U);
+  return trtri_full_t<float>(ctx, (const float*)L, n, (const float*)W, (float*)V, (float*)Vt, (float*)U);
+}
+
+extern "C" int g3_trtri_full(g3_ctx* ctx, const void* L_dev, int64_t n, const void* invd_dev, void* V_dev, void* Vt_dev, void* U_dev,
+                             g3_dtype dt) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!L_dev) return -2;
+  if (n < G3_LB || n > 2048 || (n & (n - 1)) != 0) return -3;
+  if (!invd_dev) return -4;
+  if (!V_dev) return -5;
+  if (!Vt_dev) return -6;
+  if (!U_dev) return -7;
+  if (((uintptr_t)L_dev | (uintptr_t)V_dev | (uintptr_t)Vt_dev | (uintptr_t)U_dev) & 15) return -2;
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  return g3i_trtri_full(ctx, L_dev, n, invd_dev, V_dev, Vt_dev, U_dev, dt);
+}
+
+extern "C" int g3_trsm_full(g3_ctx* ctx, const void* V_dev, int64_t n, int64_t ldv, const void* B_dev, int64_t m, int64_t ldb,
+                            void* X_dev, int64_t ldx, g3_dtype dt) {
+  if (!ctx) return -1;
+  g3_dev_guard _dg(ctx);
+  if (!V_dev) return -2;
+  if (n < 0 || n % G3_LB) return -3;
+  const int64_t al = 16 / (int64_t)g3_esize(dt);
+  if (ldv < n || ldv % al) return -4;
+  if (!B_dev) return -5;
+  if (m < 0 || m % 64) return -6;
+  if (ldb < n || ldb % al) return -7;
+  if (!X_dev || X_dev == B_dev) return -8;
+  if (ldx < n) return -9;
+  if (((uintptr_t)V_dev | (uintptr_t)B_dev) & 15) return -2;
+  int rc = g3i_reset_info(ctx);
+  if (rc) return rc;
+  return g3i_gemm_nt_ktri(ctx, X_dev, ldx, B_dev, ldb, V_dev, ldv, m, n, 1.0, 0.0, dt);
+}
+
 static int read_info(g3_ctx* ctx, int* info_host) {
   G3_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   G3_HIP(hipStreamSynchronize(ctx->stream));
   *info_host = *ctx->h_info;
+#ifdef G3_CHAIN_SERVER
   if (g3i_chain_gave_up(ctx, *info_host)) {
     // the matrix was being factored in place: the caller must supply it again (the server is off from now on)
     (void)g3i_reset_info(ctx);
     snprintf(ctx->err, sizeof(ctx->err), "the resident chain workgroups gave up; the factorisation is incomplete -- call again");
     return G3_ERR_HIP;
   }
+#endif
   return G3_OK;
 }
 
@@ -1789,10 +1391,14 @@ extern "C" int g3_potrf_nowait(g3_ctx* ctx, void* A_dev, int64_t n, int64_t ld, 
     else if (dt == G3_F64) rc = potrf_rec<double>(ctx, (double*)A_dev, n, ld, (double*)invd_dev, 0, dt);
     else rc = potrf_rec<float>(ctx, (float*)A_dev, n, ld, (float*)invd_dev, 0, dt);
   } else {
+#ifdef G3_CHAIN_SERVER
     const bool broken = ctx->chain_broken;
     ctx->chain_broken = true;              // (the flag of this call is read much later: no resident workgroups here)
+#endif
     rc = g3i_potrf(ctx, A_dev, n, ld, dt, invd_dev);
+#ifdef G3_CHAIN_SERVER
     ctx->chain_broken = broken;
+#endif
   }
   if (rc) return rc;
   hipLaunchKernelGGL(info_merge_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_info, info_accum_dev);
@@ -1882,14 +1488,18 @@ static int robust_t(g3_ctx* ctx, const T* K, int64_t ldk, T* L, int64_t ldl, int
     G3_LAUNCH_CHECK();
     int r = g3i_potrf(ctx, F, np, ldf, dt, ctx->invd);
     if (r) return r;
+#ifdef G3_CHAIN_SERVER
     const bool chain_was_on = !ctx->chain_broken;
+#endif
     r = read_info(ctx, info);
+#ifdef G3_CHAIN_SERVER
     if (r == G3_ERR_HIP && chain_was_on && ctx->chain_broken) {        // once: the copy above is simply made again
       hipLaunchKernelGGL((copy_lower_pad_kernel<T>), grid, dim3(256), 0, ctx->stream, F, ldf, K, ldk, n, np, (T)add);
       G3_LAUNCH_CHECK();
       r = g3i_potrf(ctx, F, np, ldf, dt, ctx->invd);
       if (!r) r = read_info(ctx, info);
     }
+#endif
     return r;
   };
   int info = 0, tries = 0, fallback = 0;
@@ -1968,6 +1578,6 @@ extern "C" int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void
                          tries_host, fallback_host, jitter_host);
 }
 
-#ifdef G3_PROBE   // measurement build only: the round-4 feasibility probes (scripts/probe_resident.inc)
-#include "../../scripts/probe_resident.inc"
+#ifdef G3_PROBE   // measurement build only: the round-4 feasibility probes (scripts/variants/probe_resident.inc)
+#include "../../scripts/variants/probe_resident.inc"
 #endif

@@ -222,6 +222,24 @@ class HipPanelOps:
             self._chk(self.dev.lib.g3_trsm_rlt(self.dev.ctx, L.data_ptr(), nb, L.stride(0), B.data_ptr(), m, B.stride(0),
                                                self._dt, W.data_ptr()), 'g3_trsm_rlt')
 
+    def invert_block(self, L, nb, W, V):
+        """V (nb x nb, compact) <- L^-1 by recursive doubling from the 128-block inverses W (g3_trtri_full); nb = 128 * 2^q"""
+        key = (nb, self.dev is self.dev_side)
+        if getattr(self, '_inv_scratch_key', None) != key:
+            self._inv_scratch = (self.zeros(nb, nb), self.zeros(nb, nb))
+            self._inv_scratch_key = key
+        Vt, U = self._inv_scratch
+        self._chk(self.dev.lib.g3_trtri_full(self.dev.ctx, L.data_ptr(), nb, W.data_ptr(), V.data_ptr(), Vt.data_ptr(), U.data_ptr(),
+                                             self._dt), 'g3_trtri_full')
+
+    def solve_full(self, V, nb, B, m):
+        """B[m x nb] <- B V^T = B L^-T as ONE K-triangular product (g3_trsm_full), through a compact temporary"""
+        if m > 0:
+            tmp = self.alloc(m, nb)
+            self._chk(self.dev.lib.g3_trsm_full(self.dev.ctx, V.data_ptr(), nb, V.stride(0), B.data_ptr(), m, B.stride(0),
+                                                tmp.data_ptr(), nb, self._dt), 'g3_trsm_full')
+            B.copy_(tmp)
+
     def gemm_sub(self, C_, A, B, m, n, k, lower_only=False):
         """C[m x n] -= A[m x k] B[n x k]^T"""
         if m > 0 and n > 0:
@@ -320,8 +338,16 @@ class DistributedGP:
         self.rows_rhs = len(self.my_chunks) * pad
         self.loff = {I: t * nb for t, I in enumerate(self.my_blocks)}
         self.A = o.zeros(self.rows_mat + self.rows_rhs, self.Np)          # local rows, full width
-        # nb x nb diagonal factor followed by the inverses of its 128 x 128 diagonal blocks (double buffer)
-        self.dbuf = [o.zeros(1, nb * nb + nb * pad), o.zeros(1, nb * nb + nb * pad)]
+        # Panel solve as ONE product (as g3_dist.hip, round 5): the owner of a diagonal block inverts the whole nb x nb factor
+        # and broadcasts V = L^-1 (nb x nb) instead of (L, its 128-block inverses); a rank's rows of the panel are X V^T.
+        # Needs nb = 128 * 2^q <= 2048; G3_DIST_FULLINV=0 keeps the blocked solve (the same switch as the native driver).
+        import os as _os
+        q = nb // pad
+        self.fullinv = (_os.environ.get('G3_DIST_FULLINV', '1') != '0' and nb <= 2048 and (q & (q - 1)) == 0
+                        and hasattr(o, 'invert_block'))
+        # nb x nb diagonal factor, the inverses of its 128 x 128 diagonal blocks, [its full inverse] (double buffer)
+        dlen = nb * nb + nb * pad + (nb * nb if self.fullinv else 0)
+        self.dbuf = [o.zeros(1, dlen), o.zeros(1, dlen)]
         self._perms = {}
         cmax = max(self._perm(0)[0], 1) if self.nblk > 1 else 1
         # panel rows on their way out / gathered from every rank (double buffers: the gather of panel k+1 runs
@@ -376,7 +402,17 @@ class DistributedGP:
     def _LW(self, k):
         nb = self.nb
         f = self.dbuf[k % 2]
-        return f[0, :nb * nb].view(nb, nb), f[0, nb * nb:].view(nb, 128)
+        return f[0, :nb * nb].view(nb, nb), f[0, nb * nb:nb * nb + nb * 128].view(nb, 128)
+
+    def _V(self, k):
+        nb = self.nb
+        return self.dbuf[k % 2][0, nb * nb + nb * 128:].view(nb, nb)
+
+    def _bc(self, k):
+        """what travels for diagonal block k: V alone with the full inverse, else (L, block inverses)"""
+        nb = self.nb
+        f = self.dbuf[k % 2]
+        return f[:, nb * nb + nb * 128:] if self.fullinv else f
 
     def _diag(self, I):
         """the nb x nb diagonal block of an owned row block (a view of the local matrix)"""
@@ -478,6 +514,8 @@ class DistributedGP:
         L.copy_(D)
         o.potrf_block(L, self.nb, W)
         D.copy_(L)                                       # kept for the log-determinant
+        if self.fullinv:
+            o.invert_block(L, self.nb, W, self._V(k))
 
     def _solve_and_gather(self, k):
         """panel k: solve my rows below block k (right-hand-side rows included) against L_kk, then start the
@@ -486,7 +524,10 @@ class DistributedGP:
         L, W = self._LW(k)
         c0, c1 = k * nb, (k + 1) * nb
         r_lo = sum(1 for I in self.my_blocks if I <= k) * nb
-        o.trsm(L, nb, W, A[r_lo:, c0:c1], A.shape[0] - r_lo)
+        if self.fullinv:
+            o.solve_full(self._V(k), nb, A[r_lo:, c0:c1], A.shape[0] - r_lo)
+        else:
+            o.trsm(L, nb, W, A[r_lo:, c0:c1], A.shape[0] - r_lo)
         if self.nblk - 1 - k <= 0:
             return None
         cnt, _ = self._perm(k)
@@ -503,14 +544,14 @@ class DistributedGP:
         receive"""
         o, nb = self.ops, self.nb
         if self.owner(j) != self.rank:
-            return self._bcast(self.dbuf[j % 2], self.owner(j), async_op=True)
+            return self._bcast(self._bc(j), self.owner(j), async_op=True)
         with o.lookahead():
             o.wait_event(ev)
             lo = self.loff[j]
             Pn = self.A[lo:lo + nb, (j - 1) * nb:j * nb]
             o.gemm_sub(self.A[lo:lo + nb, j * nb:(j + 1) * nb], Pn, Pn, nb, nb, nb, lower_only=True)
             self._factor_block(j)
-            return self._bcast(self.dbuf[j % 2], self.owner(j), async_op=True)
+            return self._bcast(self._bc(j), self.owner(j), async_op=True)
 
     def factor(self, spec, spec_cross, X, Xs, delta, jitter=0.0):
         """returns the global potrf info (0 = success).
@@ -535,7 +576,7 @@ class DistributedGP:
         o.reset_info()
         if self.owner(0) == self.rank:
             self._factor_block(0)
-        self._wait(self._bcast(self.dbuf[0], self.owner(0), async_op=False), 'bcast')
+        self._wait(self._bcast(self._bc(0), self.owner(0), async_op=False), 'bcast')
         work_g = self._solve_and_gather(0)
         work_b = self._lookahead(1, None) if self.nblk > 1 else None
         ev_prev = None                                   # B_{k-1}

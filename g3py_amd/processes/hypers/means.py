@@ -18,7 +18,9 @@ class Mean(Hypers):
         """m(x) for B rows of hyper values at once (values_rows[name][j] = row j) -> (B, N).  Base: row by row."""
         return np.stack([self(x, {k: np.asarray(v)[j] for k, v in values_rows.items()}) for j in range(B)])
 
-    JAC_CONSTANT = True     # d m(x) / d hyper does not depend on the hyper values (Zero, Bias, Linear: linear in them)
+    # True only for means that are linear in their hypers (d m(x) / d hyper does not depend on the hyper values): the chain
+    # gradient then evaluates `jac` once for all rows.  A user-defined mean inherits False and takes the per-row loop.
+    JAC_CONSTANT = False
 
     def jac(self, x, values):
         """[(hyper, d m(x) / d hyper as an N x size array)] for the free hypers -- what Theano's
@@ -33,6 +35,8 @@ Location = Mean
 
 
 class Zero(Mean):
+    JAC_CONSTANT = True
+
     def eval(self, x, values):
         return np.zeros(x.shape[0], dtype=x.dtype)
 
@@ -42,6 +46,7 @@ class Zero(Mean):
 
 
 class Bias(Mean):
+    JAC_CONSTANT = True
     SLOTS = (Slot('bias', False, '_Bias'),)
 
     def default_hypers(self, x=None, y=None):
@@ -60,6 +65,7 @@ class Bias(Mean):
 
 
 class Linear(Mean):
+    JAC_CONSTANT = True
     SLOTS = (Slot('constant', False, '_Constant'), Slot('coeff', False, '_Coeff', per_column=True))
 
     def default_hypers(self, x=None, y=None):

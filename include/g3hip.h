@@ -212,6 +212,20 @@ int g3_potrf_robust(g3_ctx* ctx, const void* K_dev, int64_t ldk, void* L_dev, in
 int g3_trsm_rlt(g3_ctx* ctx, const void* L_dev, int64_t n, int64_t ldl, void* B_dev, int64_t m,
                 int64_t ldb, g3_dtype dt, const void* invd_dev);
 
+/* The FULL inverse V = L^-1 of a factored n x n lower block, n = 128 * 2^q <= 2048, by recursive doubling from the
+ * inverses of its 128 x 128 diagonal blocks (invd_dev, as g3_potrf leaves them): V21 = -V22 L21 V11 level by level, two
+ * small MFMA launches per level.  L, V and the two scratch matrices Vt (= V^T on return, except for the last level) and U
+ * are COMPACT n x n (leading dimension n); only the lower block triangle of V is written.  The multi-GPU driver broadcasts
+ * V instead of (L, invd): a rank's panel solve -- the `solve_lower_triangular` of tensors.py:265-270 / gaussian.py:212 --
+ * is then one product (g3_trsm_full).  |V - L^-1| ~ kappa(L) eps per level. */
+int g3_trtri_full(g3_ctx* ctx, const void* L_dev, int64_t n, const void* invd_dev, void* V_dev, void* Vt_dev, void* U_dev,
+                  g3_dtype dt);
+
+/* X_out = B V^T for V = L^-1 from g3_trtri_full (n x n, leading dimension ldv): X L^T = B solved as ONE K-triangular MFMA
+ * product, out of place (X_out must not overlap B).  B, X_out: m x n, m a multiple of 64, n a multiple of 128. */
+int g3_trsm_full(g3_ctx* ctx, const void* V_dev, int64_t n, int64_t ldv, const void* B_dev, int64_t m, int64_t ldb, void* X_dev,
+                 int64_t ldx, g3_dtype dt);
+
 /* ---- reductions (device in, host out; synchronising) ----------------------------------- */
 /* out[0] = sum_i log L[i][i], out[1] = sum_i a[i]^2, out[2] = #non-finite in a,
  * out[3] = #non-finite or <= 0 on diag(L)   -- the pieces of logp_cho, gaussian.py:208-241 */

@@ -103,6 +103,16 @@ class NumpyPanelOps:
             b = B.numpy()
             b[:m, :nb] = scipy.linalg.solve_triangular(np.tril(L.numpy()[:nb, :nb]), b[:m, :nb].T, lower=True).T
 
+    def invert_block(self, L, nb, W, V):
+        # the full inverse the owner broadcasts instead of (L, block inverses): distributed.py::_factor_block
+        if not getattr(self, '_info', 0):
+            V.numpy()[:nb, :nb] = scipy.linalg.solve_triangular(np.tril(L.numpy()[:nb, :nb]), np.eye(nb), lower=True)
+
+    def solve_full(self, V, nb, B, m):
+        if m > 0 and not getattr(self, '_info', 0):
+            b = B.numpy()
+            b[:m, :nb] = b[:m, :nb] @ np.tril(V.numpy()[:nb, :nb]).T
+
     def gemm_sub(self, C, A, B, m, n, k, lower_only=False):
         if m > 0 and n > 0 and not getattr(self, '_info', 0):
             c = C.numpy()

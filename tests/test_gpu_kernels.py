@@ -233,6 +233,44 @@ def test_trsm_rlt(dev, n, m):
     assert np.abs(X - ref).max() < 1e-11 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+@pytest.mark.parametrize('n,m', [(128, 64), (256, 192), (512, 320), (1024, 1088), (2048, 128)])
+def test_full_inverse_of_a_diagonal_factor_and_the_one_product_solve(dev, dt, n, m):
+    """g3_trtri_full: V = L^-1 by recursive doubling from the 128-block inverses; g3_trsm_full: X L^T = B as the ONE
+    K-triangular product B V^T -- what the multi-GPU driver does with a broadcast diagonal factor (tensors.py:265-270)"""
+    import ctypes as C
+    from g3py_amd import _lib
+    rng = np.random.default_rng(n + m)
+    L = scipy.linalg.cholesky(_spd(rng, n), lower=True)
+    Ld = dev.upload(L.astype(dt))
+    code = _lib.dtype_code(dt)
+    # the block inverses: factor K = L L^T on the device (leaves L and inv(L_kk))
+    Kd = dev.upload((L @ L.T).astype(dt))
+    W = dev.alloc_inverses(n, dt)
+    info = C.c_int(0)
+    assert dev.lib.g3_potrf(dev.ctx, Kd.ptr, n, Kd.ld, code, W.ptr, C.byref(info)) == 0 and info.value == 0
+    V, Vt, U = (dev.alloc(n, n, dt, zero=True) for _ in range(3))
+    assert dev.lib.g3_trtri_full(dev.ctx, Kd.ptr, n, W.ptr, V.ptr, Vt.ptr, U.ptr, code) == 0
+    Lg = np.tril(dev.download(Kd).astype(np.float64))
+    Vh = dev.download(V).astype(np.float64)
+    assert np.abs(np.triu(Vh, 1)).max() == 0.0
+    ref = np.linalg.inv(Lg)
+    tol = (5e-13 if dt == np.float64 else 3e-4) * np.linalg.cond(Lg)
+    assert np.abs(Vh - ref).max() <= tol * np.abs(ref).max()
+    if n > 128:      # the transpose is carried up to the last level's off-diagonal block
+        h = n // 2
+        np.testing.assert_array_equal(dev.download(Vt)[:h, :h], Vh[:h, :h].T.astype(dt))
+    B = rng.standard_normal((m, n)).astype(dt)
+    Bd, Xd = dev.upload(B), dev.alloc(m, n, dt, zero=True)
+    assert dev.lib.g3_trsm_full(dev.ctx, V.ptr, n, n, Bd.ptr, m, n, Xd.ptr, n, code) == 0
+    X = dev.download(Xd).astype(np.float64)
+    want = scipy.linalg.solve_triangular(Lg, B.astype(np.float64).T, lower=True).T
+    assert np.abs(X - want).max() <= tol * np.abs(want).max()
+    # argument checks: a block size that is not 128 * 2^q, aliasing
+    assert dev.lib.g3_trtri_full(dev.ctx, Kd.ptr, 384, W.ptr, V.ptr, Vt.ptr, U.ptr, code) == -3
+    assert dev.lib.g3_trsm_full(dev.ctx, V.ptr, n, n, Bd.ptr, m, n, Bd.ptr, n, code) == -8
+
+
 def test_potrf_robust_follows_reference_schedule(dev, golden_dir):
     """CholeskyRobust (g3py/libs/tensors.py:197-222): jitter schedule, lift of non-positive
     diagonals and the 1e-10*I fallback, against oracle fixtures."""

@@ -358,12 +358,12 @@ def test_config5_matches_oracle_pin(dev, golden_dir, name, dtype, rtol, atol):
 
 
 @pytest.mark.parametrize('env', [{'G3_SB': '2'}, {'G3_SB': '3', 'G3_NB': '256'}, {'G3_SB': '4', 'G3_NB': '128', 'G3_NB_TAIL': '0'},
-                                 {'G3_GEMM_BIG_MIN': '64'}, {'G3_CHAIN': '1'}, {'G3_CHAIN': '1', 'G3_CHAIN_WGS': '5'},
+                                 {'G3_GEMM_BIG_MIN': '64'},
                                  {'G3_TRSM_SPLIT_MIN': '1024', 'G3_TRSM_SPLIT_N': '256'}])
 def test_alternative_sweep_schedules_give_the_same_factor(tmp_path, env):
     """the knobs README.md documents select other schedules of the SAME arithmetic: super-panels (G3_SB: bulk updates
-    with K = G3_SB x panel width), the 128 x 128 tile from 64 tiles on, the chain of the sweep on resident workgroups
-    (G3_CHAIN=1, round 4), the tall panel solve split at the launch level (G3_TRSM_SPLIT_*).  Each must reproduce the default sweep's statistics (the environment is read when a context is
+    with K = G3_SB x panel width), the 128 x 128 tile from 64 tiles on, the tall panel solve split at the launch level
+    (G3_TRSM_SPLIT_*).  Each must reproduce the default sweep's statistics (the environment is read when a context is
     created: run in a child)"""
     import json
     import os
@@ -395,7 +395,7 @@ print('RESULT ' + json.dumps(out))
 
     def run(extra):
         e = dict(os.environ)
-        for k in ('G3_SB', 'G3_NB', 'G3_NB_TAIL', 'G3_GEMM_BIG_MIN', 'G3_CHAIN', 'G3_CHAIN_WGS', 'G3_TRSM_SPLIT_MIN', 'G3_TRSM_SPLIT_N'):
+        for k in ('G3_SB', 'G3_NB', 'G3_NB_TAIL', 'G3_GEMM_BIG_MIN', 'G3_TRSM_SPLIT_MIN', 'G3_TRSM_SPLIT_N'):
             e.pop(k, None)
         e.update(extra)
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=e)
