@@ -257,6 +257,60 @@ def cpu_baseline(N, d, M, seed, n_cpu):
                 extrapolation='N^3 from the sample (flagged: not measured)' if n_cpu < N else None), lp
 
 
+def _pass_summary(args, N, M, S, pd, pin):
+    """one timed pass of a multi-rank run (a collective schedule) in the `schedules` block of the line"""
+    sec = pd['elapsed'] / args.steps
+    med = float(np.median(pd['step_s'])) if pd['step_s'] else sec
+    fl = step_flops(N, M, S)
+    o = {'ms_per_step': sec * 1e3, 'ms_per_step_median': med * 1e3, 'value': fl / med / 1e12, 'value_mean': fl / sec / 1e12,
+         'logp': pd['logp']}
+    if pin is not None:
+        o['logp_rel_err'] = abs(pd['logp'] - pin) / abs(pin)
+        o['pin_ok'] = bool(o['logp_rel_err'] <= 1e-8)
+    if pd['comm_all'] is not None:
+        o['comm'] = {'per_rank': [{k: _per_step(v, args.steps) for k, v in r.items()} for r in pd['comm_all']]}
+    return o
+
+
+def _per_step(v, steps):
+    o = {'calls_per_step': v['calls'] / steps, 'bytes_per_step': v['bytes'] / steps}
+    if 'device_ms' in v:
+        o['device_ms_per_step'] = v['device_ms'] / steps
+    else:
+        o['host_wait_s_per_step'] = v['wait_s'] / steps
+    return o
+
+
+def _pass_line(args, world, N, d, M, S, pd, sched):
+    """a complete line from ONE pass: what is printed if a later pass never comes back"""
+    sec = pd['elapsed'] / args.steps
+    med = float(np.median(pd['step_s'])) if pd['step_s'] else sec
+    fl = step_flops(N, M, S)
+    seed = 1005 if args.f32 else (1003 if args.kernel == 'mat52cos' else (1002 if N == 8192 else 1004))
+    pin = _golden_logp(N, d, M, seed, args.kernel) if not (args.f32 or S > 0) else None
+    ln = {'metric': 'GP logp+predict end-to-end (Gram+Cholesky+solves), N=%d %s: algorithmic TFLOP/s' % (N, 'fp32' if args.f32 else 'fp64'),
+          'value': fl / med / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+          'ms_per_step': sec * 1e3, 'ms_per_step_median': med * 1e3, 'value_mean': fl / sec / 1e12, 'higher_is_better': True,
+          'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if args.f32 else 'f64', 'data': 'synthetic',
+          'config': {'workload': args.kernel.upper() + '-kernel GaussianProcess, N=%d d=%d, M=%d test points: Gram + blocked Cholesky + '
+                                 'L^-1 y (logp) + cross-Gram + %d-rhs trsm + posterior mean/variance' % (N, d, M, M),
+                     'N': N, 'd': d, 'M': M, 'parallelism': pd['parallelism']},
+          'e2e_sec': med, 'logp': pd['logp'], 'schedule': sched,
+          'schedules': {sched: _pass_summary(args, N, M, S, pd, pin)}}
+    g = {k: sum(pd['prof'][t][k] for t in ('gemm_bulk', 'gemm_mid', 'gemm_small')) for k in ('count', 'ms', 'work')}
+    if g['count'] and g['ms'] > 0:
+        ach = g['work'] / (g['ms'] * 1e-3) / 1e12
+        peak = FP32_MATRIX_PEAK_TFLOPS if args.f32 else FP64_MATRIX_PEAK_TFLOPS
+        ln['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                          'kernel': 'gemm_nt_kernel<*>: rank 0, staircase launches of the bulk stream + a 1-in-16 sample of the chain stream\'s',
+                          'launches_per_step': g['count'] / args.steps, 'avg_launch_ms': g['ms'] / g['count'],
+                          'avg_launch_flops': g['work'] / g['count']}
+    if pin is not None:
+        ln['logp_ref'] = pin
+        ln['logp_rel_err'] = abs(pd['logp'] - pin) / abs(pin)
+    return ln
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -325,7 +379,8 @@ def main():
     # G3_DIST_BACKEND=gloo (python driver only) rehearses N > 1 on a one-GPU box: ranks may then share a device.
     driver = os.environ.get('G3_DIST_DRIVER', 'native')
     backend = os.environ.get('G3_DIST_BACKEND', 'nccl')
-    native_transport = 'callbacks' if backend == 'gloo' else 'rccl'   # gloo + native: host-staged collectives (rehearsal)
+    # gloo + native: host-staged collectives served by the library's worker threads, stream-ordered like RCCL calls (rehearsal)
+    native_transport = os.environ.get('G3_DIST_CALLBACKS', 'callbacks_async') if backend == 'gloo' else 'rccl'
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
@@ -469,30 +524,35 @@ def main():
             args.nb = 1024      # measured (replay transport, profiles/r04_replay_*): 1024-row blocks are faster than 512 at every P for configs 4 and 5
         dgp = None
         driver_fallback = None       # reason when the native driver was asked for and could not be used
-        if driver == 'native':
-            why = ''
-            try:
-                with _StdoutToStderr():
-                    dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, dtype=npdt, transport=native_transport)
-            except Exception as e:       # noqa: BLE001 -- any failure on any rank sends ALL ranks to the python driver
-                why = '%s: %s' % (type(e).__name__, e)
-            ok = torch.tensor([0 if dgp is None else 1], dtype=torch.int32)
-            if world > 1:
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if dgp is not None:
-                    dgp.close()
-                    dgp = None
-                driver = 'python (native driver unavailable%s)' % ((': ' + why) if why else ' on another rank')
-                driver_fallback = why or 'the native driver could not be created on another rank'
-                if rank == 0:
-                    print('bench.py: falling back to the torch.distributed driver -- ' + driver, file=sys.stderr)
-        if dgp is None:
-            gb = 'nccl' if (world > 1 and dist.get_backend() == 'gloo' and backend == 'nccl') else None
-            dgp = DistributedGP(dev, dist if (world > 1 or solo_pg) else None, rank, world, N, d, M, nb=args.nb, torch_device=tdev,
-                                dtype=npdt, group_backend=gb)
-        native = isinstance(dgp, NativeDistributedGP)
         result = {}
+
+        def make_driver():
+            """the driver object of this pass; the native driver reads G3_DIST_SERIAL_COLL when it is created"""
+            nonlocal driver, driver_fallback
+            d_ = None
+            if driver == 'native':
+                why = ''
+                try:
+                    with _StdoutToStderr():
+                        d_ = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=args.nb, dtype=npdt, transport=native_transport)
+                except Exception as e:       # noqa: BLE001 -- any failure on any rank sends ALL ranks to the python driver
+                    why = '%s: %s' % (type(e).__name__, e)
+                ok = torch.tensor([0 if d_ is None else 1], dtype=torch.int32)
+                if world > 1:
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if d_ is not None:
+                        d_.close()
+                        d_ = None
+                    driver = 'python (native driver unavailable%s)' % ((': ' + why) if why else ' on another rank')
+                    driver_fallback = why or 'the native driver could not be created on another rank'
+                    if rank == 0:
+                        print('bench.py: falling back to the torch.distributed driver -- ' + driver, file=sys.stderr)
+            if d_ is None:
+                gb = 'nccl' if (world > 1 and dist.get_backend() == 'gloo' and backend == 'nccl') else None
+                d_ = DistributedGP(dev, dist if (world > 1 or solo_pg) else None, rank, world, N, d, M, nb=args.nb, torch_device=tdev,
+                                   dtype=npdt, group_backend=gb)
+            return d_
 
         def step():
             if S > 0:
@@ -504,53 +564,124 @@ def main():
                 result['logp'] = lp
             else:
                 result['logp'] = dgp.step(spec_n, spec_f, Xd, Xsd, dd)
-        parallelism = 'row-block-cyclic x%d (nb=%d): diagonal-factor broadcast + panel all-gather (%s), look-ahead; driver: %s' \
-            % (world, args.nb, ('RCCL' if (native_transport == 'rccl' if native else backend == 'nccl') else 'gloo, host-staged: rehearsal'),
-               'libg3hip g3_dist_* (C++ loop, library-owned communicators)' if native else 'torch.distributed (' + str(driver) + ')')
 
-    with _StdoutToStderr():             # (the first collective of a communicator prints RCCL's banner)
-        for _ in range(args.warmup):
-            step()
-    # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
-    dev.prof_enable(0 if args.no_prof else (3 if use_dist else 1))
-    dev.prof_reset()
-    if use_dist:
-        dgp.comm_stats()         # reset: the warm-up's lazy RCCL connection setup is not part of the timed steps
-    if use_dist and native and not args.no_prof:
-        dgp.prof_enable(2)       # every MFMA GEMM launch of the driver's bulk stream (two staircase launches per step)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step_s = []
-    for _ in range(args.steps):
-        ts0 = time.perf_counter()
-        step()                   # (ends with a host synchronisation: the scalars of the evaluation come back)
-        step_s.append(time.perf_counter() - ts0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = dev.prof_collect()
-    dev.prof_enable(False)
-    if use_dist and native and not args.no_prof:
-        pb = dgp.prof_collect()
-        for k_ in pb:            # the bulk stream's launches are where a rank's flops are
-            for f_ in ('count', 'ms', 'work'):
-                prof[k_][f_] += pb[k_][f_]
-    if world > 1:
-        t = torch.tensor([elapsed] + step_s, dtype=torch.float64, device=tdev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the slowest rank, for the whole region and step by step
-        elapsed, step_s = float(t[0].item()), [float(v) for v in t[1:]]
-    comm_all = None
-    if use_dist:
-        # per-rank collective counts, bytes over the fabric (sent + received) and host seconds spent waiting
-        mine = dgp.comm_stats()
+    # ---- the timed region.  Several ranks through the native driver: TWO passes in the same processes --
+    # first with the two communicators never in flight together (G3_DIST_SERIAL_COLL=1: the conservative schedule, which
+    # cannot stall on the order of concurrent collectives), its line kept; then the driver is destroyed, the overlapped
+    # (default) one created and the region repeated.  ONE line comes out, with both (`schedules`), the headline the faster
+    # pass that reproduced the oracle pin.  If the overlapped pass runs into its limit the serial line is printed with
+    # `overlap_timeout` and every rank exits non-zero: the first real multi-GPU run cannot come back empty.
+    schedules = ['default']
+    if use_dist and world > 1 and driver == 'native':
+        schedules = [v for v in os.environ.get('G3_BENCH_SCHEDULES', 'serial,overlapped').split(',') if v in ('serial', 'overlapped')] \
+            or ['overlapped']
+    passes = {}
+    overlap_wd = None
+    serial_line = [None]
+    for sched in schedules:
+        if use_dist:
+            if sched != 'default':
+                os.environ['G3_DIST_SERIAL_COLL'] = '1' if sched == 'serial' else '0'
+            dgp = make_driver()
+            native = isinstance(dgp, NativeDistributedGP)
+            if not native:
+                schedules = [sched]                      # the torch.distributed driver has one schedule
+            parallelism = 'row-block-cyclic x%d (nb=%d): diagonal-factor broadcast + panel all-gather (%s), look-ahead; driver: %s' \
+                % (world, args.nb, ('RCCL' if (native_transport == 'rccl' if native else backend == 'nccl') else 'gloo, host-staged: rehearsal'),
+                   'libg3hip g3_dist_* (C++ loop, library-owned communicators)' if native else 'torch.distributed (' + str(driver) + ')')
+            if sched == 'overlapped' and 'serial' in passes and watchdog is not None:
+                import threading
+                lim2 = min(float(os.environ.get('G3_BENCH_WATCHDOG_S', '900')),
+                           max(60.0, 30.0 * passes['serial']['wall_s']))
+                lim2 = float(os.environ.get('G3_BENCH_OVERLAP_LIMIT_S', lim2))
+
+                def _overlap_expired(lim2=lim2):
+                    sys.stderr.write('bench.py: rank %d: the overlapped schedule made no progress for %.0f s; the line of the serial-'
+                                     'collective pass stands (G3_DIST_SERIAL_COLL=1 selects it)\n' % (rank, lim2))
+                    if rank == 0 and serial_line[0] is not None:
+                        ln = dict(serial_line[0])
+                        ln['overlap_timeout'] = True
+                        ln['overlap_limit_s'] = lim2
+                        print(json.dumps(ln), flush=True)
+                    sys.stderr.flush()
+                    os._exit(4)
+                overlap_wd = threading.Timer(lim2, _overlap_expired)
+                overlap_wd.daemon = True
+                overlap_wd.start()
+        t_wall0 = time.perf_counter()
+        with _StdoutToStderr():             # (the first collective of a communicator prints RCCL's banner)
+            for _ in range(args.warmup):
+                step()
+        # one GPU: HIP events around the bulk GEMM launches only; several GPUs: around every 16th MFMA GEMM launch of rank 0
+        dev.prof_enable(0 if args.no_prof else (3 if use_dist else 1))
+        dev.prof_reset()
+        if use_dist:
+            dgp.comm_stats()         # reset: the warm-up's lazy RCCL connection setup is not part of the timed steps
+        if use_dist and native and not args.no_prof:
+            dgp.prof_enable(2)       # every MFMA GEMM launch of the driver's bulk stream (two staircase launches per step)
         if world > 1:
-            comm_all = [None] * world
-            dist.all_gather_object(comm_all, mine)
-        else:
-            comm_all = [mine]
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_s = []
+        for _ in range(args.steps):
+            ts0 = time.perf_counter()
+            step()                   # (ends with a host synchronisation: the scalars of the evaluation come back)
+            step_s.append(time.perf_counter() - ts0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        prof = dev.prof_collect()
+        dev.prof_enable(False)
+        if use_dist and native and not args.no_prof:
+            pb = dgp.prof_collect()
+            for k_ in pb:            # the bulk stream's launches are where a rank's flops are
+                for f_ in ('count', 'ms', 'work'):
+                    prof[k_][f_] += pb[k_][f_]
+        if world > 1:
+            t = torch.tensor([elapsed] + step_s, dtype=torch.float64, device=tdev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the slowest rank, for the whole region and step by step
+            elapsed, step_s = float(t[0].item()), [float(v) for v in t[1:]]
+        comm_all = None
+        if use_dist:
+            # per-rank collective counts, bytes over the fabric (sent + received) and host seconds spent waiting
+            mine = dgp.comm_stats()
+            if world > 1:
+                comm_all = [None] * world
+                dist.all_gather_object(comm_all, mine)
+            else:
+                comm_all = [mine]
+        if overlap_wd is not None:
+            overlap_wd.cancel()
+            overlap_wd = None
+        passes[sched] = dict(elapsed=elapsed, step_s=step_s, prof=prof, comm_all=comm_all, logp=float(result['logp']),
+                             draws=result.get('draws'), cov_tries=result.get('cov_tries', 0), parallelism=parallelism,
+                             wall_s=time.perf_counter() - t_wall0)
+        if sched != schedules[-1]:
+            # the serial pass is complete: its line is ready should the overlapped pass never come back; then the driver goes
+            # (communicators, streams, buffers) and the next schedule's is created in the same processes
+            if rank == 0:
+                serial_line[0] = _pass_line(args, world, N, d, M, S, passes[sched], sched)
+            dgp.close()
+            dgp = None
+            if world > 1:
+                dist.barrier()
+        if sched == schedules[-1]:
+            break
+    # the headline pass: the faster of those that reproduced the pin (decided on rank 0's numbers, which are the maxima
+    # over ranks; every rank holds the same step times)
+    pin = _golden_logp(N, d, M, seed, args.kernel) if not (args.f32 or S > 0) else None
+
+    def _ok(pd):
+        return pin is None or abs(pd['logp'] - pin) <= 1e-8 * abs(pin)
+    order = sorted(passes, key=lambda k_: (not _ok(passes[k_]), float(np.median(passes[k_]['step_s']))))
+    chosen = order[0]
+    pd = passes[chosen]
+    elapsed, step_s, prof, comm_all, parallelism = pd['elapsed'], pd['step_s'], pd['prof'], pd['comm_all'], pd['parallelism']
+    result['logp'] = pd['logp']
+    if pd['draws'] is not None:
+        result['draws'], result['cov_tries'] = pd['draws'], pd['cov_tries']
 
     dist_grad = None
     if use_dist and native and args.grad and S == 0:
@@ -589,7 +720,10 @@ def main():
             'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'ms_per_step_median': sec_med * 1e3,
             'value_mean': flops / sec / 1e12,
             'value_note': 'value = algorithmic flops / MEDIAN step time (SURVEY.md 8d); ms_per_step = whole timed region / steps '
-                          '(the mean), value_mean the figure that goes with it',
+                          '(the mean), value_mean the figure that goes with it (rounds 1-3 quoted the mean: compare those with '
+                          'value_mean / ms_per_step).  Inputs X, y, Xs are resident in HBM when the timed region starts; SURVEY.md '
+                          '8d\'s logp metric starts at their host-to-device copy (1.3 MB here): api_ms is that host-to-host figure '
+                          'through the public API',
             'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32' if args.f32 else 'f64', 'data': 'synthetic',
             'config': {'workload': args.kernel.upper() + '-kernel GaussianProcess, N=%d d=%d, M=%d test points: Gram + blocked '
@@ -614,6 +748,13 @@ def main():
                            'note': 'bytes = sent + received by the rank; device_ms = HIP-event time of the collective calls on '
                                    'the stream each ran on (native driver); host_wait = host time inside work.wait() / blocking '
                                    'all-reduces (python driver: RCCL waits are stream dependencies, ~0 unless the host is the bottleneck)'}
+        if len(passes) > 1 or chosen != 'default':
+            out['schedule'] = chosen
+            out['schedules'] = {k_: _pass_summary(args, N, M, S, v_, pin) for k_, v_ in passes.items()}
+            out['schedule_note'] = ('serial: the diagonal-factor broadcast waits for the previous panel all-gather on every rank '
+                                    '(G3_DIST_SERIAL_COLL=1: the two communicators are never in flight together); overlapped: the '
+                                    'default, broadcast of block j+1 beside the all-gather of panel j.  Both passes ran in the same '
+                                    'processes, serial first; the headline is the faster pass that reproduced the oracle pin')
         if S > 0:
             dr = result['draws']
             out['metric'] += ' (+ posterior covariance, its Cholesky and %d draws)' % S

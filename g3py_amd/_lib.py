@@ -57,6 +57,12 @@ class DistCallbacks(C.Structure):
     _fields_ = [('user', C.c_void_p), ('bcast', DIST_BCAST_CB), ('allgather', DIST_ALLGATHER_CB),
                 ('allreduce', DIST_ALLREDUCE_CB)]
 
+class DistHostCallbacks(C.Structure):
+    """g3_dist_host_callbacks: the collectives as host callbacks on HOST staging buffers, served by the library's two
+    worker threads (asynchronous test transport)"""
+    _fields_ = [('user', C.c_void_p), ('bcast', DIST_BCAST_CB), ('allgather', DIST_ALLGATHER_CB),
+                ('allreduce', DIST_ALLREDUCE_CB)]
+
 _SIGS = {
     'g3_version': ([], C.c_int),
     'g3_ctx_create': ([C.c_int, C.POINTER(_P)], C.c_int),
@@ -122,6 +128,7 @@ _SIGS = {
     'g3_dist_unique_id': ([_P], C.c_int),
     'g3_dist_create': ([_P, _P, _P, C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
     'g3_dist_create_callbacks': ([_P, C.POINTER(DistCallbacks), C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
+    'g3_dist_create_callbacks_async': ([_P, C.POINTER(DistHostCallbacks), C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
     'g3_dist_destroy': ([_P], C.c_int),
     'g3_dist_last_error': ([_P], C.c_char_p),
     'g3_dist_plan': ([_P, _I64, C.c_int, _I64, _I64, C.c_int], C.c_int),

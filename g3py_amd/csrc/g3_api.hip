@@ -7,7 +7,22 @@
 // ----------------------------------------------------------------------------- context
 extern "C" int g3_version(void) { return 100; }
 
-extern "C" int g3_ctx_create(int device, g3_ctx** out) {
+static int ctx_create_impl(int device, hipStream_t on_stream, g3_ctx** out);
+extern "C" int g3_ctx_create(int device, g3_ctx** out) { return ctx_create_impl(device, nullptr, out); }
+// A context that works on the caller's stream and creates NO stream of its own (the side stream of a two-stream sweep is
+// created the first time one is needed, g3i_ensure_side_stream).  The multi-GPU driver's look-ahead and bulk contexts are
+// made this way: HIP maps streams onto a few hardware queues per priority, and every idle stream a process holds shifts
+// which of the streams that matter end up sharing one.
+int g3i_ctx_create_on(int device, hipStream_t stream, g3_ctx** out) { return stream ? ctx_create_impl(device, stream, out) : -3; }
+int g3i_ensure_side_stream(g3_ctx* ctx) {
+  if (ctx->side_stream) return G3_OK;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  G3_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
+  return G3_OK;
+}
+
+static int ctx_create_impl(int device, hipStream_t on_stream, g3_ctx** out) {
   if (!out) return -2;
   *out = nullptr;
   int ndev = 0;
@@ -24,8 +39,10 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
   if (e == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority, hi = greatest
   // the chain runs on the context's stream at the greatest priority, the bulk updates on the side stream at the least:
   // measured, a bulk stream WITHOUT the low priority costs 2 % (N = 8192) to 10 % (N = 32768) of the step
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
+  if (!on_stream) {
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo);
+  }
   ctx->tune = g3h_tune_from_env();
   {
     const char* lg = getenv("G3_GEMM_LOG");
@@ -51,7 +68,8 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) {
     if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     return G3_ERR_HIP;
   }
-  ctx->stream = ctx->own_stream;
+  ctx->stream = on_stream ? on_stream : ctx->own_stream;
+  ctx->adopted = on_stream != nullptr;
   *out = ctx;
   if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
   return G3_OK;

@@ -4,7 +4,7 @@
 // g3py/processes/stochastic.py:773-783); the algebra is the Gram + Cholesky + triangular solves of
 // g3py/libs/tensors.py:197-222, g3py/processes/gaussian.py:208-224 and elliptical.py:81-97.
 //
-// Layout: ROW-block-cyclic, boustrophedon dealing.  A rank stacks its nb-row blocks in
+// Layout: ROW-block-cyclic, blocks dealt from the top in load-balanced rounds (g3h_deal).  A rank stacks its nb-row blocks in
 // one full-width local matrix, followed by its share of the right-hand-side rows [delta^T; K(Xs, X)]
 // (128-row chunks), which ride through the factorisation as on one GPU.  Only the nb x nb diagonal factor
 // travels on the critical path (broadcast, on its OWN communicator and on the look-ahead stream); a panel is
@@ -30,6 +30,10 @@
 #include <rccl/rccl.h>
 #include <stdlib.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -162,6 +166,208 @@ struct CallbackTransport : Transport {
   const char* name() const override { return "callbacks"; }
 };
 
+// ---- asynchronous host-callback transport: the collectives as jobs of two worker threads (gather / all-reduce, and
+// broadcast: the product's two communicators), stream-ordered like RCCL calls.
+//   issue (host thread):  record E on the stream -> queue the job -> launch a one-wave kernel on the stream that waits for
+//                         the worker's ticket (a word in pinned host memory) -> return: the host runs ahead
+//   worker:               wait for E -> device -> pinned staging (its own copy stream) -> callback -> staging -> device
+//                         -> publish the ticket: the stream goes on
+// The wait kernel has a wall-clock limit (G3_DIST_ASYNC_TIMEOUT_S, default 120 s): a stream never hangs on a dead peer, the
+// limit sets a device error word that every later transport call reports.  The workers' copy streams have NORMAL priority:
+// HIP keeps separate hardware-queue pools per priority, so they never sit behind a waiting high- or low-priority stream of
+// the driver.
+__global__ void host_ticket_wait_kernel(const unsigned* ticket, unsigned want, unsigned long long limit, unsigned* err) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  unsigned spins = 0;
+  while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+    __builtin_amdgcn_s_sleep(8);
+    if ((++spins & 63u) == 0 && wall_clock64() - t0 > limit) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
+struct AsyncCallbackTransport : Transport {
+  g3_dist_host_callbacks cb;
+  int device = 0, rank = 0, world = 1;
+  struct Job {
+    int kind = -1;                 // G3_COLL_*; -1: quit
+    hipEvent_t ev = nullptr;
+    void* buf = nullptr;           // bcast buffer / all-gather receive buffer (device)
+    const void* send = nullptr;    // all-gather: this rank's part (device)
+    size_t bytes = 0;
+    int root = 0;
+    double* vals = nullptr;        // all-reduce (host, the caller waits)
+    int n = 0, op = 0;
+    unsigned seq = 0;
+  };
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::deque<Job> q;
+    unsigned issued = 0, done = 0;       // tickets (done is mirrored in *ticket for the device)
+    unsigned* ticket = nullptr;          // pinned, mapped
+    unsigned* ticket_dev = nullptr;
+    hipStream_t cs = nullptr;            // copy stream
+    char* stage = nullptr;               // pinned staging
+    size_t stage_bytes = 0;
+    int failed = 0;
+    char msg[200] = {0};
+  } w[2];                                // 0: all-gather + all-reduce, 1: broadcast
+  unsigned* err_host = nullptr;          // pinned: a wait kernel ran into its limit
+  unsigned* err_dev = nullptr;
+  unsigned long long limit = 12000000000ull;
+  std::vector<hipEvent_t> evpool;
+  std::mutex evmu;
+
+  int start() {
+    if (hipHostMalloc((void**)&err_host, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return G3_ERR_HIP;
+    *err_host = 0;
+    if (hipHostGetDevicePointer((void**)&err_dev, err_host, 0) != hipSuccess) return G3_ERR_HIP;
+    const int lim = g3h_env_int("G3_DIST_ASYNC_TIMEOUT_S", 120);
+    limit = (unsigned long long)(lim > 0 ? lim : 120) * 100000000ull;      // wall_clock64 ticks at 100 MHz
+    for (int i = 0; i < 2; ++i) {
+      if (hipHostMalloc((void**)&w[i].ticket, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return G3_ERR_HIP;
+      *w[i].ticket = 0;
+      if (hipHostGetDevicePointer((void**)&w[i].ticket_dev, w[i].ticket, 0) != hipSuccess) return G3_ERR_HIP;
+      if (hipStreamCreateWithFlags(&w[i].cs, hipStreamNonBlocking) != hipSuccess) return G3_ERR_HIP;
+      w[i].th = std::thread([this, i]() { run(i); });
+    }
+    return G3_OK;
+  }
+  ~AsyncCallbackTransport() override {
+    for (int i = 0; i < 2; ++i) {
+      if (w[i].th.joinable()) {
+        { std::lock_guard<std::mutex> lk(w[i].mu); w[i].q.push_back(Job()); }
+        w[i].cv.notify_all();
+        w[i].th.join();
+      }
+      if (w[i].cs) { (void)hipStreamSynchronize(w[i].cs); (void)hipStreamDestroy(w[i].cs); }
+      if (w[i].stage) (void)hipHostFree(w[i].stage);
+      if (w[i].ticket) (void)hipHostFree(w[i].ticket);
+    }
+    for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
+    if (err_host) (void)hipHostFree(err_host);
+  }
+  hipEvent_t take_event() {
+    std::lock_guard<std::mutex> lk(evmu);
+    if (!evpool.empty()) { hipEvent_t e = evpool.back(); evpool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+  }
+  void give_event(hipEvent_t e) { std::lock_guard<std::mutex> lk(evmu); evpool.push_back(e); }
+  bool ensure_stage(Worker& W, size_t bytes) {
+    if (W.stage_bytes >= bytes) return true;
+    if (W.stage) (void)hipHostFree(W.stage);
+    W.stage = nullptr; W.stage_bytes = 0;
+    if (hipHostMalloc((void**)&W.stage, bytes, hipHostMallocDefault) != hipSuccess) return false;
+    W.stage_bytes = bytes;
+    return true;
+  }
+  void fail(Worker& W, const char* what) {
+    W.failed = 1;
+    snprintf(W.msg, sizeof(W.msg), "%s", what);
+  }
+  void run(int i) {
+    Worker& W = w[i];
+    (void)hipSetDevice(device);
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(W.mu);
+        W.cv.wait(lk, [&]() { return !W.q.empty(); });
+        j = W.q.front();
+        W.q.pop_front();
+      }
+      if (j.kind < 0) return;
+      bool ok = !W.failed;
+      if (j.ev) {
+        if (hipEventSynchronize(j.ev) != hipSuccess) { ok = false; fail(W, "waiting for the stream failed"); }
+        give_event(j.ev);
+      }
+      if (ok && j.kind == G3_COLL_BCAST) {
+        ok = ensure_stage(W, j.bytes);
+        if (ok && rank == j.root) ok = hipMemcpyAsync(W.stage, j.buf, j.bytes, hipMemcpyDeviceToHost, W.cs) == hipSuccess && hipStreamSynchronize(W.cs) == hipSuccess;
+        if (ok) ok = cb.bcast(cb.user, W.stage, j.bytes, j.root) == 0;
+        if (ok && rank != j.root) ok = hipMemcpyAsync(j.buf, W.stage, j.bytes, hipMemcpyHostToDevice, W.cs) == hipSuccess && hipStreamSynchronize(W.cs) == hipSuccess;
+        if (!ok && !W.failed) fail(W, "broadcast failed (staging copy or callback)");
+      } else if (ok && j.kind == G3_COLL_ALLGATHER) {
+        ok = ensure_stage(W, j.bytes * (size_t)world);
+        char* mine = W.stage + (size_t)rank * j.bytes;
+        if (ok) ok = hipMemcpyAsync(mine, j.send, j.bytes, hipMemcpyDeviceToHost, W.cs) == hipSuccess && hipStreamSynchronize(W.cs) == hipSuccess;
+        if (ok) ok = cb.allgather(cb.user, mine, W.stage, j.bytes) == 0;
+        // everything but this rank's own part goes back (the in-place gather leaves that where it is; an out-of-place
+        // one -- send outside the receive buffer -- gets the local copy as well)
+        const bool inplace = (const char*)j.send == (const char*)j.buf + (size_t)rank * j.bytes;
+        for (int q = 0; q < world && ok; ++q)
+          if (q != rank || !inplace)
+            ok = hipMemcpyAsync((char*)j.buf + (size_t)q * j.bytes, W.stage + (size_t)q * j.bytes, j.bytes, hipMemcpyHostToDevice, W.cs) == hipSuccess;
+        if (ok) ok = hipStreamSynchronize(W.cs) == hipSuccess;
+        if (!ok && !W.failed) fail(W, "all-gather failed (staging copy or callback)");
+      } else if (ok && j.kind == G3_COLL_ALLREDUCE) {
+        ok = cb.allreduce(cb.user, j.vals, j.n, j.op) == 0;
+        if (!ok && !W.failed) fail(W, "all-reduce callback failed");
+      }
+      // the ticket is published even after a failure: a stream must never be left waiting (the failure is reported by
+      // the next transport call and ends the evaluation with an error)
+      {
+        std::lock_guard<std::mutex> lk(W.mu);
+        W.done = j.seq;
+        __atomic_store_n(W.ticket, j.seq, __ATOMIC_RELEASE);
+      }
+      W.cv_done.notify_all();
+    }
+  }
+  int check() {
+    for (int i = 0; i < 2; ++i)
+      if (w[i].failed) { snprintf(err, sizeof(err), "%s", w[i].msg); return G3_ERR_HIP; }
+    if (*err_host) { snprintf(err, sizeof(err), "a stream waited longer than the limit for a collective (peer gone?)"); return G3_ERR_HIP; }
+    return G3_OK;
+  }
+  int issue(int wi, Job j, hipStream_t s) {
+    int rc = check();
+    if (rc) return rc;
+    Worker& W = w[wi];
+    j.ev = take_event();
+    if (!j.ev || hipEventRecord(j.ev, s) != hipSuccess) { snprintf(err, sizeof(err), "event record failed"); return G3_ERR_HIP; }
+    {
+      std::lock_guard<std::mutex> lk(W.mu);
+      j.seq = ++W.issued;
+      W.q.push_back(j);
+    }
+    W.cv.notify_all();
+    hipLaunchKernelGGL(host_ticket_wait_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)W.ticket_dev, j.seq, limit, err_dev);
+    if (hipGetLastError() != hipSuccess) { snprintf(err, sizeof(err), "wait-kernel launch failed"); return G3_ERR_HIP; }
+    return G3_OK;
+  }
+  int bcast(void* buf, size_t bytes, int root, hipStream_t s) override {
+    Job j; j.kind = G3_COLL_BCAST; j.buf = buf; j.bytes = bytes; j.root = root;
+    return issue(1, j, s);
+  }
+  int allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+    Job j; j.kind = G3_COLL_ALLGATHER; j.send = send; j.buf = recv; j.bytes = bytes;
+    return issue(0, j, s);
+  }
+  int allreduce(double* host, int n, int op, hipStream_t s) override {
+    // behind everything queued on s and behind every gather issued so far; the caller needs the values: wait here
+    Job j; j.kind = G3_COLL_ALLREDUCE; j.vals = host; j.n = n; j.op = op;
+    int rc = issue(0, j, s);
+    if (rc) return rc;
+    Worker& W = w[0];
+    unsigned want;
+    { std::lock_guard<std::mutex> lk(W.mu); want = W.issued; }
+    { std::unique_lock<std::mutex> lk(W.mu); W.cv_done.wait(lk, [&]() { return W.done >= want; }); }
+    if (hipStreamSynchronize(s) != hipSuccess) return G3_ERR_HIP;
+    return check();
+  }
+  const char* name() const override { return "callbacks-async"; }
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------- the driver object
@@ -178,6 +384,7 @@ struct g3_dist {
   int d = 0, nblk = 0, nchunk = 0;
   g3_dtype dt = G3_F64;
   size_t es = 8;
+  std::vector<int> owner;       // owner[I]: the rank that holds row block I (g3h_deal, the same table on every rank)
   std::vector<int> my_blocks, my_chunks;
   std::vector<int64_t> loff;    // local row offset of an owned block, -1 otherwise
   int64_t rows_mat = 0, rows_rhs = 0, cmax = 1;
@@ -275,11 +482,11 @@ static int mark_failed(g3_dist* D, int rc) {
   return rc;
 }
 
-static int owner_of(const g3_dist* D, int I) { return g3h_owner_of(D->world, I); }   // boustrophedon dealing (g3_host.h)
+static int owner_of(const g3_dist* D, int I) { return D->owner[I]; }   // g3h_deal (g3_host.h)
 
 // blocks per rank in the padded gather of step k, and the position of global block k+1+s in the rank-major
 // gather buffer
-static int perm_of(const g3_dist* D, int k, std::vector<int32_t>* idx) { return g3h_gather_table(D->world, k + 1, D->nblk - 1, idx); }
+static int perm_of(const g3_dist* D, int k, std::vector<int32_t>* idx) { return g3h_gather_table(D->owner, D->world, k + 1, D->nblk - 1, idx); }
 
 static inline char* Aat(const g3_dist* D, int64_t row, int64_t col) { return D->A + ((size_t)row * D->Np + col) * D->es; }
 static inline char* Lof(const g3_dist* D, int k) { return D->dbuf[k % 2]; }
@@ -353,7 +560,7 @@ int ReplayTransport::allgather(const void* send, void* recv, size_t bytes, hipSt
   const int k = index;
   const size_t es = D->es, blk = (size_t)D->nb * D->nb * es;
   std::vector<int32_t> idx;
-  const int cnt = g3h_gather_table(D->world, k + 1, D->nblk - 1, &idx);
+  const int cnt = g3h_gather_table(D->owner, D->world, k + 1, D->nblk - 1, &idx);
   if ((size_t)cnt * blk != bytes) return fail("replay: panel all-gather of an unexpected size");
   // this rank's own slots, as the collective would place them
   if ((const char*)send != (char*)recv + (size_t)D->rank * bytes &&
@@ -366,7 +573,7 @@ int ReplayTransport::allgather(const void* send, void* recv, size_t bytes, hipSt
     tab.nblk = nbk - b0 < G3_RASTER_MAX + 96 ? nbk - b0 : G3_RASTER_MAX + 96;
     for (int b = 0; b < tab.nblk; ++b) {
       const int I = k + 1 + b0 + b;
-      tab.slot[b] = g3h_owner_of(D->world, I) == D->rank ? -1 : idx[I - k - 1];
+      tab.slot[b] = D->owner[I] == D->rank ? -1 : idx[I - k - 1];
     }
     const char* src0 = ref->A + ((size_t)(k + 1 + b0) * D->nb * ref->Np + (size_t)k * D->nb) * es;
     hipLaunchKernelGGL(replay_panel_kernel, dim3((unsigned)tab.nblk, 32), dim3(256), 0, s, (char*)recv, src0, (size_t)ref->Np * es,
@@ -449,32 +656,30 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
   D->ctx = ctx;
   D->rank = rank;
   D->world = world;
-  int rc = g3_ctx_create(ctx->device, &D->ctx_look);
-  if (!rc) rc = g3_ctx_create(ctx->device, &D->ctx_bulk);
-  if (rc) {
-    if (D->ctx_look) g3_ctx_destroy(D->ctx_look);
-    delete D;
-    return rc;
-  }
   g3_dev_guard _dg(ctx);
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority, hi = greatest
+  // The driver's own two streams, and NOTHING else: the look-ahead and bulk contexts work on them and create no streams of
+  // their own.  HIP maps streams onto a few hardware queues per priority; with the four idle streams two ordinary contexts
+  // would bring, whether the chain stream and the look-ahead stream share a queue (and then serialise) depended on what
+  // else the process had created before (the same replay measured 45 or 37 ms at P = 8).
   hipError_t e = hipStreamCreateWithPriority(&D->s_look, hipStreamNonBlocking, hi);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&D->s_bulk, hipStreamNonBlocking, lo);
   if (e == hipSuccess) e = hipMalloc((void**)&D->info_dev, sizeof(int));
-  if (e != hipSuccess) {
+  int rc = e == hipSuccess ? G3_OK : G3_ERR_HIP;
+  if (!rc) rc = g3i_ctx_create_on(ctx->device, D->s_look, &D->ctx_look);
+  if (!rc) rc = g3i_ctx_create_on(ctx->device, D->s_bulk, &D->ctx_bulk);
+  if (rc) {
+    if (D->ctx_look) g3_ctx_destroy(D->ctx_look);
+    if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
     if (D->s_look) (void)hipStreamDestroy(D->s_look);
     if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
     if (D->info_dev) (void)hipFree(D->info_dev);
-    g3_ctx_destroy(D->ctx_look);
-    g3_ctx_destroy(D->ctx_bulk);
     delete D;
-    return G3_ERR_HIP;
+    return rc;
   }
   D->serial_coll = g3h_env_int("G3_DIST_SERIAL_COLL", 0) != 0;
   D->want_fullinv = g3h_env_int("G3_DIST_FULLINV", 1) != 0;
-  g3_ctx_set_stream(D->ctx_look, D->s_look);
-  g3_ctx_set_stream(D->ctx_bulk, D->s_bulk);
   D->ctx_bulk->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
   *out = D;
   return G3_OK;
@@ -531,6 +736,29 @@ extern "C" int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb
   if (!t) { g3_dist_destroy(D); return G3_ERR_NOMEM; }
   t->cb = *cb;
   D->tr = t;
+  *out = D;
+  return G3_OK;
+}
+
+extern "C" int g3_dist_create_callbacks_async(g3_ctx* ctx, const g3_dist_host_callbacks* cb, int rank, int world, g3_dist** out) {
+  if (!ctx) return -1;
+  if (!cb || !cb->bcast || !cb->allgather || !cb->allreduce) return -2;
+  if (world < 1 || rank < 0 || rank >= world) return -3;
+  if (!out) return -5;
+  *out = nullptr;
+  g3_dist* D = nullptr;
+  int rc = dist_common(ctx, rank, world, &D);
+  if (rc) return rc;
+  g3_dev_guard _dg(ctx);
+  AsyncCallbackTransport* t = new (std::nothrow) AsyncCallbackTransport();
+  if (!t) { g3_dist_destroy(D); return G3_ERR_NOMEM; }
+  t->cb = *cb;
+  t->device = ctx->device;
+  t->rank = rank;
+  t->world = world;
+  D->tr = t;
+  rc = t->start();
+  if (rc) { g3_dist_destroy(D); return rc; }
   *out = D;
   return G3_OK;
 }
@@ -628,6 +856,7 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   D->Mp = g3_roundup(M, 128);
   D->nchunk = 1 + (int)(D->Mp / 128);
   D->my_blocks.clear(); D->my_chunks.clear();
+  g3h_deal(D->world, D->nblk, &D->owner);
   D->loff.assign(D->nblk, -1);
   for (int I = 0; I < D->nblk; ++I)
     if (owner_of(D, I) == D->rank) { D->loff[I] = (int64_t)D->my_blocks.size() * nb; D->my_blocks.push_back(I); }
@@ -1393,7 +1622,7 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(const T* __restrict__ A, 
 }
 
 static int perm_upto(const g3_dist* D, int k, std::vector<int32_t>* idx) {   // blocks 0 .. k in the rank-major gather
-  const int c = g3h_gather_table(D->world, 0, k, idx);
+  const int c = g3h_gather_table(D->owner, D->world, 0, k, idx);
   return c < 1 ? 1 : c;
 }
 

@@ -66,8 +66,9 @@ int g3i_potri(g3_ctx* ctx, const void* L, int64_t n, int64_t ldl, const void* in
   if (rc) return rc;
   hipEvent_t* evP = ctx->la_ev;
   hipEvent_t* evB = ctx->la_ev + nblk;
-  hipStream_t sA = ctx->stream, sB = ctx->side_stream;
   const bool two = nblk >= 3;   // small problems: everything on the caller's stream
+  if (two) { const int rs = g3i_ensure_side_stream(ctx); if (rs) return rs; }
+  hipStream_t sA = ctx->stream, sB = ctx->side_stream;
   if (!two) sB = sA;
 
   if (g3_nbatch(ctx) > 1 && ((n * es) % 16 == 0) && ((ldy * es) % 16 == 0) && ((ldc * es) % 16 == 0) &&

@@ -143,6 +143,10 @@ static inline bool g3_on_bulk_stream(const g3_ctx* ctx) {
 static inline size_t g3_esize(g3_dtype dt) { return dt == G3_F64 ? 8 : 4; }
 static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
+// a context on the caller's stream that creates no stream of its own; the low-priority side stream on first need
+int g3i_ctx_create_on(int device, hipStream_t stream, g3_ctx** out);
+int g3i_ensure_side_stream(g3_ctx* ctx);
+
 // internal launchers (stream-ordered, no host sync)
 int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,
                 int64_t ldb, int64_t m, int64_t n, int64_t k, double alpha, double beta,

@@ -995,6 +995,7 @@ static int potrf_lookahead(g3_ctx* ctx, T* A, int64_t n, int64_t ld, T* W, int64
   hipEvent_t* evB1 = ctx->la_ev + ngrp;        // P1(s) done (stream B)
   hipEvent_t* evB2a = ctx->la_ev + 2 * ngrp;   // P2a(s) done (stream B)
   hipEvent_t evJoin = ctx->la_ev[4 * ngrp];
+  { const int rs = g3i_ensure_side_stream(ctx); if (rs) return rs; }
   hipStream_t sA = ctx->stream, sB = ctx->side_stream;
   auto r = [&](int k) { return k < nblk ? bnd[k] : n; };                 // first column of panel k
   auto c = [&](int s) { return s < ngrp ? bnd[gb[s]] : n; };             // first column of super-panel s
@@ -1147,6 +1148,7 @@ static int trsm_lookahead(g3_ctx* ctx, const T* L, int64_t n, int64_t ldl, T* B,
   hipEvent_t* evX = ctx->la_ev;            // block j of X solved (stream A)
   hipEvent_t* evU = ctx->la_ev + nblk;     // everything right of block j+1 carries block j (stream B)
   hipEvent_t evJoin = ctx->la_ev[2 * nblk];
+  { const int rs = g3i_ensure_side_stream(ctx); if (rs) return rs; }
   hipStream_t sA = ctx->stream, sB = ctx->side_stream;
   auto c = [&](int j) { return j < nblk ? (int64_t)j * NBK : n; };
   G3_HIP(hipEventRecord(evJoin, sA));

@@ -44,6 +44,25 @@ import sys as _sys
 import numpy as np
 
 
+def deal_blocks(P, nblk):
+    """owner[I] of row block I -- the line-by-line mirror of g3_host.h::g3h_deal: blocks are dealt from the top in rounds of
+    P, every rank one block per round, the least loaded rank so far the heaviest block of the round (block I weighs
+    I^2 + 6 I + 1: its trailing updates, column updates and panel solves over the sweep); ties go to the lowest rank"""
+    owner = [0] * max(nblk, 0)
+    load = [0] * P
+    top = nblk - 1
+    while top >= 0:
+        order = sorted(range(P), key=lambda q: (load[q], q))
+        for i in range(P):
+            I = top - i
+            if I < 0:
+                break
+            owner[I] = order[i]
+            load[order[i]] += I * I + 6 * I + 1
+        top -= P
+    return owner
+
+
 def block_ranges(Np, nb):
     r = list(range(0, Np, nb))
     return [(a, min(nb, Np - a)) for a in r]
@@ -332,6 +351,7 @@ class DistributedGP:
         self.ops = ops if ops is not None else HipPanelOps(dev, torch, torch_device, dtype)
         self.torch = torch
         o = self.ops
+        self._owner = deal_blocks(world, self.nblk)
         self.my_blocks = [I for I in range(self.nblk) if self.owner(I) == rank]
         self.my_chunks = [c for c in range(self.nchunk) if c % world == rank]
         self.rows_mat = len(self.my_blocks) * nb
@@ -375,12 +395,9 @@ class DistributedGP:
         self.comm = {k: {'calls': 0, 'bytes': 0, 'wait_s': 0.0} for k in ('bcast', 'allgather', 'allreduce')}
 
     def owner(self, I):
-        """row blocks are dealt in boustrophedon order (0..P-1, P-1..0, ...): the trailing-update work
-        of block I grows like I^2, and the snake keeps the ranks' shares within a few per cent of
-        each other where plain round-robin leaves the last rank with up to 1.4x the mean"""
-        P = self.world
-        r = I % (2 * P)
-        return r if r < P else 2 * P - 1 - r
+        """the rank that holds row block I (deal_blocks: from the top, in load-balanced rounds -- the ranks' total work
+        is within 2 % of the mean at P = 8 with 32 blocks; round-robin leaves the last rank at 1.4x)"""
+        return self._owner[I]
 
     def _perm(self, k):
         """(blocks per rank in the padded gather of step k, block table): entry s of the table (global
@@ -684,8 +701,8 @@ class DistributedGP:
         a = o.zeros(1, Np)
         if 0 in self.my_chunks:
             a.copy_(self.A[self.rows_mat:self.rows_mat + 1])
-        self._wait(self._bcast(a, self.owner(0), async_op=False))
-        if self.rank == self.owner(0):
+        self._wait(self._bcast(a, 0, async_op=False))            # chunk 0 lives on rank 0 (chunks are dealt c % world)
+        if self.rank == 0:
             acc[1] = float((a[0].double() * a[0].double()).sum().item())
         for t, c in enumerate(self.my_chunks):
             if c == 0:
@@ -774,7 +791,11 @@ class NativeDistributedGP:
     DistributedGP, which stays as the readable reference of the schedule (and runs on CPU with a test double).
 
     transport='callbacks' (tests only): the collectives are served by `dist` through host staging, so several ranks
-    can share ONE GPU -- RCCL refuses that -- and the library's schedule is checked for world > 1 on a one-GPU box."""
+    can share ONE GPU -- RCCL refuses that -- and the library's schedule is checked for world > 1 on a one-GPU box.
+    Every collective there is a blocking host call behind a stream synchronisation (a debugging aid);
+    transport='callbacks_async' is the faithful one: the library's two worker threads serve the panel all-gathers and the
+    diagonal-factor broadcasts from two gloo groups while the host thread runs ahead and the three streams keep working
+    -- the stream semantics of the RCCL path (g3_dist_create_callbacks_async, include/g3hip.h)."""
 
     def __init__(self, dev, dist, rank, world, N, d, M, nb=512, dtype=np.float64, transport='rccl', reference=None, keep=False):
         import ctypes as C
@@ -830,6 +851,11 @@ class NativeDistributedGP:
             rc = lib.g3_dist_create_callbacks(dev.ctx, C.byref(self._cb), rank, world, C.byref(self.h))
             if rc:
                 raise _lib.G3Error('g3_dist_create_callbacks failed (%d)' % rc)
+        elif transport == 'callbacks_async':
+            self._cb = self._make_host_callbacks()
+            rc = lib.g3_dist_create_callbacks_async(dev.ctx, C.byref(self._cb), rank, world, C.byref(self.h))
+            if rc:
+                raise _lib.G3Error('g3_dist_create_callbacks_async failed (%d)' % rc)
         elif transport == 'replay':
             # measurement: this object plays rank `rank` of a `world`-rank evaluation alone on the GPU; `reference` is a
             # world-1 NativeDistributedGP created with keep=True that has evaluated the same problem (g3hip.h)
@@ -916,6 +942,67 @@ class NativeDistributedGP:
         self._cb_keep = (self._lib.DIST_BCAST_CB(bcast), self._lib.DIST_ALLGATHER_CB(allgather),
                          self._lib.DIST_ALLREDUCE_CB(allreduce))
         return self._lib.DistCallbacks(None, *self._cb_keep)
+
+    def _make_host_callbacks(self):
+        """collectives for the asynchronous test transport: the library hands HOST staging buffers to these callbacks from
+        its two worker threads -- `bcast` from the broadcast worker, `allgather` / `allreduce` from the gather worker -- so
+        each kind gets a gloo group of its own (two communicators, as in the RCCL path) and works in place on the buffer"""
+        import torch
+        C, dist, world = self._C, self.dist, self.world
+        self.coll_trace = None
+        self._g_gather = self._g_bcast = None
+        if world > 1:
+            ranks = list(range(world))
+            self._g_gather = dist.new_group(ranks=ranks, backend='gloo')
+            self._g_bcast = dist.new_group(ranks=ranks, backend='gloo')
+
+        def view(ptr, n):
+            return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * n).from_address(ptr)))
+
+        def bcast(user, buf, nbytes, root):
+            try:
+                if self.coll_trace is not None:
+                    self.coll_trace.append(('bcast', int(nbytes), int(root)))
+                if world > 1:
+                    dist.broadcast(view(buf, nbytes), src=root, group=self._g_bcast)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allgather(user, sendp, recvp, nbytes):
+            try:
+                if self.coll_trace is not None:
+                    self.coll_trace.append(('allgather', int(nbytes), None))
+                if world > 1:
+                    out = view(recvp, nbytes * world)
+                    mine = view(sendp, nbytes).clone()          # (the send part lies inside the receive buffer)
+                    dist.all_gather(list(out.view(world, nbytes).unbind(0)), mine, group=self._g_gather)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allreduce(user, vals, n, op):
+            try:
+                a = np.ctypeslib.as_array(vals, shape=(n,))
+                if self.coll_trace is not None:
+                    self.coll_trace.append(('allreduce', int(n) * 8, ('sum', 'min', 'max')[op]))
+                self.last_allreduce_in = a.copy()
+                if world > 1:
+                    t = torch.from_numpy(a.copy())
+                    dist.all_reduce(t, op=[dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX][op], group=self._g_gather)
+                    a[:] = t.numpy()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb_keep = (self._lib.DIST_BCAST_CB(bcast), self._lib.DIST_ALLGATHER_CB(allgather),
+                         self._lib.DIST_ALLREDUCE_CB(allreduce))
+        return self._lib.DistHostCallbacks(None, *self._cb_keep)
 
     @staticmethod
     def _ptr_ld(a):

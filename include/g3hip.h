@@ -438,6 +438,24 @@ typedef struct {
   int (*allreduce)(void* user, double* vals_host, int n, int op /* 0 sum, 1 min, 2 max */);
 } g3_dist_callbacks;
 int g3_dist_create_callbacks(g3_ctx* ctx, const g3_dist_callbacks* cb, int rank, int world, g3_dist** out);
+/* ASYNCHRONOUS test transport (round 5): the same three collectives as host callbacks, but on HOST staging buffers and
+ * served by two worker threads the library owns -- one for the panel all-gathers and scalar all-reduces, one for the
+ * diagonal-factor broadcasts, i.e. the product's two communicators.  A collective is stream-ordered exactly like an RCCL
+ * call: the library records an event on the stream, hands the job to the worker and makes the STREAM (not the host) wait
+ * for it; the worker waits for the event, stages device -> pinned host, calls the callback, stages back and releases the
+ * stream.  The host thread runs ahead over the whole sweep, collectives of both kinds are in flight together beside the
+ * three streams' kernels, and a cross-rank ordering or buffer-reuse fault shows -- which the blocking transport above
+ * (a hipStreamSynchronize before every collective) serialises away.  `bcast` is called from the broadcast worker,
+ * `allgather` and `allreduce` from the gather worker, each in the order the library issues them (the same on every rank):
+ * serve the two kinds from two independent communicators (e.g. two gloo process groups).  allgather: host_recv holds
+ * world x bytes_per_rank, this rank's part already at host_recv + rank * bytes_per_rank (= host_send). */
+typedef struct {
+  void* user;
+  int (*bcast)(void* user, void* host_buf, size_t bytes, int root);
+  int (*allgather)(void* user, const void* host_send, void* host_recv, size_t bytes_per_rank);
+  int (*allreduce)(void* user, double* vals_host, int n, int op /* 0 sum, 1 min, 2 max */);
+} g3_dist_host_callbacks;
+int g3_dist_create_callbacks_async(g3_ctx* ctx, const g3_dist_host_callbacks* cb, int rank, int world, g3_dist** out);
 /* Replay transport (measurement): ONE rank of a `world`-rank evaluation, alone on one GPU.  `reference` is a world-1
  * driver (either transport) for which g3_dist_set_keep(reference, 1) was called BEFORE g3_dist_plan and which has since
  * evaluated the same problem: its local matrix is the whole factor, its block inverses were kept.  In the replayed

@@ -14,6 +14,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def cb_transport(name='callbacks'):
+    """the native driver's test transport for world > 1 on one GPU: the ASYNCHRONOUS one by default (worker threads,
+    stream-ordered collectives in flight beside the three streams: g3_dist_create_callbacks_async); G3_TEST_TRANSPORT=
+    callbacks selects the blocking one, kept as a debugging aid.  Other names pass through."""
+    if name != 'callbacks':
+        return name
+    return os.environ.get('G3_TEST_TRANSPORT', 'callbacks_async')
+
+
 class NumpyPanelOps:
     def __init__(self, torch):
         self.torch = torch
@@ -254,7 +263,7 @@ def native_worker(rank, world, port, N, d, M, nb, transport, spec_f, noise, out_
         spec_n = orc.with_noise(spec_f, noise) if noise is not None else spec_f
         npdt = np.float32 if dtype == 'f32' else np.float64
         dev = g3.Device(0)
-        dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, dtype=npdt, transport=transport)
+        dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, dtype=npdt, transport=cb_transport(transport))
         Xd, Xsd, yd = dev.upload(X.astype(npdt)), dev.upload(Xs.astype(npdt)), dev.upload(y.astype(npdt))
         Z = np.random.default_rng(5).standard_normal((M, draws)) if draws else None
         lp = dgp.step(spec_n, spec_f, Xd, Xsd, yd, Z=Z)
@@ -312,7 +321,7 @@ def api_worker(rank, world, port, N, d, M, transport, out_path, warped=False):
                 params[k] = np.log(0.1)
             elif k.endswith('_freq_log_'):
                 params[k] = np.log(np.full(d, 0.2))
-        gp.distribute(dist, rank, world, nb=128, transport=transport)
+        gp.distribute(dist, rank, world, nb=128, transport=cb_transport(transport))
         lp = gp.logp(params)
         pr = gp.predict(params, mean=True, var=True, std=True, median=True, quantiles=True)
         lpred = gp.logpredictive(params, vector=np.asarray(pr.median) + 0.01)
@@ -370,7 +379,7 @@ def tp_worker(rank, world, port, N, d, M, out_path):
                 params[k] = np.log(np.full(d, 0.9))
             elif 'Noise' in k:
                 params[k] = np.log(0.1)
-        tp.distribute(dist, rank, world, nb=128, transport='callbacks')
+        tp.distribute(dist, rank, world, nb=128, transport=cb_transport())
         lp, var, g = tp.logp(params), np.asarray(tp.variance(params)), np.asarray(tp.dlogp(params))
         tp.undistribute()
         lp1, var1, g1 = tp.logp(params), np.asarray(tp.variance(params)), np.asarray(tp.dlogp(params))
@@ -401,7 +410,7 @@ def native_multi_worker(rank, world, port, cases, out_path):
             X, y, Xs = synth(N, d, M, seed)
             spec_f = ('MAT32', 1.1, np.linspace(0.7, 1.2, d), None)
             spec_n = orc.with_noise(spec_f, 0.2)
-            dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, dtype=np.float64, transport='callbacks')
+            dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, dtype=np.float64, transport=cb_transport())
             Xd, Xsd, yd = dev.upload(X), dev.upload(Xs), dev.upload(y)
             dgp.set_grad(True)
             lp = dgp.step(spec_n, spec_f, Xd, Xsd, yd)
@@ -457,7 +466,7 @@ def contrib_worker(rank, world, port, N, d, M, nb, out_dir):
         X, y, Xs = synth(N, d, M, 77)
         spec_f = ('SE', 1.0, np.ones(d), None)
         dev = g3.Device(0)
-        dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, transport='callbacks')
+        dgp = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, transport=cb_transport())
         lp = dgp.step(orc.with_noise(spec_f, 0.1), spec_f, dev.upload(X), dev.upload(Xs), dev.upload(y))
         assert dgp.last_allreduce_in.shape == (2 + 2 * M,)
         np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), contrib=dgp.last_allreduce_in, logp=lp, mean=dgp.last['mean'], ss=dgp.last['ss'])
@@ -482,7 +491,7 @@ def twin_worker(rank, world, port, N, d, M, nb, out_dir):
         spec_f = ('SE', 1.0, np.ones(d), None)
         spec_n = orc.with_noise(spec_f, 0.1)
         dev = g3.Device(0)
-        nat = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, transport='callbacks')
+        nat = NativeDistributedGP(dev, dist, rank, world, N, d, M, nb=nb, transport=cb_transport())
         nat.coll_trace = []
         lp_n = nat.step(spec_n, spec_f, dev.upload(X), dev.upload(Xs), dev.upload(y))
         nat_trace = list(nat.coll_trace)

@@ -334,28 +334,35 @@ static void test_ring_and_jitter() {
 }
 
 static void test_dealing() {
-  // the multi-GPU driver's block dealing and gather tables: every block has exactly one owner, the snake keeps the
-  // counts within one, the table is injective, rank-major, ascending inside a rank, and never reaches past P * count
+  // the multi-GPU driver's block dealing and gather tables: every block has exactly one owner, the rounds keep the
+  // counts within one and the ranks' total work (block I weighs I^2 + 6 I + 1) within a few per cent once every rank holds
+  // four blocks, the table is injective, rank-major, ascending inside a rank, and never reaches past P * count
   for (int P = 1; P <= 9; ++P)
     for (int nblk = 1; nblk <= 70; nblk += (nblk < 20 ? 1 : 7)) {
-      std::vector<int> cnt(P, 0);
+      std::vector<int> cnt(P, 0), owner;
+      std::vector<double> load(P, 0.0);
+      g3h_deal(P, nblk, &owner);
+      CHECK((int)owner.size() == nblk);
       for (int I = 0; I < nblk; ++I) {
-        const int q = g3h_owner_of(P, I);
+        const int q = owner[I];
         CHECK(q >= 0 && q < P);
         cnt[q]++;
+        load[q] += (double)I * I + 6.0 * I + 1.0;
       }
       int lo = cnt[0], hi = cnt[0];
-      for (int q = 0; q < P; ++q) { lo = cnt[q] < lo ? cnt[q] : lo; hi = cnt[q] > hi ? cnt[q] : hi; }
+      double lmax = 0, lsum = 0;
+      for (int q = 0; q < P; ++q) { lo = cnt[q] < lo ? cnt[q] : lo; hi = cnt[q] > hi ? cnt[q] : hi; lmax = load[q] > lmax ? load[q] : lmax; lsum += load[q]; }
       CHECK(hi - lo <= 1);
+      if (nblk >= 4 * P) CHECK(lmax <= 1.05 * lsum / P);
       for (int a = -1; a < nblk; a += (nblk < 12 ? 1 : 5))
         for (int b = a; b < nblk; b += (nblk < 12 ? 1 : 3)) {
           const int first = a + 1, last = b;          // perm_of(k): k + 1 .. nblk - 1; perm_upto(k): 0 .. k
           std::vector<int32_t> idx;
-          const int c = g3h_gather_table(P, first, last, &idx);
+          const int c = g3h_gather_table(owner, P, first, last, &idx);
           CHECK((int)idx.size() == (last >= first ? last - first + 1 : 0));
           std::vector<int> seen(P * (c > 0 ? c : 1), 0), prev(P, -1);
           for (int I = first; I <= last; ++I) {
-            const int t = idx[I - first], q = g3h_owner_of(P, I);
+            const int t = idx[I - first], q = owner[I];
             CHECK(c > 0 && t >= q * c && t < (q + 1) * c);      // inside the owner's slots
             CHECK(!seen[t]);                                    // injective
             seen[t] = 1;
@@ -366,7 +373,14 @@ static void test_dealing() {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc == 4 && !strcmp(argv[1], "deal")) {        // "deal P nblk": print the table (the Python twin must deal identically)
+    std::vector<int> owner;
+    g3h_deal(atoi(argv[2]), atoi(argv[3]), &owner);
+    for (int q : owner) printf("%d ", q);
+    printf("\n");
+    return 0;
+  }
   test_dealing();
   test_rasters();
   test_trsm_ops();

@@ -129,3 +129,43 @@ def test_driver_downgrade_is_loud():
     out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, G3_DIST_ALLOW_FALLBACK='1'))
     assert out.returncode == 0, out.stderr[-1500:]
     assert 'driver_fallback' in json.loads([l for l in out.stdout.splitlines() if l.strip().startswith('{')][0])
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_runs_the_serial_pass_first_and_prints_both_in_one_line():
+    """`bench.py --gpus N` (N > 1) runs the native driver twice in the same processes -- serial collective
+    order first, then the overlapped default -- and prints ONE line with both passes; the headline is the faster pass that
+    reproduced the pin.  Rehearsed with two ranks sharing the GPU over gloo (asynchronous callback transport)."""
+    env = dict(os.environ, G3_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--points', '8192', '--queries', '1024', '--steps', '2',
+                          '--warmup', '1', '--cpu-n', '0', '--no-measure-traffic', '--no-api', '--panel', '512'], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    _check_line(j, n_gpus=2)
+    assert set(j['schedules']) == {'serial', 'overlapped'} and j['schedule'] in j['schedules']
+    for k, v in j['schedules'].items():
+        assert v['ms_per_step'] > 0 and v['pin_ok'] and v['logp_rel_err'] <= 1e-8, (k, v)
+        assert len(v['comm']['per_rank']) == 2 and v['comm']['per_rank'][1]['allgather']['calls_per_step'] == 8192 // 512 - 1
+    best = min(j['schedules'], key=lambda k: j['schedules'][k]['ms_per_step_median'])
+    assert j['schedule'] == best and abs(j['ms_per_step_median'] - j['schedules'][best]['ms_per_step_median']) < 1e-9
+    assert 'overlap_timeout' not in j and j['logp_rel_err'] <= 1e-8 and j['comm']['driver'] == 'native'
+
+
+@pytest.mark.gpu
+def test_overlapped_pass_that_never_returns_leaves_the_serial_line_and_a_failure():
+    """... and if the overlapped pass runs into its limit the serial pass's line is printed with `overlap_timeout` and the run
+    exits non-zero.  Forced here with a limit shorter than any pass."""
+    env = dict(os.environ, G3_DIST_BACKEND='gloo', G3_BENCH_OVERLAP_LIMIT_S='0.001')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--points', '8192', '--queries', '1024', '--steps', '2',
+                          '--warmup', '1', '--cpu-n', '0', '--no-measure-traffic', '--no-api', '--panel', '512'], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
+    j = json.loads(lines[0])
+    _check_line(j, n_gpus=2)
+    assert j['overlap_timeout'] is True and j['schedule'] == 'serial' and list(j['schedules']) == ['serial']
+    assert j['logp_rel_err'] <= 1e-8

@@ -522,7 +522,33 @@ def test_python_twin_issues_the_collectives_of_the_native_driver(tmp_path, world
         assert len([e for e in j['native'] if e[0] == 'allgather']) == -(-N // nb) - 1
 
 
-@pytest.mark.parametrize('world,transport', [(3, 'callbacks'), (1, 'rccl')])
+@pytest.mark.parametrize('transport', ['callbacks', 'callbacks_async'])
+@pytest.mark.parametrize('world,N,nb,M', [(2, 1500, 256, 50), (3, 2300, 128, 130), (4, 1100, 128, 130)])
+def test_native_driver_on_both_callback_transports(tmp_path, monkeypatch, transport, world, N, nb, M):
+    """the schedule of g3_dist.hip with collectives genuinely in flight.  'callbacks_async': two worker
+    threads of the library serve the all-gathers and the broadcasts from two gloo groups while the host runs ahead and the
+    three streams keep working (stream-ordered like RCCL calls); 'callbacks': every collective a blocking host call behind a
+    stream synchronisation (the debugging aid).  Same numbers from both, and from the oracle (the rest of this file runs on
+    the asynchronous one by default: dist_helpers.cb_transport)"""
+    import torch.multiprocessing as mp
+    from oracle import g3_oracle as orc
+    monkeypatch.setenv('G3_TEST_TRANSPORT', transport)
+    d = 4
+    spec_f = ('SE', 1.0, np.ones(d), None)
+    out = str(tmp_path / 'res.npz')
+    mp.spawn(native_worker, args=(world, _free_port(), N, d, M, nb, 'callbacks', spec_f, 0.1, out, False, 4), nprocs=world, join=True)
+    r = np.load(out)
+    X, y, Xs = synth(N, d, M, 77)
+    gp = orc.GP(spec_f, 0.1)
+    ref = gp.logp(X, y)
+    assert abs(float(r['logp']) - ref) <= 1e-10 * abs(ref)
+    np.testing.assert_allclose(r['mean'], gp.mean(Xs, X, y), atol=1e-8)
+    np.testing.assert_allclose(r['var'], gp.variance(Xs, X, y), atol=1e-8)
+    Z = np.random.default_rng(5).standard_normal((M, 4))
+    np.testing.assert_allclose(r['draws'], gp.sampler(Xs, X, y, rand=Z), atol=1e-7)
+
+
+@pytest.mark.parametrize('world,transport', [(3, 'callbacks'), (3, 'callbacks_async'), (1, 'rccl')])
 def test_native_driver_serial_collectives_knob(tmp_path, monkeypatch, world, transport):
     """G3_DIST_SERIAL_COLL=1 makes the diagonal-factor broadcast wait for the previous panel's all-gather, so
     the two communicators are never in flight together (the conservative schedule for the first multi-GPU runs): same
@@ -530,6 +556,9 @@ def test_native_driver_serial_collectives_knob(tmp_path, monkeypatch, world, tra
     import torch.multiprocessing as mp
     from oracle import g3_oracle as orc
     monkeypatch.setenv('G3_DIST_SERIAL_COLL', '1')
+    if transport.startswith('callbacks'):
+        monkeypatch.setenv('G3_TEST_TRANSPORT', transport)
+        transport = 'callbacks'
     N, d, M, nb = 1100, 3, 70, 128
     spec_f = ('SE', 1.0, np.ones(d), None)
     out = str(tmp_path / 'res.npz')

@@ -29,3 +29,11 @@ def test_host_logic_under_asan_ubsan(tmp_path):
     env['G3_STAIR_MAX'] = '3'
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    # the block dealing of the multi-GPU drivers: the Python twin (distributed.py::deal_blocks) deals exactly as g3_host.h::g3h_deal
+    import sys
+    sys.path.insert(0, ROOT)
+    from g3py_amd.distributed import deal_blocks
+    for P, nblk in [(1, 5), (2, 7), (3, 13), (4, 32), (5, 32), (8, 32), (8, 33), (8, 64), (7, 50), (8, 1), (3, 2)]:
+        r = subprocess.run([exe, 'deal', str(P), str(nblk)], capture_output=True, text=True, timeout=60, env=env)
+        assert r.returncode == 0
+        assert [int(v) for v in r.stdout.split()] == deal_blocks(P, nblk), (P, nblk)
