@@ -180,6 +180,22 @@ def step_flops(N, M, S=0):
     return f
 
 
+_REAL_STDOUT = [None]     # a private duplicate of the process's stdout, taken before anything redirects fd 1
+
+
+def _emit_line(obj):
+    """the ONE line, on the real stdout even while fd 1 points at stderr (a watchdog may fire inside such a block)"""
+    data = (json.dumps(obj) + '\n').encode()
+    try:
+        sys.stdout.flush()
+    except Exception:
+        pass
+    fd = _REAL_STDOUT[0] if _REAL_STDOUT[0] is not None else 1
+    while data:
+        n = os.write(fd, data)
+        data = data[n:]
+
+
 class _StdoutToStderr:
     """fd 1 points at stderr inside the block: gloo and RCCL announce themselves on the C stdout (connection counts, the
     version banner at the first communicator), and the bench's stdout carries exactly ONE line"""
@@ -312,6 +328,8 @@ def _pass_line(args, world, N, d, M, S, pd, sched):
 
 
 def main():
+    if _REAL_STDOUT[0] is None:
+        _REAL_STDOUT[0] = os.dup(1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -469,8 +487,8 @@ def main():
             sys.stderr.write('bench.py: rank %d made no progress for %.0f s (a collective some rank never entered?); '
                              'G3_DIST_DRIVER=python selects the torch.distributed driver\n' % (rank, limit))
             if rank == 0:
-                print(json.dumps({'metric': 'GP logp+predict end-to-end', 'value': None, 'n_gpus': world,
-                                  'error': 'watchdog: no progress for %.0f s' % limit}), flush=True)
+                _emit_line({'metric': 'GP logp+predict end-to-end', 'value': None, 'n_gpus': world,
+                            'error': 'watchdog: no progress for %.0f s' % limit})
             sys.stderr.flush()
             os._exit(3)
         watchdog = threading.Timer(limit, _expired)
@@ -602,7 +620,7 @@ def main():
                         ln = dict(serial_line[0])
                         ln['overlap_timeout'] = True
                         ln['overlap_limit_s'] = lim2
-                        print(json.dumps(ln), flush=True)
+                        _emit_line(ln)
                     sys.stderr.flush()
                     os._exit(4)
                 overlap_wd = threading.Timer(lim2, _overlap_expired)

@@ -215,6 +215,8 @@ struct AsyncCallbackTransport : Transport {
     hipStream_t cs = nullptr;            // copy stream
     char* stage = nullptr;               // pinned staging
     size_t stage_bytes = 0;
+    std::vector<char*> retired;          // outgrown staging buffers: released at teardown (hipHostFree synchronises the
+                                         // DEVICE -- called while a stream waits for this worker it would never return)
     int failed = 0;
     char msg[200] = {0};
   } w[2];                                // 0: all-gather + all-reduce, 1: broadcast
@@ -248,6 +250,7 @@ struct AsyncCallbackTransport : Transport {
       }
       if (w[i].cs) { (void)hipStreamSynchronize(w[i].cs); (void)hipStreamDestroy(w[i].cs); }
       if (w[i].stage) (void)hipHostFree(w[i].stage);
+      for (char* p : w[i].retired) (void)hipHostFree(p);
       if (w[i].ticket) (void)hipHostFree(w[i].ticket);
     }
     for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
@@ -263,8 +266,9 @@ struct AsyncCallbackTransport : Transport {
   void give_event(hipEvent_t e) { std::lock_guard<std::mutex> lk(evmu); evpool.push_back(e); }
   bool ensure_stage(Worker& W, size_t bytes) {
     if (W.stage_bytes >= bytes) return true;
-    if (W.stage) (void)hipHostFree(W.stage);
+    if (W.stage) W.retired.push_back(W.stage);       // (not freed here: see `retired`)
     W.stage = nullptr; W.stage_bytes = 0;
+    bytes += bytes / 4;                              // head room: plans of one driver differ by a few blocks
     if (hipHostMalloc((void**)&W.stage, bytes, hipHostMallocDefault) != hipSuccess) return false;
     W.stage_bytes = bytes;
     return true;
@@ -412,6 +416,7 @@ struct g3_dist {
   char* vt = nullptr;           // nb x nb scratch of the inversion: V^T
   char* ubuf = nullptr;         // nb x nb scratch of the inversion: (L21 V11)^T per pair
   char* rbuf = nullptr;         // (rows_rhs + rows_inv) x nb: the right-hand-side rows of a panel, solved out of place
+  int deal_snake = 0;           // G3_DIST_DEAL=snake (read at creation): the round-4 dealing, for A/B measurements
   int plan_gen = 0;             // bumped by every g3_dist_plan: a replay notices a re-planned reference
   int replay_refs = 0;          // replay drivers that read this driver's factor: it refuses re-plan / destroy meanwhile
   // phases timed with the collectives' event machinery: 3 = a diagonal block's update + factorisation, 4 = a panel solve
@@ -680,6 +685,10 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
   }
   D->serial_coll = g3h_env_int("G3_DIST_SERIAL_COLL", 0) != 0;
   D->want_fullinv = g3h_env_int("G3_DIST_FULLINV", 1) != 0;
+  {
+    const char* dl = getenv("G3_DIST_DEAL");
+    D->deal_snake = (dl && !strcmp(dl, "snake")) ? 1 : 0;
+  }
   D->ctx_bulk->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
   *out = D;
   return G3_OK;
@@ -856,7 +865,7 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   D->Mp = g3_roundup(M, 128);
   D->nchunk = 1 + (int)(D->Mp / 128);
   D->my_blocks.clear(); D->my_chunks.clear();
-  g3h_deal(D->world, D->nblk, &D->owner);
+  g3h_deal(D->world, D->nblk, &D->owner, D->deal_snake);
   D->loff.assign(D->nblk, -1);
   for (int I = 0; I < D->nblk; ++I)
     if (owner_of(D, I) == D->rank) { D->loff[I] = (int64_t)D->my_blocks.size() * nb; D->my_blocks.push_back(I); }

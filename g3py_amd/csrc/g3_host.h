@@ -304,9 +304,16 @@ static inline void trsm_ops_rec(TrsmOps* ops, int64_t c0, int64_t n) {
 // a full one.  Round-robin would leave the last rank at 1.4x.  Deterministic (ties: lowest rank): every rank computes
 // the same table, and g3py_amd/distributed.py::deal_blocks mirrors it line by line.
 #include <algorithm>
-static inline void g3h_deal(int P, int nblk, std::vector<int>* owner) {
+static inline void g3h_deal(int P, int nblk, std::vector<int>* owner, int snake = 0) {
   owner->assign(nblk > 0 ? nblk : 0, 0);
   if (P < 1) return;
+  if (snake) {            // G3_DIST_DEAL=snake: the boustrophedon of rounds 1-4 (A/B measurements)
+    for (int I = 0; I < nblk; ++I) {
+      const int r = I % (2 * P);
+      (*owner)[I] = r < P ? r : 2 * P - 1 - r;
+    }
+    return;
+  }
   std::vector<int64_t> load(P, 0);
   std::vector<int> order(P);
   for (int top = nblk - 1; top >= 0; top -= P) {

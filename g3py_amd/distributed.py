@@ -48,6 +48,9 @@ def deal_blocks(P, nblk):
     """owner[I] of row block I -- the line-by-line mirror of g3_host.h::g3h_deal: blocks are dealt from the top in rounds of
     P, every rank one block per round, the least loaded rank so far the heaviest block of the round (block I weighs
     I^2 + 6 I + 1: its trailing updates, column updates and panel solves over the sweep); ties go to the lowest rank"""
+    import os
+    if os.environ.get('G3_DIST_DEAL', '') == 'snake':       # the boustrophedon of rounds 1-4 (A/B measurements, as g3_dist.hip)
+        return [(I % (2 * P)) if (I % (2 * P)) < P else 2 * P - 1 - (I % (2 * P)) for I in range(max(nblk, 0))]
     owner = [0] * max(nblk, 0)
     load = [0] * P
     top = nblk - 1

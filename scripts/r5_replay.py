@@ -29,7 +29,7 @@ spec_f = ('SE', 1.0, np.ones(d), None)
 from oracle import g3_oracle as orc          # (only for the noise wrapper of the kernel spec: no arithmetic)
 spec_n = orc.with_noise(spec_f, 0.1)
 flops = bench.step_flops(N, M)
-KNOBS = ('G3_DIST_FULLINV', 'G3_GEMM_BIG_MIN_K', 'G3_GEMM_BIG_MIN', 'G3_TRSM_THIN_MAX', 'G3_SIDE_LDS')
+KNOBS = ('G3_DIST_FULLINV', 'G3_GEMM_BIG_MIN_K', 'G3_GEMM_BIG_MIN', 'G3_TRSM_THIN_MAX', 'G3_SIDE_LDS', 'G3_DIST_DEAL', 'R5_IDLE')
 
 
 def env_of(name):
@@ -43,6 +43,10 @@ def env_of(name):
             e['G3_GEMM_BIG_MIN'] = part[3:]
         elif part.startswith('lds'):
             e['G3_SIDE_LDS'] = part[3:]
+        elif part == 'snake':
+            e['G3_DIST_DEAL'] = 'snake'
+        elif part.startswith('idle'):           # idle<n>: n idle high- and n idle low-priority streams created before the drivers
+            e['R5_IDLE'] = part[4:]
     return e
 
 
@@ -72,6 +76,7 @@ for var in variants:
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env_of(var))
+    idle = [torch.cuda.Stream(priority=pr) for _ in range(int(os.environ.get('R5_IDLE', '0'))) for pr in (-1, 0)]
     dev = g3.Device(0)                               # the knobs are read when a context is created
     Xd, Xsd, dd = wrap(dev, Xt, N, d), wrap(dev, Xst, M, d), wrap(dev, dlt, 1, N)
     ref = NativeDistributedGP(dev, None, 0, 1, N, d, M, nb=nb, dtype=dt, transport='callbacks', keep=True)
