@@ -29,6 +29,7 @@
 #include <math.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include <condition_variable>
 #include <deque>
@@ -380,6 +381,14 @@ struct g3_dist {
   g3_ctx* ctx_look = nullptr;   // look-ahead stream: its own context, so no scratch / info flag is shared
   g3_ctx* ctx_bulk = nullptr;   // bulk stream
   hipStream_t s_look = nullptr, s_bulk = nullptr;
+  // The chain runs on a stream of the DRIVER (not the caller's), created back to back with the other two: which hardware
+  // queue -- and which of the chip's compute pipes -- a stream lands on is decided by creation order, and the same replayed
+  // rank measured 36.9 or 42.1 ms (config 4, P = 8, one box) depending on how many streams the process had created before
+  // the driver's.  Three consecutive creations keep the three streams of the sweep on distinct queues whatever the caller
+  // did; its stream only brackets an entry point (ChainScope).  G3_DIST_OWN_CHAIN=0: the chain on the caller's stream.
+  hipStream_t s_chain = nullptr;
+  hipEvent_t ev_bracket = nullptr;
+  std::vector<hipStream_t> pad_streams;   // G3_DIST_PAD_STREAMS=n (measurements): n idle streams created in front of the three
   int rank = 0, world = 1;
   Transport* tr = nullptr;
   // plan
@@ -480,6 +489,28 @@ struct ReplayTransport : Transport {
       return _rc < 0 ? _rc : G3_ERR_HIP;                                                           \
     }                                                                                              \
   } while (0)
+
+// An entry point's work runs on the driver's own chain stream: it starts behind everything the caller has queued on its
+// stream, and the caller's stream continues behind it.  (The context's program ring records its events on the stream a slot
+// was consumed on, so switching the stream of a context between calls is safe.)
+struct ChainScope {
+  g3_dist* D;
+  hipStream_t user;
+  explicit ChainScope(g3_dist* D_) : D(D_), user(D_->ctx->stream) {
+    if (!D->s_chain) return;
+    (void)hipEventRecord(D->ev_bracket, user);
+    (void)hipStreamWaitEvent(D->s_chain, D->ev_bracket, 0);
+    D->ctx->stream = D->s_chain;
+  }
+  ~ChainScope() {
+    if (!D->s_chain) return;
+    (void)hipEventRecord(D->ev_bracket, D->s_chain);
+    (void)hipStreamWaitEvent(user, D->ev_bracket, 0);
+    D->ctx->stream = user;
+  }
+  ChainScope(const ChainScope&) = delete;
+  ChainScope& operator=(const ChainScope&) = delete;
+};
 
 // a sweep that ended in an error on this rank: its RCCL communicators are aborted (not destroyed) at teardown
 static int mark_failed(g3_dist* D, int rc) {
@@ -642,6 +673,131 @@ static int do_allreduce(g3_dist* D, double* host, int n, int op) {
   return coll_end(D, D->ctx->stream);
 }
 
+// ---------------------------------------------------------------------------------------- stream placement probe
+// Where a HIP stream's hardware queue lands is decided by the runtime from the process's stream history, and it matters:
+// when the bulk stream's queue shares a compute pipe with the chain's or the look-ahead's, their small kernels wait for the
+// pipe to finish DISPATCHING a CU-filling bulk launch -- the same replayed rank (config 4, P = 8) took 33.5 or 42 ms with
+// nothing changed but the number of idle streams created before the driver's (profiles/r05_placement.txt).  HIP offers no
+// way to ask; so the driver measures: it creates four high- and four low-priority candidates, and for every pair runs a
+// dispatch-bound kernel (32768 short workgroups, ~0.7 ms) on one while a one-wave kernel is submitted on the other.  Sharing
+// shows as the small kernel's latency jumping from ~20 us to a large part of the long kernel's duration.  The three streams
+// of the sweep are a triple with no sharing; the rest are destroyed.  ~60 ms once per driver; G3_DIST_PROBE=0 takes the
+// first of each (G3_DIST_PROBE_LOG=1 prints the matrix).
+__global__ void probe_long_kernel(int iters) {
+  for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
+}
+__global__ void probe_tiny_kernel(unsigned* out) {
+  if (threadIdx.x == 0 && out) *out = 1u;
+}
+static double probe_now_us() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+// latency (us) of a one-wave kernel submitted on `a` while the dispatch-bound kernel runs on `b`, and that kernel's duration
+static bool probe_pair(hipStream_t a, hipStream_t b, unsigned* scratch, double* tiny_us, double* long_us, int reps) {
+  double best = 1e30, lbest = 1e30;
+  for (int rep = 0; rep < reps; ++rep) {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const double t0 = probe_now_us();
+    hipLaunchKernelGGL(probe_long_kernel, dim3(32768), dim3(256), 0, b, 12);
+    // let the long kernel get going, then submit the small one and wait for it
+    while (probe_now_us() - t0 < 100.0) {}
+    const double t1 = probe_now_us();
+    hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, a, scratch);
+    if (hipStreamSynchronize(a) != hipSuccess) return false;
+    const double t2 = probe_now_us();
+    if (hipStreamSynchronize(b) != hipSuccess) return false;
+    const double t3 = probe_now_us();
+    if (t2 - t1 < best) best = t2 - t1;
+    if (t3 - t0 < lbest) lbest = t3 - t0;
+  }
+  *tiny_us = best;
+  *long_us = lbest;
+  return hipGetLastError() == hipSuccess;
+}
+
+// picks (chain, look, bulk) out of freshly created candidates; on any failure falls back to the first of each
+static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
+  const int NH = 4, NL = 4;
+  hipStream_t H[NH] = {nullptr, nullptr, nullptr, nullptr}, L[NL] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < NH && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&H[i], hipStreamNonBlocking, hi);
+  for (int i = 0; i < NL && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&L[i], hipStreamNonBlocking, lo);
+  unsigned* scratch = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void**)&scratch, sizeof(unsigned));
+  auto cleanup = [&](int kc, int kl, int kb) {
+    for (int i = 0; i < NH; ++i) if (H[i] && i != kc && i != kl) (void)hipStreamDestroy(H[i]);
+    for (int i = 0; i < NL; ++i) if (L[i] && i != kb) (void)hipStreamDestroy(L[i]);
+    if (scratch) (void)hipFree(scratch);
+  };
+  if (e != hipSuccess) { cleanup(-1, -1, -1); return G3_ERR_HIP; }
+  int kc = 0, kl = 1, kb = 0;
+  const bool probe = g3h_env_int("G3_DIST_PROBE", 1) != 0, log = g3h_env_int("G3_DIST_PROBE_LOG", 0) != 0;
+  hipStream_t user = D->ctx->stream;
+  if (probe) {
+    // th[i][j]: latency of a one-wave kernel on high candidate i (index NH = the caller's stream) beside a dispatch-bound
+    // launch on low candidate j; tt[i][j]: the same beside one on high candidate j.  Two signatures: the SAME hardware
+    // queue (the small kernel waits for the whole launch: most of its duration), and two queues on the same compute
+    // PIPE (the pipe serves its queues in turns: ~100 us instead of ~35 for every dependent kernel of a chain)
+    double th[NH + 1][NL], tt[NH + 1][NH + 1], lmean = 0, base = 1e30;
+    bool hl[NH + 1][NL], hh[NH + 1][NH + 1];
+    bool ok = true;
+    double t_us = 0, l_us = 0;
+    int nl = 0;
+    for (int i = 0; i <= NH && ok; ++i) {
+      hipStream_t a = i < NH ? H[i] : user;
+      for (int j = 0; j < NL && ok; ++j) {
+        ok = probe_pair(a, L[j], scratch, &t_us, &l_us, 2);
+        th[i][j] = t_us;
+        lmean += l_us; ++nl;
+        if (t_us < base) base = t_us;
+      }
+      for (int j = 0; j <= NH && ok; ++j) {
+        tt[i][j] = 0;
+        if (j == i) continue;
+        hipStream_t b = j < NH ? H[j] : user;
+        ok = probe_pair(a, b, scratch, &t_us, &l_us, 1);
+        tt[i][j] = t_us;
+        if (t_us < base) base = t_us;
+      }
+    }
+    lmean /= nl > 0 ? nl : 1;
+    const double limit = base * 2.0 > base + 40.0 ? base * 2.0 : base + 40.0;
+    for (int i = 0; i <= NH && ok; ++i) {
+      for (int j = 0; j < NL; ++j) {
+        hl[i][j] = th[i][j] > limit;
+        if (log) fprintf(stderr, "libg3hip placement: high %d / low %d: small kernel %.0f us beside a %.0f us dispatch-bound launch%s\n", i, j,
+                         th[i][j], lmean, hl[i][j] ? (th[i][j] > 0.5 * lmean ? "  <- same queue" : "  <- same pipe") : "");
+      }
+      for (int j = 0; j <= NH; ++j) {
+        hh[i][j] = j != i && tt[i][j] > limit;
+        if (log && hh[i][j]) fprintf(stderr, "libg3hip placement: high %d / high %d: %.0f us%s\n", i, j, tt[i][j],
+                                     tt[i][j] > 0.5 * lmean ? "  <- same queue" : "  <- same pipe");
+      }
+    }
+    if (ok) {
+      // chain candidates: the driver's own (0 .. NH-1) or the caller's stream (NH); fewest conflicts wins, first in order on ties
+      int bestc = 1 << 30;
+      for (int b = 0; b < NL; ++b)
+        for (int c = own_chain ? 0 : NH; c <= (own_chain ? NH - 1 : NH); ++c)
+          for (int l = 0; l < NH; ++l) {
+            if (l == c) continue;
+            const int conflicts = 4 * (int)hl[c][b] + 4 * (int)hl[l][b] + (int)(hh[c][l] || hh[l][c]);
+            if (conflicts < bestc) { bestc = conflicts; kc = c; kl = l; kb = b; }
+          }
+      if (log) fprintf(stderr, "libg3hip placement: chain = high %d%s, look-ahead = high %d, bulk = low %d (%d conflicts)\n", kc,
+                       kc == NH ? " (caller's stream)" : "", kl, kb, bestc);
+    }
+  }
+  if (!own_chain) kc = NH;
+  D->s_chain = kc < NH ? H[kc] : nullptr;
+  D->s_look = H[kl];
+  D->s_bulk = L[kb];
+  cleanup(kc, kl, kb);
+  return G3_OK;
+}
+
 // ---------------------------------------------------------------------------------------- create / destroy
 extern "C" int g3_dist_unique_id(void* id_out) {
   if (!id_out) return -1;
@@ -668,8 +824,15 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
   // their own.  HIP maps streams onto a few hardware queues per priority; with the four idle streams two ordinary contexts
   // would bring, whether the chain stream and the look-ahead stream share a queue (and then serialise) depended on what
   // else the process had created before (the same replay measured 45 or 37 ms at P = 8).
-  hipError_t e = hipStreamCreateWithPriority(&D->s_look, hipStreamNonBlocking, hi);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&D->s_bulk, hipStreamNonBlocking, lo);
+  hipError_t e = hipSuccess;
+  for (int i = 0, n = g3h_env_int("G3_DIST_PAD_STREAMS", 0); i < n && e == hipSuccess; ++i) {
+    hipStream_t ps = nullptr;
+    e = hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, (i & 1) ? lo : hi);
+    if (e == hipSuccess) D->pad_streams.push_back(ps);
+  }
+  const bool own_chain = g3h_env_int("G3_DIST_OWN_CHAIN", 1) != 0;
+  if (e == hipSuccess && pick_streams(D, lo, hi, own_chain) != G3_OK) e = hipErrorUnknown;
+  if (e == hipSuccess && D->s_chain) e = hipEventCreateWithFlags(&D->ev_bracket, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&D->info_dev, sizeof(int));
   int rc = e == hipSuccess ? G3_OK : G3_ERR_HIP;
   if (!rc) rc = g3i_ctx_create_on(ctx->device, D->s_look, &D->ctx_look);
@@ -679,6 +842,9 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
     if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
     if (D->s_look) (void)hipStreamDestroy(D->s_look);
     if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
+    if (D->s_chain) (void)hipStreamDestroy(D->s_chain);
+    if (D->ev_bracket) (void)hipEventDestroy(D->ev_bracket);
+    for (hipStream_t ps : D->pad_streams) (void)hipStreamDestroy(ps);
     if (D->info_dev) (void)hipFree(D->info_dev);
     delete D;
     return rc;
@@ -838,6 +1004,9 @@ extern "C" int g3_dist_destroy(g3_dist* D) {
   if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
   if (D->s_look) (void)hipStreamDestroy(D->s_look);
   if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
+  if (D->s_chain) { (void)hipStreamSynchronize(D->s_chain); (void)hipStreamDestroy(D->s_chain); }
+  if (D->ev_bracket) (void)hipEventDestroy(D->ev_bracket);
+  for (hipStream_t ps : D->pad_streams) (void)hipStreamDestroy(ps);
   delete D;
   return G3_OK;
 }
@@ -1433,6 +1602,7 @@ extern "C" int g3_dist_gp_factor_predict(g3_dist* D, const g3_kernel_prog* prog,
   if (D->M > 0 && (!mean_host || !ss_host)) return -10;
   if (g3i_validate_prog(prog, D->d) || g3i_validate_prog(prog_cross, D->d)) return -2;
   g3_dev_guard _dg(D->ctx);
+  ChainScope _cs(D);
   int rc = factor_robust(D, prog, prog_cross, X_dev, ldx, Xs_dev, ldxs, delta_dev);
   if (rc) return mark_failed(D, rc);
   std::vector<double> mm(D->M > 0 ? D->M : 1), sv(D->M > 0 ? D->M : 1);
@@ -1554,6 +1724,7 @@ extern "C" int g3_dist_posterior_cov(g3_dist* D, const g3_kernel_prog* prog, con
   if (!cov_dev) return -5;
   if (ldc < D->Mp) return -6;
   g3_dev_guard _dg(D->ctx);
+  ChainScope _cs(D);
   int rcx = same_xs_as_evaluated(D, Xs_dev, ldxs);
   if (rcx) return rcx;
   return posterior_cov(D, prog, Xs_dev, ldxs, (char*)cov_dev, ldc);
@@ -1573,6 +1744,7 @@ extern "C" int g3_dist_posterior_draws(g3_dist* D, const g3_kernel_prog* prog_f,
   if (!out_host) return -8;
   if (g3i_validate_prog(prog_f, D->d)) return -2;
   g3_dev_guard _dg(D->ctx);
+  ChainScope _cs(D);
   {
     const int rcx = same_xs_as_evaluated(D, Xs_dev, ldxs);
     if (rcx) return rcx;
@@ -1658,6 +1830,7 @@ extern "C" int g3_dist_gp_dlogp(g3_dist* D, const g3_kernel_prog* prog, const g3
   if (ldx < D->d) return -5;
   if (!slots_host) return -7;
   g3_dev_guard _dg(D->ctx);
+  ChainScope _cs(D);
   const int64_t nb = D->nb, Np = D->Np;
   const size_t es = D->es;
   const int nblk = D->nblk;
@@ -1750,6 +1923,7 @@ extern "C" int g3_dist_comm_stats(g3_dist* D, double out_host[9]) {
   if (!out_host) return -2;
   g3_dev_guard _dg(D->ctx);
   G3D_HIP(hipStreamSynchronize(D->ctx->stream));
+  if (D->s_chain) G3D_HIP(hipStreamSynchronize(D->s_chain));
   G3D_HIP(hipStreamSynchronize(D->s_look));
   G3D_HIP(hipStreamSynchronize(D->s_bulk));
   double ms[G3_NKIND] = {0, 0, 0, 0, 0};

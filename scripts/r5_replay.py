@@ -29,7 +29,7 @@ spec_f = ('SE', 1.0, np.ones(d), None)
 from oracle import g3_oracle as orc          # (only for the noise wrapper of the kernel spec: no arithmetic)
 spec_n = orc.with_noise(spec_f, 0.1)
 flops = bench.step_flops(N, M)
-KNOBS = ('G3_DIST_FULLINV', 'G3_GEMM_BIG_MIN_K', 'G3_GEMM_BIG_MIN', 'G3_TRSM_THIN_MAX', 'G3_SIDE_LDS', 'G3_DIST_DEAL', 'R5_IDLE')
+KNOBS = ('G3_DIST_FULLINV', 'G3_GEMM_BIG_MIN_K', 'G3_GEMM_BIG_MIN', 'G3_TRSM_THIN_MAX', 'G3_SIDE_LDS', 'G3_DIST_DEAL', 'R5_IDLE', 'G3_DIST_OWN_CHAIN', 'G3_DIST_PAD_STREAMS')
 
 
 def env_of(name):
@@ -43,6 +43,10 @@ def env_of(name):
             e['G3_GEMM_BIG_MIN'] = part[3:]
         elif part.startswith('lds'):
             e['G3_SIDE_LDS'] = part[3:]
+        elif part == 'userchain':
+            e['G3_DIST_OWN_CHAIN'] = '0'
+        elif part.startswith('pad'):
+            e['G3_DIST_PAD_STREAMS'] = part[3:]
         elif part == 'snake':
             e['G3_DIST_DEAL'] = 'snake'
         elif part.startswith('idle'):           # idle<n>: n idle high- and n idle low-priority streams created before the drivers
