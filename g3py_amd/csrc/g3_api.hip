@@ -14,11 +14,81 @@ extern "C" int g3_ctx_create(int device, g3_ctx** out) { return ctx_create_impl(
 // made this way: HIP maps streams onto a few hardware queues per priority, and every idle stream a process holds shifts
 // which of the streams that matter end up sharing one.
 int g3i_ctx_create_on(int device, hipStream_t stream, g3_ctx** out) { return stream ? ctx_create_impl(device, stream, out) : -3; }
+// ---- stream placement probe (shared with the multi-GPU driver, g3_dist.hip::pick_streams).  Two HIP streams whose hardware
+// queues sit on the same compute pipe disturb each other: while the pipe dispatches a CU-filling launch of one, every small
+// kernel of the other waits ~100 us instead of ~35 (and most of the launch when they share the QUEUE).  HIP decides the
+// placement from the process's stream history and offers no way to ask, so it is measured.
+#include <time.h>
+__global__ void probe_long_kernel(int iters) {
+  for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
+}
+__global__ void probe_tiny_kernel(unsigned* out) {
+  if (threadIdx.x == 0 && out) *out = 1u;
+}
+static double probe_now_us() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+// latency (us) of a one-wave kernel submitted on `a` while the dispatch-bound kernel runs on `b`, and that kernel's duration
+bool g3i_probe_pair(hipStream_t a, hipStream_t b, unsigned* scratch, double* tiny_us, double* long_us, int reps) {
+  double best = 1e30, lbest = 1e30;
+  for (int rep = 0; rep < reps; ++rep) {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const double t0 = probe_now_us();
+    hipLaunchKernelGGL(probe_long_kernel, dim3(32768), dim3(256), 0, b, 12);
+    // let the long kernel get going, then submit the small one and wait for it
+    while (probe_now_us() - t0 < 100.0) {}
+    const double t1 = probe_now_us();
+    hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, a, scratch);
+    if (hipStreamSynchronize(a) != hipSuccess) return false;
+    const double t2 = probe_now_us();
+    if (hipStreamSynchronize(b) != hipSuccess) return false;
+    const double t3 = probe_now_us();
+    if (t2 - t1 < best) best = t2 - t1;
+    if (t3 - t0 < lbest) lbest = t3 - t0;
+  }
+  *tiny_us = best;
+  *long_us = lbest;
+  return hipGetLastError() == hipSuccess;
+}
+
+
+// The low-priority side stream of the two-stream sweeps: (re)chosen, by the probe above, the first time a sweep needs it with
+// the stream the context currently works on -- four low-priority candidates (the context's own side stream among them), the
+// first whose queue does not share a pipe with the chain's stream wins.  ~7 ms once per (context, stream); G3_PROBE=0 keeps
+// whatever the runtime dealt.
 int g3i_ensure_side_stream(g3_ctx* ctx) {
-  if (ctx->side_stream) return G3_OK;
+  if (ctx->side_stream && (ctx->side_for == ctx->stream || !ctx->tune.probe)) return G3_OK;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  G3_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
+  if (!ctx->side_stream) G3_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, lo));
+  ctx->side_for = ctx->stream;
+  if (!ctx->tune.probe) return G3_OK;
+  const int NL = 4;
+  hipStream_t L[NL] = {ctx->side_stream, nullptr, nullptr, nullptr};
+  for (int i = 1; i < NL; ++i)
+    if (hipStreamCreateWithPriority(&L[i], hipStreamNonBlocking, lo) != hipSuccess) L[i] = nullptr;
+  double t[NL], base = 1e30, tl = 0;
+  bool ok = true;
+  unsigned* scratch = (unsigned*)(ctx->d_stats + 63);   // (the last word of the reduction scratch: no reduction uses it)
+  for (int i = 0; i < NL && ok; ++i) {
+    t[i] = 1e30;
+    if (!L[i]) continue;
+    ok = g3i_probe_pair(ctx->stream, L[i], scratch, &t[i], &tl, 2);
+    if (t[i] < base) base = t[i];
+  }
+  int pick = 0;
+  if (ok) {
+    const double limit = base * 2.0 > base + 40.0 ? base * 2.0 : base + 40.0;
+    for (int i = 0; i < NL; ++i)
+      if (L[i] && t[i] <= limit) { pick = i; break; }
+    if (ctx->tune.probe > 1)
+      fprintf(stderr, "libg3hip placement: side stream candidates %.0f %.0f %.0f %.0f us beside the chain's stream -> %d\n", t[0], t[1], t[2], t[3], pick);
+  }
+  for (int i = 0; i < NL; ++i)
+    if (L[i] && i != pick) (void)hipStreamDestroy(L[i]);
+  ctx->side_stream = L[pick];
   return G3_OK;
 }
 
@@ -962,13 +1032,13 @@ static int gp_factor_batched_impl(g3_ctx* ctx, const MemberProgs& mp, int batch,
   }
   const int64_t wstride = Np * G3_LB;
   // K_b = tt_to_cov(cov(X)) (elliptical.py:70-71), right-hand-side block = [delta_b; 0]
+  const unsigned nb = (unsigned)((Np + 255) / 256);
+  char* rhs = (char*)K + (size_t)Np * ldk * es;
+  const bool small = Np <= 2 * G3_LB;       // one workgroup per member does the whole evaluation (g3i_small_factor_batched)
   int pr = g3i_prof_begin(ctx, G3_TAG_GRAM, (double)batch * ((double)N * d + 0.5 * (double)N * (N + 1)) * es);
   rc = g3i_gram_batched(ctx, dprogs, progs, batch, X, N, ldx, d, dt, K, ldk, kstride, Np,
                         G3_GRAM_LOWER | G3_GRAM_SCRUB | G3_GRAM_PAD_EYE);
   if (rc) return rc;
-  const unsigned nb = (unsigned)((Np + 255) / 256);
-  char* rhs = (char*)K + (size_t)Np * ldk * es;
-  const bool small = Np <= 2 * G3_LB;       // one workgroup per member does the whole evaluation (g3i_small_factor_batched)
   if (small) {
     if (dt == G3_F64)
       hipLaunchKernelGGL((diag_stats_kernel<double>), dim3(batch), dim3(1024), 0, ctx->stream, (double*)K, N, ldk, (double*)nullptr, 1, kstride);

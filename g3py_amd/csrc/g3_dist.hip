@@ -683,40 +683,6 @@ static int do_allreduce(g3_dist* D, double* host, int n, int op) {
 // shows as the small kernel's latency jumping from ~20 us to a large part of the long kernel's duration.  The three streams
 // of the sweep are a triple with no sharing; the rest are destroyed.  ~60 ms once per driver; G3_DIST_PROBE=0 takes the
 // first of each (G3_DIST_PROBE_LOG=1 prints the matrix).
-__global__ void probe_long_kernel(int iters) {
-  for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
-}
-__global__ void probe_tiny_kernel(unsigned* out) {
-  if (threadIdx.x == 0 && out) *out = 1u;
-}
-static double probe_now_us() {
-  struct timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
-}
-// latency (us) of a one-wave kernel submitted on `a` while the dispatch-bound kernel runs on `b`, and that kernel's duration
-static bool probe_pair(hipStream_t a, hipStream_t b, unsigned* scratch, double* tiny_us, double* long_us, int reps) {
-  double best = 1e30, lbest = 1e30;
-  for (int rep = 0; rep < reps; ++rep) {
-    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
-    const double t0 = probe_now_us();
-    hipLaunchKernelGGL(probe_long_kernel, dim3(32768), dim3(256), 0, b, 12);
-    // let the long kernel get going, then submit the small one and wait for it
-    while (probe_now_us() - t0 < 100.0) {}
-    const double t1 = probe_now_us();
-    hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, a, scratch);
-    if (hipStreamSynchronize(a) != hipSuccess) return false;
-    const double t2 = probe_now_us();
-    if (hipStreamSynchronize(b) != hipSuccess) return false;
-    const double t3 = probe_now_us();
-    if (t2 - t1 < best) best = t2 - t1;
-    if (t3 - t0 < lbest) lbest = t3 - t0;
-  }
-  *tiny_us = best;
-  *long_us = lbest;
-  return hipGetLastError() == hipSuccess;
-}
-
 // picks (chain, look, bulk) out of freshly created candidates; on any failure falls back to the first of each
 static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
   const int NH = 4, NL = 4;
@@ -748,7 +714,7 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
     for (int i = 0; i <= NH && ok; ++i) {
       hipStream_t a = i < NH ? H[i] : user;
       for (int j = 0; j < NL && ok; ++j) {
-        ok = probe_pair(a, L[j], scratch, &t_us, &l_us, 2);
+        ok = g3i_probe_pair(a, L[j], scratch, &t_us, &l_us, 2);
         th[i][j] = t_us;
         lmean += l_us; ++nl;
         if (t_us < base) base = t_us;
@@ -757,7 +723,7 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
         tt[i][j] = 0;
         if (j == i) continue;
         hipStream_t b = j < NH ? H[j] : user;
-        ok = probe_pair(a, b, scratch, &t_us, &l_us, 1);
+        ok = g3i_probe_pair(a, b, scratch, &t_us, &l_us, 1);
         tt[i][j] = t_us;
         if (t_us < base) base = t_us;
       }

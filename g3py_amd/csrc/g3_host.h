@@ -40,6 +40,7 @@ struct G3hTune {
   int gram_interpret;     // G3_GRAM_NOFAST   1: always the interpreted Gram kernel (A/B measurements)
   int grad_interpret;     // G3_GRAD_GENERIC  1: always the interpreted Gram-gradient kernel
   int gram_jit;           // G3_GRAM_JIT      0: never generate a Gram kernel for an expression (g3_gram_jit.hip); default 1
+  int probe;              // G3_PROBE         stream-placement probe of the two-stream sweeps (1; 0: off; 2: also print what it found)
 };
 #define G3H_STAIR_MAX 160
 static inline G3hTune g3h_tune_from_env() {
@@ -68,6 +69,7 @@ static inline G3hTune g3h_tune_from_env() {
   t.gram_interpret = g3h_env_int("G3_GRAM_NOFAST", 0) ? 1 : 0;
   t.grad_interpret = g3h_env_int("G3_GRAD_GENERIC", 0) ? 1 : 0;
   t.gram_jit = g3h_env_int("G3_GRAM_JIT", 1) ? 1 : 0;
+  t.probe = g3h_env_int("G3_PROBE", 1);
   return t;
 }
 

@@ -16,6 +16,7 @@ struct g3_ctx {
   hipStream_t stream;      // stream work is enqueued on
   hipStream_t own_stream;  // created by the context
   hipStream_t side_stream; // low-priority stream carrying the bulk trailing updates (look-ahead)
+  hipStream_t side_for;    // the stream the side stream's placement was probed against (g3i_ensure_side_stream)
   hipEvent_t* la_ev;       // look-ahead events (2 per panel)
   int la_nev;
   int64_t nb_lookahead;    // panel width of the flat right-looking sweep (0 = default)
@@ -146,6 +147,8 @@ static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m 
 // a context on the caller's stream that creates no stream of its own; the low-priority side stream on first need
 int g3i_ctx_create_on(int device, hipStream_t stream, g3_ctx** out);
 int g3i_ensure_side_stream(g3_ctx* ctx);
+// latency (us) of a one-wave kernel submitted on `a` while a dispatch-bound launch (its duration in *long_us) runs on `b`
+bool g3i_probe_pair(hipStream_t a, hipStream_t b, unsigned* scratch, double* tiny_us, double* long_us, int reps);
 
 // internal launchers (stream-ordered, no host sync)
 int g3i_gemm_nt(g3_ctx* ctx, void* C, int64_t ldc, const void* A, int64_t lda, const void* B,

@@ -690,9 +690,18 @@ potrf256_kernel(T* A, int64_t ld, T* W, int* info, int64_t row_base, int64_t a_b
 //   L = chol(K_b) in place (the fused 256-wide factorisation, or the 128-wide one), its block inverses W_b,
 //   a_b = L^-1 delta_b through the inverses (a_0 = W_0 d_0;  a_1 = W_1 (d_1 - L_10 a_0)),
 //   sum log L_ii, a^T a, the counts of non-finite entries -- four doubles per member.
-// The covariance comes from the one batched Gram launch before it (grid.z = batch).
+// The covariance comes from the one batched Gram launch before it (grid.z = batch; generated per expression since round
+// 4: 0.20 ms per 4096 members at N = 128).  Building it INSIDE this kernel was tried twice in round 5 and measured slower:
+// the member's program interpreted per pair (g3_kernel_eval.h::prog_eval) costs 63 us per member, a written-out stationary
+// kernel 27 us, against the 37 us of the whole factorisation -- one 512-thread workgroup per CU has two waves per SIMD and
+// hides neither the loads of the inputs nor the fp64 exp; the full-occupancy Gram kernel does (profiles/r05_chain_small.txt).
+#ifdef G3_SMALL_VGPR     // measurement builds: force the register budget (two workgroups per CU need <= 128)
+#define G3_SMALL_ATTR __attribute__((amdgpu_num_vgpr(G3_SMALL_VGPR)))
+#else
+#define G3_SMALL_ATTR
+#endif
 template <typename T>
-__global__ void __launch_bounds__(512, 4)
+__global__ void __launch_bounds__(512, 4) G3_SMALL_ATTR
 small_factor_kernel(T* K, int64_t ld, int64_t kstride, T* Wall, int64_t wstride, const T* delta, int64_t ldd, T* a_out, int64_t astride,
                     double* stats, int* info, int n, int np) {
   const int b = blockIdx.x;
@@ -700,9 +709,12 @@ small_factor_kernel(T* K, int64_t ld, int64_t kstride, T* Wall, int64_t wstride,
   T* A = K + (int64_t)b * kstride;
   T* W = Wall + (int64_t)b * wstride;
   __shared__ DiagLds<T> S;
-  __shared__ T vec[2 * G3_LB];        // the right-hand side, then a
-  __shared__ T part[4 * G3_LB];       // partial dot products (4 column quarters x 128 rows)
-  __shared__ double red[4][8];
+  // the solve's scratch lives in the memory the factorisation has finished with: the kernel then asks for 78 KB of LDS, and
+  // TWO workgroups fit on a CU (2 x 78 <= 160 KB) when the register budget allows it as well
+  T* const vec = reinterpret_cast<T*>(&S);                  // [2 * 128]  the right-hand side, then a
+  T* const part = vec + 2 * G3_LB;                          // [4 * 128]  partial dot products (4 column quarters x 128 rows)
+  double (*const red)[8] = reinterpret_cast<double (*)[8]>(part + 4 * G3_LB);   // [4][8]
+  static_assert(sizeof(DiagLds<T>) >= 6 * G3_LB * sizeof(T) + 32 * sizeof(double), "solve scratch must fit in the factorisation's LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const int w = wv < 4 ? wv : 11 - wv;
