@@ -1012,8 +1012,11 @@ static int gp_factor_batched_impl(g3_ctx* ctx, const MemberProgs& mp, int batch,
   const size_t sbytes = (size_t)batch * 4 * sizeof(double);
   const size_t fbytes = mp.progs ? 0 : (size_t)batch * mp.nfield * sizeof(double);
   const size_t obytes = mp.progs ? 0 : (((size_t)mp.nfield * sizeof(int32_t) + 15) & ~(size_t)15);
-  rc = ensure_bbuf(ctx, pbytes + sbytes + (mp.progs ? 0 : sizeof(g3_kernel_prog)) + fbytes + obytes);
+  const size_t cbytes = g3i_coop_ctl_bytes(batch);
+  const size_t head = (pbytes + sbytes + (mp.progs ? 0 : sizeof(g3_kernel_prog)) + fbytes + obytes + 255) & ~(size_t)255;
+  rc = ensure_bbuf(ctx, head + cbytes);
   if (rc) return rc;
+  unsigned* coop_ctl = (unsigned*)((char*)ctx->bbuf + head);
   g3_kernel_prog* dprogs = (g3_kernel_prog*)ctx->bbuf;
   double* dstats = (double*)((char*)ctx->bbuf + pbytes);
   if (mp.progs) {
@@ -1067,21 +1070,33 @@ static int gp_factor_batched_impl(g3_ctx* ctx, const MemberProgs& mp, int batch,
   if (!small) {
   g3i_prof_end(ctx, pr);
   G3_LAUNCH_CHECK();
-  // one sweep factors every member; a member whose pivot fails only stops its own launches
-  ctx->batch = batch;
-  ctx->bstride = kstride;
-  ctx->bstride_w = wstride;
-  ctx->bw_base = (const char*)invd;
-  ctx->bw_bytes = (size_t)batch * wstride * es;
   pr = g3i_prof_begin(ctx, G3_TAG_POTRF, (double)batch * ((double)N * N * N / 3.0 + (double)N * N));
-  rc = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, RB);
-  g3i_prof_end(ctx, pr);
-  if (!rc && hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-    rc = G3_ERR_HIP;
-  if (!rc) rc = g3i_reset_info(ctx);
-  ctx->batch = 0;
-  ctx->bw_base = nullptr;
-  if (rc) return rc;
+  if (Np <= ctx->tune.coop_max_n && batch >= ctx->tune.coop_min_batch) {
+    // long chains of medium members: a group of workgroups per member, the whole batch in ONE launch (g3_chainb.hip): 1.2 -
+    // 1.3x the lock-step sweep below at N <= 512, 1.08x at 768 - 1024; short batches (< ~200 members) stay with the sweep,
+    // whose launches are at least as wide as the batch (profiles/r05_chain_medium.txt)
+    rc = g3i_coop_factor_batched(ctx, K, ldk, kstride, invd, wstride, coop_ctl, batch, Np, dt);
+    g3i_prof_end(ctx, pr);
+    if (!rc && hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = G3_ERR_HIP;
+    if (!rc && hipMemsetAsync(ctx->d_info, 0, sizeof(int) * batch, ctx->stream) != hipSuccess) rc = G3_ERR_HIP;   // every member's flag
+    if (rc) return rc;
+  } else {
+    // one sweep factors every member; a member whose pivot fails only stops its own launches
+    ctx->batch = batch;
+    ctx->bstride = kstride;
+    ctx->bstride_w = wstride;
+    ctx->bw_base = (const char*)invd;
+    ctx->bw_bytes = (size_t)batch * wstride * es;
+    rc = g3i_potrf_tall(ctx, K, Np, ldk, dt, invd, RB);
+    g3i_prof_end(ctx, pr);
+    if (!rc && hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = G3_ERR_HIP;
+    if (!rc) rc = g3i_reset_info(ctx);
+    ctx->batch = 0;
+    ctx->bw_base = nullptr;
+    if (rc) return rc;
+  }
   // a_b = first row of the solved right-hand-side block; log det and a^T a per member
   G3_HIP(hipMemcpy2DAsync(a, (size_t)Np * es, rhs, (size_t)kstride * es, (size_t)Np * es, (size_t)batch,
                           hipMemcpyDeviceToDevice, ctx->stream));

@@ -40,6 +40,9 @@ struct G3hTune {
   int gram_interpret;     // G3_GRAM_NOFAST   1: always the interpreted Gram kernel (A/B measurements)
   int grad_interpret;     // G3_GRAD_GENERIC  1: always the interpreted Gram-gradient kernel
   int gram_jit;           // G3_GRAM_JIT      0: never generate a Gram kernel for an expression (g3_gram_jit.hip); default 1
+  int coop_max_n;         // G3_COOP_MAX_N    chains: largest padded N whose members are factored by a workgroup group in one launch (1024; 0: never)
+  int coop_min_batch;     // G3_COOP_MIN_BATCH  ... and the shortest batch it is used for (200: below that the lock-step sweep is faster)
+  int coop_group;         // G3_COOP_GROUP    workgroups per member of that kernel (0: by batch size, 1 ... 8)
   int probe;              // G3_PROBE         stream-placement probe of the two-stream sweeps (1; 0: off; 2: also print what it found)
 };
 #define G3H_STAIR_MAX 160
@@ -69,6 +72,9 @@ static inline G3hTune g3h_tune_from_env() {
   t.gram_interpret = g3h_env_int("G3_GRAM_NOFAST", 0) ? 1 : 0;
   t.grad_interpret = g3h_env_int("G3_GRAD_GENERIC", 0) ? 1 : 0;
   t.gram_jit = g3h_env_int("G3_GRAM_JIT", 1) ? 1 : 0;
+  t.coop_max_n = g3h_env_int("G3_COOP_MAX_N", 1024);
+  t.coop_min_batch = g3h_env_int("G3_COOP_MIN_BATCH", 200);
+  t.coop_group = g3h_env_int("G3_COOP_GROUP", 0);
   t.probe = g3h_env_int("G3_PROBE", 1);
   return t;
 }

@@ -190,6 +190,12 @@ int g3i_logp_terms_dev(g3_ctx* ctx, const void* L, int64_t n, int64_t ld, const 
 // workgroup per member, one launch (g3_potrf.hip)
 int g3i_small_factor_batched(g3_ctx* ctx, void* K, int64_t ld, int64_t kstride, void* W, int64_t wstride, const void* delta, int64_t ldd,
                              void* a, int64_t astride, double* dstats, int batch, int64_t n, int64_t np, g3_dtype dt);
+// batch members of 384 ... 1024 padded rows: a group of workgroups per member factors it (and solves its right-hand-side rows)
+// in ONE launch for the whole batch (g3_chainb.hip); ctl: g3i_coop_ctl_bytes(batch) of device scratch
+size_t g3i_coop_ctl_bytes(int batch);
+int g3i_coop_group(const g3_ctx* ctx, int batch, int64_t np);
+int g3i_coop_factor_batched(g3_ctx* ctx, void* K, int64_t ld, int64_t kstride, void* W, int64_t wstride, unsigned* ctl, int batch,
+                            int64_t np, g3_dtype dt);
 #ifdef G3_CHAIN_SERVER
 // true when `info` says the chain server gave up: it is switched off for this context (one line on stderr)
 bool g3i_chain_gave_up(g3_ctx* ctx, int info);

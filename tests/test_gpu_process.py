@@ -723,6 +723,57 @@ def test_small_chain_one_workgroup_per_member(N, dtype):
         np.testing.assert_allclose(gp.dlogp_chain(chain[:5]), g1, rtol=1e-8, atol=1e-9)
 
 
+@pytest.mark.parametrize('N,B,group,dtype', [(300, 210, 0, np.float64), (512, 260, 0, np.float64), (700, 24, 3, np.float64), (1024, 12, 5, np.float64),
+                                             (896, 10, 2, np.float32), (384, 33, 8, np.float64)])
+def test_medium_chain_cooperative_kernel_equals_the_sweep_and_the_one_at_a_time_path(monkeypatch, N, B, group, dtype):
+    """VERDICT r4 item 5 (stochastic.py:515-531,740-771): members of 256 < N <= 1024 are factored by a GROUP of
+    workgroups each, the whole batch in one launch (g3_chainb.hip) -- one workgroup per member for long chains (group 0 = by
+    batch size), several (G3_COOP_GROUP) when forced, incl. an odd number of 128-blocks and fp32.  Every member equals the
+    batched lock-step sweep (G3_COOP_MAX_N=0) at 1e-12 and the one-at-a-time evaluation; a member whose first factorisation
+    fails (no noise, duplicated inputs) takes the jitter schedule alone, as before."""
+    import g3py_amd as g3
+    from g3py_amd import _lib
+    from g3py_amd.device import compile_spec
+    rng = np.random.default_rng(N + B)
+    d = 3
+    X = rng.uniform(0, N ** (1 / d), (N, d))
+    X[1] = X[0]                                    # a duplicated input: singular without noise
+    y = np.sin(X.sum(1) / 2) + 0.1 * rng.standard_normal(N)
+    hyp = [(1.0 + 0.3 * (i % 7) / 7, 0.7 + 0.6 * (i % 5) / 5, 0.05 + 0.1 * (i % 3) / 3) for i in range(B)]
+    hyp[B // 2] = (1.0, 1.0, 0.0)                  # this member needs the jitter schedule
+    progs = [compile_spec(('sum', ('MAT52', v, np.full(d, r), None), ('NOISE', nz)), d) for v, r, nz in hyp]
+    arr = (_lib.KernelProg * B)(*progs)
+    Np = _lib.roundup(N)
+    kstride = (Np + _lib.G3_RHS_PAD) * Np
+    f32 = np.dtype(dtype) == np.float32
+    res = {}
+    for mode in ('coop', 'sweep'):
+        monkeypatch.setenv('G3_COOP_MAX_N', '1024' if mode == 'coop' else '0')
+        monkeypatch.setenv('G3_COOP_MIN_BATCH', '2')
+        monkeypatch.setenv('G3_COOP_GROUP', str(group))
+        dev = g3.Device(0)                         # the knobs are read when a context is created
+        K = dev.alloc(B * (Np + _lib.G3_RHS_PAD), Np, dtype)
+        W = dev.alloc(B * Np, _lib.G3_PAD, dtype)
+        a = dev.alloc(B, Np, dtype)
+        Xd, dd = dev.upload(X.astype(dtype)), dev.upload(np.tile(y, (B, 1)).astype(dtype))
+        st = dev.gp_factor_batched(arr, Xd, N, d, dd, K, kstride, W, a, raw=True)
+        res[mode] = (st.copy(), dev.download(a, B, N).astype(np.float64))
+        if mode == 'coop':
+            K1, a1, W1 = dev.alloc(Np + _lib.G3_RHS_PAD, Np, dtype), dev.alloc(1, Np, dtype), dev.alloc_inverses(Np, dtype)
+            yd = dev.upload(y.astype(dtype))
+            for i in (0, B // 2, B - 1):
+                s1 = dev.gp_factor(progs[i], Xd, N, d, yd, K1, W1, a1)
+                assert abs(s1['logdet'] - st[i, 0]) <= (2e-4 if f32 else 1e-11) * abs(s1['logdet']), (i, s1['logdet'], st[i, 0])
+                assert abs(s1['quad'] - st[i, 1]) <= (2e-3 if f32 else 1e-9) * abs(s1['quad'])
+                assert int(s1['tries']) == int(st[i, 3])
+        dev.close()
+    (sc, ac), (ss, as_) = res['coop'], res['sweep']
+    assert sc[B // 2, 3] >= 1 and np.all(np.delete(sc[:, 3], B // 2) == 0)          # only that member retried
+    np.testing.assert_array_equal(sc[:, 3:], ss[:, 3:])
+    np.testing.assert_allclose(sc[:, :2], ss[:, :2], rtol=2e-4 if f32 else 1e-11)
+    np.testing.assert_allclose(ac, as_, rtol=0, atol=(2e-3 if f32 else 1e-9) * np.abs(as_).max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('N', [96, 700])
 def test_chain_fields_abi_equals_programs_abi(N):
