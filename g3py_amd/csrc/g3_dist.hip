@@ -689,7 +689,26 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
   hipStream_t H[NH] = {nullptr, nullptr, nullptr, nullptr}, L[NL] = {nullptr, nullptr, nullptr, nullptr};
   hipError_t e = hipSuccess;
   for (int i = 0; i < NH && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&H[i], hipStreamNonBlocking, hi);
-  for (int i = 0; i < NL && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&L[i], hipStreamNonBlocking, lo);
+  // From six ranks on the bulk stream may not use 32 of the 256 CUs (mask bit i = CU i div 8 of XCC i mod 8: the first four
+  // CUs of every XCC; G3_DIST_BULK_MASK=n overrides, 0 = none): the chain's and the look-ahead's latency-bound kernels then
+  // find CUs without bulk workgroups.  At P = 8 a rank's own step is ~34 ms but the SERIAL chain of diagonal blocks -- every
+  // block's update + factorisation + inversion on its owner, which no rank can overlap with the next block's -- summed to
+  // 48 ms: that, not the rank, bounds the P-rank step.  With the reservation: rank 35.5 ms, chain 36.3 ms (config 4, replay,
+  // profiles/r05_replay_mask.txt; 48 or 64 CUs cost the bulk more than the chain gains; at P = 4 the rank is the bound and the
+  // reservation costs 7 %: off).  A CU-masked stream cannot carry the low priority; it is still below the two high ones.
+  const int reserve = g3h_env_int("G3_DIST_BULK_MASK", D->world >= 6 ? 32 : 0);
+  if (reserve > 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, D->ctx->device) != hipSuccess) e = hipErrorUnknown;
+    uint32_t mask[16];
+    for (int i = 0; i < 16; ++i) mask[i] = 0xffffffffu;
+    const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
+    if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    for (int b = 0; b < reserve && b < prop.multiProcessorCount; ++b) mask[b / 32] &= ~(1u << (b % 32));
+    for (int i = 0; i < NL && e == hipSuccess; ++i) e = hipExtStreamCreateWithCUMask(&L[i], words, mask);
+  } else {
+    for (int i = 0; i < NL && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&L[i], hipStreamNonBlocking, lo);
+  }
   unsigned* scratch = nullptr;
   if (e == hipSuccess) e = hipMalloc((void**)&scratch, sizeof(unsigned));
   auto cleanup = [&](int kc, int kl, int kb) {
