@@ -186,6 +186,22 @@ extern "C" int g3_ctx_destroy(g3_ctx* ctx) {
   return G3_OK;
 }
 
+// A stream the context has worked on is about to be destroyed by its owner (the multi-GPU driver's chain stream): the caller
+// has synchronised it; forget every reference -- the program ring records its events on the stream a slot was consumed on
+void g3i_ctx_forget_stream(g3_ctx* ctx, hipStream_t s) {
+  if (!ctx || !s) return;
+  if (ctx->prog_stream == s) {
+    for (int i = 0; i < G3_PROG_SLOTS; ++i) ctx->prog_busy[i] = false;
+    ctx->prog_last = -1;
+    ctx->prog_stream = nullptr;
+  }
+  if (ctx->info_stream == s) {
+    ctx->info_clean = false;
+    ctx->info_stream = nullptr;
+  }
+  if (ctx->side_for == s) ctx->side_for = nullptr;
+}
+
 extern "C" int g3_ctx_set_stream(g3_ctx* ctx, void* s) {
   if (!ctx) return -1;
   g3_dev_guard _dg(ctx);

@@ -989,7 +989,11 @@ extern "C" int g3_dist_destroy(g3_dist* D) {
   if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
   if (D->s_look) (void)hipStreamDestroy(D->s_look);
   if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
-  if (D->s_chain) { (void)hipStreamSynchronize(D->s_chain); (void)hipStreamDestroy(D->s_chain); }
+  if (D->s_chain) {
+    (void)hipStreamSynchronize(D->s_chain);
+    g3i_ctx_forget_stream(D->ctx, D->s_chain);      // the caller's context worked on it inside every entry point
+    (void)hipStreamDestroy(D->s_chain);
+  }
   if (D->ev_bracket) (void)hipEventDestroy(D->ev_bracket);
   for (hipStream_t ps : D->pad_streams) (void)hipStreamDestroy(ps);
   delete D;

@@ -147,6 +147,7 @@ static inline int64_t g3_roundup(int64_t n, int64_t m) { return (n + m - 1) / m 
 // a context on the caller's stream that creates no stream of its own; the low-priority side stream on first need
 int g3i_ctx_create_on(int device, hipStream_t stream, g3_ctx** out);
 int g3i_ensure_side_stream(g3_ctx* ctx);
+void g3i_ctx_forget_stream(g3_ctx* ctx, hipStream_t s);     // s (synchronised) is about to be destroyed by its owner
 // latency (us) of a one-wave kernel submitted on `a` while a dispatch-bound launch (its duration in *long_us) runs on `b`
 bool g3i_probe_pair(hipStream_t a, hipStream_t b, unsigned* scratch, double* tiny_us, double* long_us, int reps);
 
