@@ -10,7 +10,7 @@
 #include "g3_host.h"
 #include <stdlib.h>
 
-#define GT 64           // output tile edge
+#define GT 64           // output tile rows
 
 #include "g3_kernel_eval.h"
 
@@ -30,6 +30,9 @@ static __host__ __device__ inline int prog_trig_pairs(const g3_kernel_prog* p) {
 // One workgroup (256 threads) writes a 64-row x 128-column tile; a thread owns two adjacent
 // columns (one 16-byte store per row for fp64: a wave writes 1 KiB of one row per instruction)
 // and every fourth row.
+// Round 5 (profiles/r05_gram.md): the store pattern alone streams at 5.5 TB/s (a dense fill of the same bytes: 5.75);
+// what held the kernel at 3.7 TB/s was the per-element control flow of the loop (see the interior loop below), not the
+// tile shape: 128-row tiles and non-temporal stores were built and measured (+-3 % in the sweep, noisier) and removed.
 #define GTN 128
 // FK: g3_kind of the fast path's stationary term, -1 = generic program; PK: g3_kind of its periodic second term
 // (G3_K_COS, G3_K_SIN, G3_K_SM) or -1.  The sum  stationary + periodic (+ noise)  is the shape of BASELINE config 3's kernel.
@@ -44,6 +47,7 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
   if constexpr (!SE_FAST) prog += blockIdx.z;
   K += (int64_t)blockIdx.z * kstride;
   int64_t bi = blockIdx.y, bj = blockIdx.x;
+  constexpr int gt = GT;
   if (flags & G3_GRAM_LOWER) {
     // 1-D grid over the tiles on or below the diagonal only: row-block b has b/2 + 1 column
     // tiles (64-row, 128-column tiles), prefix q(q+1) + r(q+1) for b = 2q + r
@@ -57,14 +61,14 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
     bi = 2 * q + r;
     bj = rem;
   }
-  const int64_t i0 = bi * GT, j0 = bj * GTN;
+  const int64_t i0 = bi * gt, j0 = bj * GTN;
   if (i0 >= n1pad || j0 >= n2pad) return;
   extern __shared__ __attribute__((aligned(16))) char smem_g[];
   const int dp = d | 1;  // odd row stride: conflict-free column-varying reads
   T* xi_s = reinterpret_cast<T*>(smem_g);
-  T* xj_s = xi_s + GT * dp;
+  T* xj_s = xi_s + gt * dp;
   const int tid = threadIdx.x;
-  for (int e = tid; e < GT * d; e += 256) {
+  for (int e = tid; e < gt * d; e += 256) {
     const int r = e / d, c = e - r * d;
     xi_s[r * dp + c] = (i0 + r < n1) ? X1[(i0 + r) * ldx1 + c] : T(0);
   }
@@ -87,13 +91,13 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
       for (int l = prog->nleaf; l < G3_MAXLEAF; ++l) toff_s[l] = -1;
     }
     __syncthreads();
-    for (int e = tid; e < (GT + GTN) * ntrig; e += 256) {
+    for (int e = tid; e < (gt + GTN) * ntrig; e += 256) {
       const int pnt = e / ntrig, t = e - pnt * ntrig;
       int l = 0;
       while (l + 1 < prog->nleaf && !(toff_s[l] >= 0 && t >= toff_s[l] && t < toff_s[l] + prog->leaf[l].ndims)) ++l;
       const g3_leaf& lf = prog->leaf[l];
       const int k = t - toff_s[l];
-      const T x = (pnt < GT ? xi_s[pnt * dp + lf.dims[k]] : xj_s[(pnt - GT) * dp + lf.dims[k]]);
+      const T x = (pnt < gt ? xi_s[pnt * dp + lf.dims[k]] : xj_s[(pnt - gt) * dp + lf.dims[k]]);
       const T scale = (lf.kind == G3_K_SINC) ? T(2 * G3_PI * G3_PI) : T(2 * G3_PI);
       const T th = scale * (T)lf.freq[k] * x;
       const T sn = sin(th), cs = cos(th);
@@ -104,9 +108,9 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
   constexpr int FTS = 2 * D + 1;        // fast path: [cos, sin] of 2 pi freq_k x_k per point, odd row stride
   if constexpr (SE_FAST && PK >= 0) {
     __syncthreads();
-    for (int e = tid; e < (GT + GTN) * D; e += 256) {
+    for (int e = tid; e < (gt + GTN) * D; e += 256) {
       const int pnt = e / D, k = e - pnt * D;
-      const T x = pnt < GT ? xi_s[pnt * dp + k] : xj_s[(pnt - GT) * dp + k];
+      const T x = pnt < gt ? xi_s[pnt * dp + k] : xj_s[(pnt - gt) * dp + k];
       const T th = se.f[k] * x;
       trig_s[pnt * FTS + 2 * k] = cos(th);
       trig_s[pnt * FTS + 2 * k + 1] = sin(th);
@@ -125,7 +129,7 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
 #pragma unroll
     for (int c = 0; c < D; ++c) { xra[c] = xja[c]; xrb[c] = xjb[c]; }
     if constexpr (PK >= 0) {
-      const T* ta = trig_s + (GT + 2 * tx) * FTS;
+      const T* ta = trig_s + (gt + 2 * tx) * FTS;
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         cja[c] = ta[2 * c]; sja[c] = ta[2 * c + 1];
@@ -136,8 +140,100 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
   const bool scr = (flags & G3_GRAM_SCRUB) != 0;
   const bool eye = (flags & G3_GRAM_PAD_EYE) != 0;
   const bool vec_ok = two && ((ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(K) & (2 * sizeof(T) - 1)) == 0);
+  typedef T vec2 __attribute__((ext_vector_type(2)));
+  // the fast path's value for (tile row rr, column ja + q): var * k(d) [+ | *] the periodic term; no noise, no scrub
+  auto fast_value = [&](int rr, int q) -> T {
+    const T* xi = xi_s + rr * dp;
+    T dd = T(0);
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const T dx = xi[c] - (q ? xrb[c] : xra[c]);
+      if constexpr (FK == G3_K_OU) dd += fabs(dx) * se.w[c];      // metrics.py:89-91
+      else dd += (dx * dx) * se.w[c];                             // metrics.py:100-102
+    }
+    T kv;
+    if constexpr (FK == G3_K_MAT32) {
+      const T s3 = sqrt(T(3) * dd);
+      kv = (T(1) + s3) * g3_exp(-s3);
+    } else if constexpr (FK == G3_K_MAT52) {
+      const T s5 = sqrt(T(5) * dd);
+      kv = (T(1) + s5 + dd * T(5.0 / 3.0)) * g3_exp(-s5);
+    } else if constexpr (FK == G3_K_RQ) {
+      kv = pow(T(1) + dd / se.alpha, -se.alpha);
+    } else {
+      kv = g3_exp(-dd);
+    }
+    T val = se.var * kv;
+    if constexpr (PK >= 0) {
+      const T* ti = trig_s + rr * FTS;
+      T pr = T(1), sm = T(0);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {   // cos(theta_i - theta_j), angle-difference identity (as the generic path)
+        const T cd = ti[2 * c] * (q ? cjb[c] : cja[c]) + ti[2 * c + 1] * (q ? sjb[c] : sja[c]);
+        if constexpr (PK == G3_K_SIN) {
+          sm += (T(0.5) * (T(1) - cd)) * se.pr[c];            // sin^2(pi f dx) = (1 - cos(2 pi f dx)) / 2, kernels.py:471-472
+        } else {
+          pr *= cd;                                           // COS, SM: kernels.py:466-467, 486-487
+          if constexpr (PK == G3_K_SM) {
+            const T dx = xi[c] - (q ? xrb[c] : xra[c]);
+            sm += (dx * dx) * se.pr[c];
+          }
+        }
+      }
+      T pv;
+      if constexpr (PK == G3_K_COS) pv = se.pvar * pr;
+      else if constexpr (PK == G3_K_SIN) pv = se.pvar * exp(T(2) * sm);   // positive exponent, as written in the reference
+      else pv = se.pvar * (exp(T(-2 * G3_PI * G3_PI) * sm) * pr);
+      val = se.mul ? val * pv : val + pv;       // KernelProd (the locally periodic form) or KernelSum
+    }
+    return val;
+  };
+  if constexpr (SE_FAST) {
+    // Interior tiles (every row and column inside the matrix: all but the last tile row / column) take a loop without
+    // per-element control flow -- up to four rows x two columns of independent exp chains in flight, the noise added by a
+    // select and only in tiles the diagonal crosses, tt_to_num as ONE test per eight values (non-finite values are the
+    // exception).  The per-element branches of the general loop below serialise those chains: SE, d = 4, N = 32768 in the
+    // headline step 1.15 ms (3.7 TB/s) -> 0.86 ms (5.0 TB/s; profiles/r05_gram.md).  Same formulas in the same order (the compiler places its fused multiply-adds per loop: equal to rounding).
+    if (vec_ok && i0 + gt <= n1 && j0 + GTN <= n2) {
+      const int64_t dlo = i0 + diag_off;
+      const bool touches = sym && dlo < j0 + GTN && j0 < dlo + gt;      // (uniform)
+      // rows in flight per thread: four, fewer where the periodic term's cos / sin registers (4 D) leave no room
+      constexpr int UR = PK < 0 ? 4 : (D <= 2 ? 2 : 1);
+      for (int r0 = ty; r0 < gt; r0 += 4 * UR) {
+        T v[UR][2];
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) v[u][q] = fast_value(r0 + 4 * u, q);
+        if (touches) {
+#pragma unroll
+          for (int u = 0; u < UR; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) v[u][q] += (dlo + r0 + 4 * u == ja + q) ? se.noise : T(0);
+        }
+        if (scr) {
+          bool bad = false;
+#pragma unroll
+          for (int u = 0; u < UR; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bad |= !__builtin_isfinite(v[u][q]);
+          if (bad) {
+#pragma unroll
+            for (int u = 0; u < UR; ++u)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) v[u][q] = scrub(v[u][q]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+          *reinterpret_cast<vec2*>(K + (i0 + r0 + 4 * u) * ldk + ja) = vec2{v[u][0], v[u][1]};
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll 4
-  for (int rr = ty; rr < GT; rr += 4) {
+  for (int rr = ty; rr < gt; rr += 4) {
     const int64_t i = i0 + rr;
     if (i >= n1pad) break;
     T v[2];
@@ -147,54 +243,12 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
       if (i < n1 && j < n2) {
         const bool dg = sym && (i + diag_off == j);   // diag_off: row offset of a row block of a square matrix
         if (SE_FAST) {
-          const T* xi = xi_s + rr * dp;
-          T dd = T(0);
-#pragma unroll
-          for (int c = 0; c < D; ++c) {
-            const T dx = xi[c] - (q ? xrb[c] : xra[c]);
-            if constexpr (FK == G3_K_OU) dd += fabs(dx) * se.w[c];      // metrics.py:89-91
-            else dd += (dx * dx) * se.w[c];                             // metrics.py:100-102
-          }
-          T kv;
-          if constexpr (FK == G3_K_MAT32) {
-            const T s3 = sqrt(T(3) * dd);
-            kv = (T(1) + s3) * g3_exp(-s3);
-          } else if constexpr (FK == G3_K_MAT52) {
-            const T s5 = sqrt(T(5) * dd);
-            kv = (T(1) + s5 + dd * T(5.0 / 3.0)) * g3_exp(-s5);
-          } else if constexpr (FK == G3_K_RQ) {
-            kv = pow(T(1) + dd / se.alpha, -se.alpha);
-          } else {
-            kv = g3_exp(-dd);
-          }
-          v[q] = se.var * kv;
-          if constexpr (PK >= 0) {
-            const T* ti = trig_s + rr * FTS;
-            T pr = T(1), sm = T(0);
-#pragma unroll
-            for (int c = 0; c < D; ++c) {   // cos(theta_i - theta_j), angle-difference identity (as the generic path)
-              const T cd = ti[2 * c] * (q ? cjb[c] : cja[c]) + ti[2 * c + 1] * (q ? sjb[c] : sja[c]);
-              if constexpr (PK == G3_K_SIN) {
-                sm += (T(0.5) * (T(1) - cd)) * se.pr[c];            // sin^2(pi f dx) = (1 - cos(2 pi f dx)) / 2, kernels.py:471-472
-              } else {
-                pr *= cd;                                           // COS, SM: kernels.py:466-467, 486-487
-                if constexpr (PK == G3_K_SM) {
-                  const T dx = xi[c] - (q ? xrb[c] : xra[c]);
-                  sm += (dx * dx) * se.pr[c];
-                }
-              }
-            }
-            T pv;
-            if constexpr (PK == G3_K_COS) pv = se.pvar * pr;
-            else if constexpr (PK == G3_K_SIN) pv = se.pvar * exp(T(2) * sm);   // positive exponent, as written in the reference
-            else pv = se.pvar * (exp(T(-2 * G3_PI * G3_PI) * sm) * pr);
-            v[q] = se.mul ? v[q] * pv : v[q] + pv;       // KernelProd (the locally periodic form) or KernelSum
-          }
+          v[q] = fast_value(rr, q);
           if (dg) v[q] += se.noise;
         } else {
           if (ntrig > 0)
             v[q] = prog_eval<T>(prog, xi_s + rr * dp, q ? xjb : xja, dg, sym != 0, trig_s + rr * tstride,
-                                trig_s + (GT + 2 * tx + q) * tstride, toff_s);
+                                trig_s + (gt + 2 * tx + q) * tstride, toff_s);
           else
             v[q] = prog_eval<T>(prog, xi_s + rr * dp, q ? xjb : xja, dg, sym != 0);
         }
@@ -205,7 +259,6 @@ gram_kernel(const g3_kernel_prog* __restrict__ prog, SeParams<T, D> se, const T*
     }
     T* p = K + i * ldk + ja;
     if (vec_ok) {
-      typedef T vec2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<vec2*>(p) = vec2{v[0], v[1]};
     } else {
       p[0] = v[0];

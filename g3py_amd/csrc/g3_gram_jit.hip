@@ -189,6 +189,44 @@ g3_gram_jit(const jprog* __restrict__ prog, const T* __restrict__ X1, i64 n1, i6
   for (int c = 0; c < JD; ++c) { xra[c] = xj_s[(2 * tx) * dp + c]; xrb[c] = xj_s[(2 * tx + 1) * dp + c]; }
   const bool scr = (flags & 2u) != 0, eye = (flags & 4u) != 0;
   const bool vec_ok = two && ((ldk & 1) == 0) && ((reinterpret_cast<unsigned long long>(K) & (2 * sizeof(T) - 1)) == 0);
+  typedef T vec2 __attribute__((ext_vector_type(2)));
+  if (vec_ok && i0 + GT <= n1 && j0 + GTN <= n2) {
+    // interior tile: no per-element control flow (g3_gram.hip::gram_kernel, round 5) -- two rows x two columns of
+    // independent evaluations in flight, the diagonal test only in tiles the diagonal crosses, tt_to_num as one test
+    // per four values.  Same formulas as the general loop below (equal to rounding).
+    const i64 dlo = i0 + diag_off;
+    const bool touches = sym && dlo < j0 + GTN && j0 < dlo + GT;        // (uniform)
+    auto rows = [&](const bool on_diag) __attribute__((always_inline)) {
+      for (int r0 = ty; r0 < GT; r0 += 8) {
+        T v[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int rr = r0 + 4 * u;
+            const bool dg = on_diag && (dlo + rr == ja + q);
+            v[u][q] = prog_eval(prog, xi_s + rr * dp, q ? xrb : xra, dg, sym != 0, trig_s + rr * tstride, trig_s + (GT + 2 * tx + q) * tstride);
+          }
+        if (scr) {
+          bool bad = false;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bad |= !__builtin_isfinite(v[u][q]);
+          if (bad) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) v[u][q] = scrub(v[u][q]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<vec2*>(K + (i0 + r0 + 4 * u) * ldk + ja) = vec2{v[u][0], v[u][1]};
+      }
+    };
+    if (touches) rows(true); else rows(false);
+    return;
+  }
   for (int rr = ty; rr < GT; rr += 4) {
     const i64 i = i0 + rr;
     if (i >= n1pad) break;
@@ -206,7 +244,6 @@ g3_gram_jit(const jprog* __restrict__ prog, const T* __restrict__ X1, i64 n1, i6
     }
     T* p = K + i * ldk + ja;
     if (vec_ok) {
-      typedef T vec2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<vec2*>(p) = vec2{v[0], v[1]};
     } else {
       p[0] = v[0];

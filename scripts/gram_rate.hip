@@ -34,8 +34,8 @@ __device__ __forceinline__ double exp_fast(double x) {
   return x != x ? x : v;
 }
 
-template <int MATH, int NT, int TR>
-__global__ void __launch_bounds__(256) gram_se(const double* __restrict__ X, int64_t n, double* __restrict__ K, int64_t ldk,
+template <int MATH, int NT, int TR, int NTH = 256, int UNR = 4>
+__global__ void __launch_bounds__(NTH) gram_se(const double* __restrict__ X, int64_t n, double* __restrict__ K, int64_t ldk,
                                                double w0, double w1, double w2, double w3, double var, double noise) {
   constexpr int D = 4, GTN = 128, DP = 5;
   constexpr int RB = TR / 64;   // 64-row units per tile: a tile on the diagonal band spans RB * 64 rows
@@ -50,17 +50,22 @@ __global__ void __launch_bounds__(256) gram_se(const double* __restrict__ X, int
     const int64_t r = rem >= q + 1 ? 1 : 0;
     if (r) rem -= q + 1;
     bi = 2 * q + r; bj = rem;
-  } else {   // TR == 128: row b has b + 1 tiles
+  } else if (TR == 128) {   // row b has b + 1 tiles
     int64_t q = (int64_t)((sqrt(1.0 + 8.0 * (double)id) - 1.0) * 0.5);
     while ((q + 1) * (q + 2) / 2 <= id) ++q;
     while (q * (q + 1) / 2 > id) --q;
     bi = q; bj = id - q * (q + 1) / 2;
+  } else {                  // TR == 256: row b has 2 b + 2 tiles
+    int64_t q = (int64_t)((sqrt(1.0 + 4.0 * (double)id) - 1.0) * 0.5);
+    while ((q + 1) * (q + 2) <= id) ++q;
+    while (q * (q + 1) > id) --q;
+    bi = q; bj = id - q * (q + 1);
   }
   const int64_t i0 = bi * TR, j0 = bj * GTN;
   __shared__ double xi_s[TR * DP], xj_s[GTN * DP];
   const int tid = threadIdx.x;
-  for (int e = tid; e < TR * D; e += 256) { const int r = e / D, c = e - r * D; xi_s[r * DP + c] = X[(i0 + r) * D + c]; }
-  for (int e = tid; e < GTN * D; e += 256) { const int r = e / D, c = e - r * D; xj_s[r * DP + c] = X[(j0 + r) * D + c]; }
+  for (int e = tid; e < TR * D; e += NTH) { const int r = e / D, c = e - r * D; xi_s[r * DP + c] = X[(i0 + r) * D + c]; }
+  for (int e = tid; e < GTN * D; e += NTH) { const int r = e / D, c = e - r * D; xj_s[r * DP + c] = X[(j0 + r) * D + c]; }
   __syncthreads();
   const int tx = tid & 63, ty = tid >> 6;
   const int64_t ja = j0 + 2 * tx;
@@ -68,8 +73,8 @@ __global__ void __launch_bounds__(256) gram_se(const double* __restrict__ X, int
   const double w[4] = {w0, w1, w2, w3};
 #pragma unroll
   for (int c = 0; c < D; ++c) { xa[c] = xj_s[2 * tx * DP + c]; xb[c] = xj_s[(2 * tx + 1) * DP + c]; }
-#pragma unroll 4
-  for (int rr = ty; rr < TR; rr += 4) {
+#pragma unroll UNR
+  for (int rr = ty; rr < TR; rr += NTH / 64) {
     const int64_t i = i0 + rr;
     double v[2];
 #pragma unroll
@@ -132,17 +137,22 @@ int main(int argc, char** argv) {
   const int64_t t64 = n / 64, q = t64 / 2, tiles64 = q * (q + 1);
   const int64_t t128 = n / 128, tiles128 = t128 * (t128 + 1) / 2;
   printf("N = %lld, lower triangle %.3f GB; 64x128 tiles %lld, 128x128 tiles %lld\n", (long long)n, gb, (long long)tiles64, (long long)tiles128);
-#define RUN(M, NTV, TRV)                                                                                              \
+#define RUN4(M, NTV, TRV, NTHV, UNRV)                                                                                  \
   {                                                                                                                   \
-    const int64_t g = (TRV == 64) ? tiles64 : tiles128;                                                               \
-    const double ms = time_ms([&] { hipLaunchKernelGGL((gram_se<M, NTV, TRV>), dim3((unsigned)g), dim3(256), 0, 0, X, n, K, n,      \
+    const int64_t g = (TRV == 64) ? tiles64 : (TRV == 128 ? tiles128 : (n / 256) * (n / 256 + 1));                     \
+    const double ms = time_ms([&] { hipLaunchKernelGGL((gram_se<M, NTV, TRV, NTHV, UNRV>), dim3((unsigned)g), dim3(NTHV), 0, 0, X, n, K, n, \
                                                        0.5, 0.4, 0.3, 0.2, 1.3, 0.1); }, 10);                          \
-    printf("math %d nt %d rows %3d: %.3f ms  %.2f TB/s\n", M, NTV, TRV, ms, gb / ms);                                 \
+    printf("math %d nt %d rows %3d threads %d unroll %d: %.3f ms  %.2f TB/s\n", M, NTV, TRV, NTHV, UNRV, ms, gb / ms);  \
   }
+#define RUN(M, NTV, TRV) RUN4(M, NTV, TRV, 256, 4)
   RUN(0, 0, 64) RUN(1, 0, 64) RUN(2, 0, 64)
   RUN(0, 1, 64) RUN(1, 1, 64) RUN(2, 1, 64)
   RUN(0, 0, 128) RUN(1, 0, 128) RUN(2, 0, 128)
   RUN(0, 1, 128) RUN(1, 1, 128) RUN(2, 1, 128)
+  RUN(0, 0, 256) RUN(0, 1, 256) RUN(1, 1, 256)
+  RUN4(0, 0, 128, 512, 4) RUN4(0, 1, 128, 512, 4) RUN4(0, 0, 256, 512, 4) RUN4(0, 1, 256, 512, 4)
+  RUN4(0, 0, 128, 256, 8) RUN4(0, 1, 128, 256, 8) RUN4(0, 0, 128, 256, 2) RUN4(0, 1, 128, 256, 2)
+  RUN4(0, 0, 256, 256, 8) RUN4(0, 1, 256, 256, 8) RUN4(0, 0, 128, 128, 4) RUN4(0, 1, 128, 128, 4)
   const int64_t nvec = (int64_t)(0.5 * n * (n + 1)) / 2;
   for (int blocks : {1024, 4096, 16384}) {
     double ms = time_ms([&] { hipLaunchKernelGGL((fill<0>), dim3(blocks), dim3(256), 0, 0, K, nvec); }, 10);

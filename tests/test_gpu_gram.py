@@ -78,6 +78,61 @@ def test_gram_ragged_sizes_and_padding(dev, n):
     np.testing.assert_allclose(np.tril(Kl[:n, :n]), np.tril(orc.kernel_cov(spec, X)), rtol=1e-13)
 
 
+def test_gram_interior_tiles_equal_edge_tiles_and_the_oracle(dev):
+    """round 5 (profiles/r05_gram.md): tiles that lie wholly inside the matrix take a loop without per-element control flow
+    (noise by select in the tiles the diagonal crosses, tt_to_num as one test per eight values).  The same elements
+    computed by the interior loop (even leading dimension, N = 391: six full tile rows, three full tile columns) and by
+    the general loop (odd leading dimension: no paired stores, so every tile takes it) agree to rounding -- same
+    formulas, but the compiler places its fused multiply-adds per loop: 1e-14 in fp64, the fp32 tolerance in fp32 --
+    and both equal the oracle; a NaN input inside an interior tile is scrubbed as tensors.py:90-92 prescribes; the
+    row-block entry point of the multi-GPU driver puts the noise on the TRUE diagonal"""
+    import ctypes as C
+    import g3py_amd._lib as lib
+    from g3py_amd.device import compile_spec
+    from oracle import g3_oracle as orc
+    rng = np.random.default_rng(5)
+    n, m = 391, 100
+    for d, spec in ((4, orc.with_noise(('SE', 1.3, np.linspace(0.6, 1.4, 4), None), 0.1)),
+                    (2, orc.with_noise(('sum', ('MAT52', 1.0, np.array([0.7, 1.1]), None),
+                                        ('COS', 0.5, np.array([0.2, 0.3]), None)), 0.2)),
+                    (8, orc.with_noise(('sum', ('MAT52', 1.0, np.linspace(0.5, 1.2, 8), None),
+                                        ('COS', 0.5, np.full(8, 0.125), None)), 0.1)),
+                    (3, ('OU', 0.8, np.array([0.5, 1.0, 1.5]), None))):
+        X, Xs = rng.uniform(0, 3, (n, d)), rng.uniform(0, 3, (200, d))
+        pad = lib.roundup(n)
+        for dtype, tol in ((np.float64, 1e-12), (np.float32, 3e-4)):
+            before = dev.gram_path_stats()['table']
+            same = dict(rtol=1e-14, atol=1e-15) if dtype == np.float64 else dict(rtol=tol, atol=tol * 0.1)
+            big, small = _gram(dev, spec, X, dtype=dtype), _gram(dev, spec, X[:m], dtype=dtype)    # ld = 391: general loop
+            np.testing.assert_array_equal(big[:m, :m], small)
+            np.testing.assert_allclose(big, orc.kernel_cov(spec, X), rtol=tol, atol=tol * 0.1)
+            cross = _gram(dev, spec, Xs, X, dtype=dtype)
+            np.testing.assert_allclose(cross, orc.kernel_cov(spec, Xs, X), rtol=tol, atol=tol * 0.1)
+            even = _gram(dev, spec, X, dtype=dtype, pad=pad)[:n, :n]                                # ld = 512: interior loop
+            np.testing.assert_allclose(even, big, **same)
+            np.testing.assert_allclose(even, orc.kernel_cov(spec, X), rtol=tol, atol=tol * 0.1)
+            np.testing.assert_array_equal(even[:128, :128], _gram(dev, spec, X[:128], dtype=dtype))  # N = 128: interior loop too
+            low = _gram(dev, spec, X, dtype=dtype, flags=lib.G3_GRAM_LOWER | lib.G3_GRAM_PAD_EYE | lib.G3_GRAM_SCRUB, pad=pad)
+            np.testing.assert_array_equal(np.tril(low[:n, :n]), np.tril(even))
+            np.testing.assert_array_equal(low[n:, n:], np.eye(pad - n))
+            assert dev.gram_path_stats()['table'] == before + 6       # all of it on the compile-time table
+        # a NaN input in the middle of an interior tile: row / column 70 of the covariance are NaN -> 0 (tt_to_num)
+        Xn = X.copy()
+        Xn[70, 0] = np.nan
+        with np.errstate(all='ignore'):
+            ref = orc.tt_to_num(orc.kernel_cov(spec, Xn))
+        got = _gram(dev, spec, Xn, flags=lib.G3_GRAM_SCRUB, pad=pad)[:n, :n]
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+        assert not got[70, :70].any() and np.isnan(_gram(dev, spec, Xn, pad=pad)[70, 3])
+        # rows [128, 256) of the square covariance through g3_gram_rows (noise where i + row0 == j)
+        prog = compile_spec(spec, d)
+        A = dev.upload(X)
+        out = dev.alloc(128, 256, np.float64, zero=True)
+        assert dev.lib.g3_gram_rows(dev.ctx, C.byref(prog), A.ptr, n, A.ld, d, 128, 128, lib.dtype_code(np.float64), out.ptr, out.ld,
+                                    lib.G3_GRAM_PAD_EYE) == 0
+        np.testing.assert_array_equal(dev.download(out), _gram(dev, spec, X, pad=pad)[128:256, :256])
+
+
 def test_gram_scrub_fuses_tt_to_num(dev):
     import g3py_amd._lib as lib
     from oracle import g3_oracle as orc
