@@ -457,6 +457,10 @@ def main():
     spec_n = ('sum', spec_f, ('NOISE', 0.1))
     npdt = np.float32 if args.f32 else np.float64
     tdt = torch.float32 if args.f32 else torch.float64
+    # G3_BENCH_IDLE_STREAMS=n: n pairs of idle streams created first -- a different stream history of the process, hence a
+    # different placement of the library's streams on hardware queues (A/B measurements of the placement probe)
+    _idle = [torch.cuda.Stream(device=torch.device('cuda', local_rank), priority=pr)
+             for _ in range(int(os.environ.get('G3_BENCH_IDLE_STREAMS', '0'))) for pr in (-1, 0)]
     dev = g3.Device(local_rank)
     # the critical-path stream gets high priority; the library's side stream (bulk updates) is low
     hp = torch.cuda.Stream(device=tdev0, priority=-1) if os.environ.get('G3_BENCH_HIPRIO', '1') == '1' else None
