@@ -53,6 +53,35 @@ __global__ void __launch_bounds__(512, 4) k_diag128(T* A, int64_t ld, T* W, int*
   }
 }
 
+// the SAME 128-block program run R times inside one launch (fresh data each time): the first pass fetches its 43 KB of
+// instructions from memory, later passes find them in the instruction cache -- is instruction fetch part of the 29 us?
+template <typename T>
+__global__ void __launch_bounds__(512, 4) k_diag128_rep(T* A, int64_t ld, T* W, int* info, int64_t a_batch, int64_t w_batch, int reps, unsigned long long* ts) {
+  __shared__ DiagLds<T> S;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = wv < 4 ? wv : 11 - wv;
+#pragma nounroll
+  for (int r = 0; r < reps; ++r) {
+    __syncthreads();
+    if (threadIdx.x == 0) ts[2 * r] = wall_clock64();
+    T* Ar = A + (int64_t)r * a_batch;
+    T* Wr = W + (int64_t)r * w_batch;
+    switch (w) {
+      case 0: diag128_wave<T, true, 0>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      case 1: diag128_wave<T, true, 1>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      case 2: diag128_wave<T, true, 2>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      case 3: diag128_wave<T, true, 3>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      case 4: diag128_wave<T, true, 4>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      case 5: diag128_wave<T, true, 5>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      case 6: diag128_wave<T, true, 6>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+      default: diag128_wave<T, true, 7>(Ar, ld, Wr, G3_LB, info, 0, S, lane); break;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ts[2 * r + 1] = wall_clock64();
+  }
+}
+
 int main() {
   const int n = 256, BMAX = 2048;
   std::vector<double> h((size_t)n * n);
@@ -98,6 +127,22 @@ int main() {
       hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost);
       printf("  B = %4d: %8.1f us per launch  (%.2f workgroups per CU; %.1f us per member and CU)  info %d\n", B, best * 1e3, B / 256.0,
              best * 1e3 / (B > 256 ? B / 256.0 : 1.0), hinfo);
+    }
+  }
+  {
+    const int R = 6;
+    unsigned long long* ts;
+    hipMalloc(&ts, 2 * R * sizeof(unsigned long long));
+    for (int trial = 0; trial < 3; ++trial) {
+      for (int b = 0; b < R; ++b) hipMemcpyAsync(A + (size_t)b * n * n, A0, (size_t)n * n * 8, hipMemcpyDeviceToDevice, 0);
+      hipDeviceSynchronize();
+      hipLaunchKernelGGL(k_diag128_rep<double>, dim3(1), dim3(512), 0, 0, A, (int64_t)n, W, info, (int64_t)n * n, (int64_t)2 * 128 * 128, R, ts);
+      hipDeviceSynchronize();
+      unsigned long long h[2 * R];
+      hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
+      printf("diag128 program run %d times inside one launch (100 MHz clock), us per pass:", R);
+      for (int r = 0; r < R; ++r) printf(" %.2f", (double)(h[2 * r + 1] - h[2 * r]) * 0.01);
+      printf("\n");
     }
   }
   return 0;
