@@ -16,7 +16,6 @@ cases = [('SE+noise d=4 N=32768 lower', ('sum', ('SE', 1.0, np.ones(4), None), (
          ('SE+noise d=16 N=16384 lower', ('sum', ('SE', 1.0, np.ones(16), None), ('NOISE', 0.1)), 16384, 16, True),
          ('SE+noise d=4 N=8192 lower (config 2)', ('sum', ('SE', 1.0, np.ones(4), None), ('NOISE', 0.1)), 8192, 4, True),
          ('SE+noise d=16 N=65536 lower fp32 (config 5 shape)', ('sum', ('SE', 1.0, np.ones(16), None), ('NOISE', 0.1)), 65536, 16, True, np.float32)]
-print('G3_GRAM_TALL_MIN=%s G3_GRAM_NT_MIN_MB=%s' % (os.environ.get('G3_GRAM_TALL_MIN', 'default'), os.environ.get('G3_GRAM_NT_MIN_MB', 'default')))
 for case in cases:
     name, spec, N, d, lower = case[:5]
     npdt = case[5] if len(case) > 5 else np.float64
