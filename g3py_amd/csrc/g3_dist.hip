@@ -379,8 +379,14 @@ struct AsyncCallbackTransport : Transport {
 struct g3_dist {
   g3_ctx* ctx = nullptr;        // chain stream (the caller's context)
   g3_ctx* ctx_look = nullptr;   // look-ahead stream: its own context, so no scratch / info flag is shared
-  g3_ctx* ctx_bulk = nullptr;   // bulk stream
+  g3_ctx* ctx_bulk = nullptr;   // bulk stream (the one the current plan uses: plain or CU-masked, see g3_dist_plan)
   hipStream_t s_look = nullptr, s_bulk = nullptr;
+  // From six ranks on the driver holds TWO bulk streams, one barred from 32 CUs (pick_streams) and one plain, each with its
+  // context; a plan takes the masked one only where the serial diagonal chain would otherwise outlast the rank's own step
+  hipStream_t s_bulk_alt[2] = {nullptr, nullptr};      // [0] plain low-priority, [1] CU-masked (nullptr: not created)
+  g3_ctx* ctx_bulk_alt[2] = {nullptr, nullptr};
+  int bulk_mask_mode = 0;                              // G3_DIST_BULK_MASK_MODE: 0 by plan (default), 1 always, -1 never
+  int bulk_masked = 0;                                 // what the current plan took
   // The chain runs on a stream of the DRIVER (not the caller's), created back to back with the other two: which hardware
   // queue -- and which of the chip's compute pipes -- a stream lands on is decided by creation order, and the same replayed
   // rank measured 36.9 or 42.1 ms (config 4, P = 8, one box) depending on how many streams the process had created before
@@ -685,18 +691,21 @@ static int do_allreduce(g3_dist* D, double* host, int n, int op) {
 // first of each (G3_DIST_PROBE_LOG=1 prints the matrix).
 // picks (chain, look, bulk) out of freshly created candidates; on any failure falls back to the first of each
 static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
-  const int NH = 4, NL = 4;
-  hipStream_t H[NH] = {nullptr, nullptr, nullptr, nullptr}, L[NL] = {nullptr, nullptr, nullptr, nullptr};
+  const int NH = 4, NL = 8, NLP = 4;      // low candidates 0 .. NLP-1: plain low priority; NLP .. NL-1: CU-masked (if any)
+  hipStream_t H[NH] = {nullptr, nullptr, nullptr, nullptr}, L[NL] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipError_t e = hipSuccess;
   for (int i = 0; i < NH && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&H[i], hipStreamNonBlocking, hi);
-  // From six ranks on the bulk stream may not use 32 of the 256 CUs (mask bit i = CU i div 8 of XCC i mod 8: the first four
-  // CUs of every XCC; G3_DIST_BULK_MASK=n overrides, 0 = none): the chain's and the look-ahead's latency-bound kernels then
-  // find CUs without bulk workgroups.  At P = 8 a rank's own step is ~34 ms but the SERIAL chain of diagonal blocks -- every
-  // block's update + factorisation + inversion on its owner, which no rank can overlap with the next block's -- summed to
-  // 48 ms: that, not the rank, bounds the P-rank step.  With the reservation: rank 35.5 ms, chain 36.3 ms (config 4, replay,
-  // profiles/r05_replay_mask.txt; 48 or 64 CUs cost the bulk more than the chain gains; at P = 4 the rank is the bound and the
-  // reservation costs 7 %: off).  A CU-masked stream cannot carry the low priority; it is still below the two high ones.
+  // From six ranks on a bulk stream exists that may not use 32 of the 256 CUs (mask bit i = CU i div 8 of XCC i mod 8: the
+  // first four CUs of every XCC; G3_DIST_BULK_MASK=n overrides, 0 = none): the chain's and the look-ahead's latency-bound
+  // kernels then find CUs without bulk workgroups.  At P = 8 a rank's own step is ~34 ms (config 4) but the SERIAL chain of
+  // diagonal blocks -- every block's update + factorisation + inversion on its owner, which no rank can overlap with the next
+  // block's -- summed to 48 ms: that, not the rank, bounds the P-rank step.  With the reservation: rank 35.5 ms, chain 36.3 ms
+  // (replay, profiles/r05_replay_mask.txt; 48 or 64 CUs cost the bulk more than the chain gains; at P = 4 the rank is the
+  // bound and the reservation costs 7 %).  Where the rank's step is far longer than the chain (config 5's shape: 137 against
+  // 59 ms) the reservation only costs, so a PLAN chooses (g3_dist_plan) between this stream and a plain one.  A CU-masked
+  // stream cannot carry the low priority; it is still below the two high ones.
   const int reserve = g3h_env_int("G3_DIST_BULK_MASK", D->world >= 6 ? 32 : 0);
+  for (int i = 0; i < NLP && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&L[i], hipStreamNonBlocking, lo);
   if (reserve > 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, D->ctx->device) != hipSuccess) e = hipErrorUnknown;
@@ -705,19 +714,17 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
     const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
     if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
     for (int b = 0; b < reserve && b < prop.multiProcessorCount; ++b) mask[b / 32] &= ~(1u << (b % 32));
-    for (int i = 0; i < NL && e == hipSuccess; ++i) e = hipExtStreamCreateWithCUMask(&L[i], words, mask);
-  } else {
-    for (int i = 0; i < NL && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&L[i], hipStreamNonBlocking, lo);
+    for (int i = NLP; i < NL && e == hipSuccess; ++i) e = hipExtStreamCreateWithCUMask(&L[i], words, mask);
   }
   unsigned* scratch = nullptr;
   if (e == hipSuccess) e = hipMalloc((void**)&scratch, sizeof(unsigned));
-  auto cleanup = [&](int kc, int kl, int kb) {
+  auto cleanup = [&](int kc, int kl, int kb, int kb2) {
     for (int i = 0; i < NH; ++i) if (H[i] && i != kc && i != kl) (void)hipStreamDestroy(H[i]);
-    for (int i = 0; i < NL; ++i) if (L[i] && i != kb) (void)hipStreamDestroy(L[i]);
+    for (int i = 0; i < NL; ++i) if (L[i] && i != kb && i != kb2) (void)hipStreamDestroy(L[i]);
     if (scratch) (void)hipFree(scratch);
   };
-  if (e != hipSuccess) { cleanup(-1, -1, -1); return G3_ERR_HIP; }
-  int kc = 0, kl = 1, kb = 0;
+  if (e != hipSuccess) { cleanup(-1, -1, -1, -1); return G3_ERR_HIP; }
+  int kc = 0, kl = 1, kb = 0, kbm = reserve > 0 ? NLP : -1;     // kb: the plain bulk stream; kbm: the masked one
   const bool probe = g3h_env_int("G3_DIST_PROBE", 1) != 0, log = g3h_env_int("G3_DIST_PROBE_LOG", 0) != 0;
   hipStream_t user = D->ctx->stream;
   if (probe) {
@@ -733,6 +740,7 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
     for (int i = 0; i <= NH && ok; ++i) {
       hipStream_t a = i < NH ? H[i] : user;
       for (int j = 0; j < NL && ok; ++j) {
+        if (!L[j]) { th[i][j] = 0; continue; }
         ok = g3i_probe_pair(a, L[j], scratch, &t_us, &l_us, 2);
         th[i][j] = t_us;
         lmean += l_us; ++nl;
@@ -751,8 +759,8 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
     const double limit = base * 2.0 > base + 40.0 ? base * 2.0 : base + 40.0;
     for (int i = 0; i <= NH && ok; ++i) {
       for (int j = 0; j < NL; ++j) {
-        hl[i][j] = th[i][j] > limit;
-        if (log) fprintf(stderr, "libg3hip placement: high %d / low %d: small kernel %.0f us beside a %.0f us dispatch-bound launch%s\n", i, j,
+        hl[i][j] = L[j] != nullptr && th[i][j] > limit;
+        if (log && L[j]) fprintf(stderr, "libg3hip placement: high %d / low %d: small kernel %.0f us beside a %.0f us dispatch-bound launch%s\n", i, j,
                          th[i][j], lmean, hl[i][j] ? (th[i][j] > 0.5 * lmean ? "  <- same queue" : "  <- same pipe") : "");
       }
       for (int j = 0; j <= NH; ++j) {
@@ -763,23 +771,37 @@ static int pick_streams(g3_dist* D, int lo, int hi, bool own_chain) {
     }
     if (ok) {
       // chain candidates: the driver's own (0 .. NH-1) or the caller's stream (NH); fewest conflicts wins, first in order on ties
+      // the two high streams together with the best plain AND the best masked bulk candidate for them: a plan may take either
       int bestc = 1 << 30;
-      for (int b = 0; b < NL; ++b)
-        for (int c = own_chain ? 0 : NH; c <= (own_chain ? NH - 1 : NH); ++c)
-          for (int l = 0; l < NH; ++l) {
-            if (l == c) continue;
-            const int conflicts = 4 * (int)hl[c][b] + 4 * (int)hl[l][b] + (int)(hh[c][l] || hh[l][c]);
-            if (conflicts < bestc) { bestc = conflicts; kc = c; kl = l; kb = b; }
+      for (int c = own_chain ? 0 : NH; c <= (own_chain ? NH - 1 : NH); ++c)
+        for (int l = 0; l < NH; ++l) {
+          if (l == c) continue;
+          int bp = 0, cp = 1 << 30, bm = -1, cm = 0;
+          for (int b = 0; b < NLP; ++b) {
+            const int k = 4 * (int)hl[c][b] + 4 * (int)hl[l][b];
+            if (k < cp) { cp = k; bp = b; }
           }
-      if (log) fprintf(stderr, "libg3hip placement: chain = high %d%s, look-ahead = high %d, bulk = low %d (%d conflicts)\n", kc,
-                       kc == NH ? " (caller's stream)" : "", kl, kb, bestc);
+          if (reserve > 0) {
+            cm = 1 << 30;
+            for (int b = NLP; b < NL; ++b) {
+              const int k = 4 * (int)hl[c][b] + 4 * (int)hl[l][b];
+              if (k < cm) { cm = k; bm = b; }
+            }
+          }
+          const int conflicts = cp + cm + (int)(hh[c][l] || hh[l][c]);
+          if (conflicts < bestc) { bestc = conflicts; kc = c; kl = l; kb = bp; kbm = bm; }
+        }
+      if (log) fprintf(stderr, "libg3hip placement: chain = high %d%s, look-ahead = high %d, bulk = low %d, masked bulk = %d (%d conflicts)\n", kc,
+                       kc == NH ? " (caller's stream)" : "", kl, kb, kbm, bestc);
     }
   }
   if (!own_chain) kc = NH;
   D->s_chain = kc < NH ? H[kc] : nullptr;
   D->s_look = H[kl];
-  D->s_bulk = L[kb];
-  cleanup(kc, kl, kb);
+  D->s_bulk_alt[0] = L[kb];
+  D->s_bulk_alt[1] = kbm >= 0 ? L[kbm] : nullptr;
+  D->s_bulk = D->s_bulk_alt[0];
+  cleanup(kc, kl, kb, kbm);
   return G3_OK;
 }
 
@@ -821,12 +843,14 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&D->info_dev, sizeof(int));
   int rc = e == hipSuccess ? G3_OK : G3_ERR_HIP;
   if (!rc) rc = g3i_ctx_create_on(ctx->device, D->s_look, &D->ctx_look);
-  if (!rc) rc = g3i_ctx_create_on(ctx->device, D->s_bulk, &D->ctx_bulk);
+  for (int i = 0; i < 2 && !rc; ++i)
+    if (D->s_bulk_alt[i]) rc = g3i_ctx_create_on(ctx->device, D->s_bulk_alt[i], &D->ctx_bulk_alt[i]);
+  D->ctx_bulk = D->ctx_bulk_alt[0];
   if (rc) {
     if (D->ctx_look) g3_ctx_destroy(D->ctx_look);
-    if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
+    for (int i = 0; i < 2; ++i) if (D->ctx_bulk_alt[i]) g3_ctx_destroy(D->ctx_bulk_alt[i]);
     if (D->s_look) (void)hipStreamDestroy(D->s_look);
-    if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
+    for (int i = 0; i < 2; ++i) if (D->s_bulk_alt[i]) (void)hipStreamDestroy(D->s_bulk_alt[i]);
     if (D->s_chain) (void)hipStreamDestroy(D->s_chain);
     if (D->ev_bracket) (void)hipEventDestroy(D->ev_bracket);
     for (hipStream_t ps : D->pad_streams) (void)hipStreamDestroy(ps);
@@ -840,7 +864,12 @@ static int dist_common(g3_ctx* ctx, int rank, int world, g3_dist** out) {
     const char* dl = getenv("G3_DIST_DEAL");
     D->deal_snake = (dl && !strcmp(dl, "snake")) ? 1 : 0;
   }
-  D->ctx_bulk->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
+  for (int i = 0; i < 2; ++i)
+    if (D->ctx_bulk_alt[i]) D->ctx_bulk_alt[i]->bulk_role = true;     // its small-tile launches leave room on every CU for the chain's kernels (g3_gemm.hip)
+  {
+    const char* mm = getenv("G3_DIST_BULK_MASK_MODE");
+    D->bulk_mask_mode = !mm ? 0 : (!strcmp(mm, "always") ? 1 : (!strcmp(mm, "never") ? -1 : 0));
+  }
   *out = D;
   return G3_OK;
 }
@@ -980,15 +1009,15 @@ extern "C" int g3_dist_destroy(g3_dist* D) {
   g3_dev_guard _dg(D->ctx);
   (void)hipStreamSynchronize(D->ctx->stream);
   if (D->s_look) (void)hipStreamSynchronize(D->s_look);
-  if (D->s_bulk) (void)hipStreamSynchronize(D->s_bulk);
+  for (int i = 0; i < 2; ++i) if (D->s_bulk_alt[i]) (void)hipStreamSynchronize(D->s_bulk_alt[i]);
   delete D->tr;            // communicators first: their kernels are done
   free_plan(D);
   for (hipEvent_t e : D->tev) (void)hipEventDestroy(e);
   if (D->info_dev) (void)hipFree(D->info_dev);
   if (D->ctx_look) g3_ctx_destroy(D->ctx_look);
-  if (D->ctx_bulk) g3_ctx_destroy(D->ctx_bulk);
+  for (int i = 0; i < 2; ++i) if (D->ctx_bulk_alt[i]) g3_ctx_destroy(D->ctx_bulk_alt[i]);
   if (D->s_look) (void)hipStreamDestroy(D->s_look);
-  if (D->s_bulk) (void)hipStreamDestroy(D->s_bulk);
+  for (int i = 0; i < 2; ++i) if (D->s_bulk_alt[i]) (void)hipStreamDestroy(D->s_bulk_alt[i]);
   if (D->s_chain) {
     (void)hipStreamSynchronize(D->s_chain);
     g3i_ctx_forget_stream(D->ctx, D->s_chain);      // the caller's context worked on it inside every entry point
@@ -1020,6 +1049,19 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   D->N = N; D->d = d; D->M = M; D->nb = nb; D->dt = dt; D->es = g3_esize(dt);
   D->Np = g3_roundup(N, nb);
   D->nblk = (int)(D->Np / nb);
+  {
+    // Which bulk stream: the CU-masked one (32 CUs left to the chain's kernels) where the serial diagonal chain -- N / nb
+    // blocks of ~1.5 ms (fp64) / ~1.2 ms (fp32) each beside an unmasked bulk stream -- would outlast the rank's own
+    // N^3 / (3 P) flops at ~52 (fp64) / ~100 (fp32) TFLOP/s: config 4 on 8 ranks yes (48 against 34 ms), config 5's shape no
+    // (59 against 137 ms).  Both figures from the replays of profiles/r05_replay_*; G3_DIST_BULK_MASK_MODE=always|never overrides.
+    const double chain_s = (double)D->nblk * (dt == G3_F64 ? 1.5e-3 : 1.2e-3);
+    const double rank_s = (double)N * (double)N * (double)N / (3.0 * D->world) / (dt == G3_F64 ? 52e12 : 100e12);
+    const bool want = D->bulk_mask_mode > 0 || (D->bulk_mask_mode == 0 && chain_s > rank_s);
+    const int pick = (want && D->s_bulk_alt[1] && D->bulk_mask_mode >= 0) ? 1 : 0;
+    D->s_bulk = D->s_bulk_alt[pick];
+    D->ctx_bulk = D->ctx_bulk_alt[pick];
+    D->bulk_masked = pick;
+  }
   D->Mp = g3_roundup(M, 128);
   D->nchunk = 1 + (int)(D->Mp / 128);
   D->my_blocks.clear(); D->my_chunks.clear();
@@ -1949,8 +1991,12 @@ extern "C" int g3_dist_phase_stats(g3_dist* D, double out_host[4]) {
 
 extern "C" int g3_dist_prof_enable(g3_dist* D, int on) {
   if (!D) return -1;
-  int rc = g3_prof_enable(D->ctx_bulk, on);
-  if (!rc) rc = g3_prof_reset(D->ctx_bulk);
+  int rc = G3_OK;
+  for (int i = 0; i < 2 && !rc; ++i)
+    if (D->ctx_bulk_alt[i]) {
+      rc = g3_prof_enable(D->ctx_bulk_alt[i], on);
+      if (!rc) rc = g3_prof_reset(D->ctx_bulk_alt[i]);
+    }
   return rc;
 }
 extern "C" int g3_dist_prof_collect(g3_dist* D, double* out_host) {

@@ -29,7 +29,7 @@ spec_f = ('SE', 1.0, np.ones(d), None)
 from oracle import g3_oracle as orc          # (only for the noise wrapper of the kernel spec: no arithmetic)
 spec_n = orc.with_noise(spec_f, 0.1)
 flops = bench.step_flops(N, M)
-KNOBS = ('G3_DIST_FULLINV', 'G3_GEMM_BIG_MIN_K', 'G3_GEMM_BIG_MIN', 'G3_TRSM_THIN_MAX', 'G3_SIDE_LDS', 'G3_DIST_DEAL', 'R5_IDLE', 'G3_DIST_OWN_CHAIN', 'G3_DIST_PAD_STREAMS', 'G3_DIST_BULK_MASK')
+KNOBS = ('G3_DIST_FULLINV', 'G3_GEMM_BIG_MIN_K', 'G3_GEMM_BIG_MIN', 'G3_TRSM_THIN_MAX', 'G3_SIDE_LDS', 'G3_DIST_DEAL', 'R5_IDLE', 'G3_DIST_OWN_CHAIN', 'G3_DIST_PAD_STREAMS', 'G3_DIST_BULK_MASK', 'G3_DIST_BULK_MASK_MODE')
 
 
 def env_of(name):
@@ -47,6 +47,8 @@ def env_of(name):
             e['G3_DIST_OWN_CHAIN'] = '0'
         elif part.startswith('pad'):
             e['G3_DIST_PAD_STREAMS'] = part[3:]
+        elif part in ('maskalways', 'masknever'):   # which bulk stream a plan takes (default: by plan, g3_dist_plan)
+            e['G3_DIST_BULK_MASK_MODE'] = part[4:]
         elif part.startswith('mask'):
             e['G3_DIST_BULK_MASK'] = part[4:]
         elif part == 'snake':
