@@ -1050,11 +1050,11 @@ extern "C" int g3_dist_plan(g3_dist* D, int64_t N, int d, int64_t M, int64_t nb,
   D->Np = g3_roundup(N, nb);
   D->nblk = (int)(D->Np / nb);
   {
-    // Which bulk stream: the CU-masked one (32 CUs left to the chain's kernels) where the serial diagonal chain -- N / nb
-    // blocks of ~1.5 ms (fp64) / ~1.2 ms (fp32) each beside an unmasked bulk stream -- would outlast the rank's own
+    // Which bulk stream: the CU-masked one (32 CUs left to the chain's kernels) where the serial diagonal chain -- N / 1024
+    // times ~1.5 ms (fp64) / ~1.2 ms (fp32) beside an unmasked bulk stream (measured at nb = 1024) -- would outlast the rank's own
     // N^3 / (3 P) flops at ~52 (fp64) / ~100 (fp32) TFLOP/s: config 4 on 8 ranks yes (48 against 34 ms), config 5's shape no
     // (59 against 137 ms).  Both figures from the replays of profiles/r05_replay_*; G3_DIST_BULK_MASK_MODE=always|never overrides.
-    const double chain_s = (double)D->nblk * (dt == G3_F64 ? 1.5e-3 : 1.2e-3);
+    const double chain_s = (double)D->Np / 1024.0 * (dt == G3_F64 ? 1.5e-3 : 1.2e-3);   // (latency-bound: ~ proportional to nb per block)
     const double rank_s = (double)N * (double)N * (double)N / (3.0 * D->world) / (dt == G3_F64 ? 52e12 : 100e12);
     const bool want = D->bulk_mask_mode > 0 || (D->bulk_mask_mode == 0 && chain_s > rank_s);
     const int pick = (want && D->s_bulk_alt[1] && D->bulk_mask_mode >= 0) ? 1 : 0;
